@@ -1,0 +1,200 @@
+/*
+ * drude_tgnh.h -- C ABI of the MI355X (gfx950) DrudeTGNHIntegrator step kernel.
+ *
+ * This is the drop-in boundary: what an OpenMM-HIP `KernelImpl` for
+ * `IntegrateDrudeTGNHStepKernel` (reference: openmmapi/include/openmm/DrudeTGNHKernels.h:48-74)
+ * binds to.  Plain C types only; the caller owns the particle buffers (OpenMM's
+ * posq / velm / force / posDelta device arrays), the library owns topology,
+ * scratch and thermostat state.  All work is enqueued on the caller's HIP
+ * stream; functions named *_get_* that return host values synchronise that
+ * stream, nothing else does.  One handle per device; handles are not
+ * thread-safe.  Every function returns a tgnh_status; tgnh_last_error() has
+ * the message (the OpenMM glue turns it into an OpenMMException).
+ *
+ * Reference interfaces replaced (file:line in scychon/openmm_drudeNose):
+ *   tgnh_create            IntegrateDrudeTGNHStepKernel::initialize
+ *                          platforms/cuda/src/CudaDrudeTGNHKernels.cpp:75-282,
+ *                          platforms/reference/src/ReferenceDrudeTGNHKernels.cpp:104-219
+ *   tgnh_step_begin/_end   IntegrateDrudeTGNHStepKernel::execute
+ *                          CudaDrudeTGNHKernels.cpp:284-408 split at the force call-out (:380);
+ *                          ReferenceDrudeTGNHKernels.cpp:221-415 split at :384
+ *   tgnh_get_kinetic_energy  ::computeKineticEnergy  CudaDrudeTGNHKernels.cpp:654-661,
+ *                          ReferenceDrudeTGNHKernels.cpp:586-588
+ *   tgnh_set_*             values the reference re-reads from the integrator every
+ *                          step (CudaDrudeTGNHKernels.cpp:292,298,437-439,469)
+ *   tgnh_destroy           ~CudaIntegrateDrudeTGNHStepKernel  CudaDrudeTGNHKernels.cpp:52-73
+ */
+#ifndef DRUDE_TGNH_H_
+#define DRUDE_TGNH_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGNH_ABI_VERSION 1
+
+typedef int tgnh_status;
+enum {
+    TGNH_OK = 0,
+    TGNH_ERR_ARG = -1,            /* bad argument / size */
+    TGNH_ERR_GROUP_MISMATCH = -2, /* CudaDrudeTGNHKernels.cpp:145-146, :192-193 */
+    TGNH_ERR_HARDWALL = -3,       /* ReferenceDrudeTGNHKernels.cpp:311-312 */
+    TGNH_ERR_UNSUPPORTED = -4,    /* topology the fused tile path cannot hold */
+    TGNH_ERR_HIP = -5,            /* a HIP runtime call failed */
+    TGNH_ERR_STATE = -6           /* call order (buffers not bound, ...) */
+};
+
+/* Semantic mode: the two platform implementations differ. */
+enum { TGNH_MODE_DUALNH = 0,      /* platforms/reference semantics */
+       TGNH_MODE_TGNH = 1 };      /* platforms/cuda semantics (temperature groups + COM) */
+
+/* OpenMM precision modes: real = posq type, mixed = velm/posDelta type. */
+enum { TGNH_PREC_SINGLE = 0,      /* float4 posq, float4 velm */
+       TGNH_PREC_MIXED = 1,       /* float4 posq + float4 posqCorrection, double4 velm */
+       TGNH_PREC_DOUBLE = 2 };    /* double4 posq, double4 velm */
+
+/* flags for tgnh_desc.flags */
+enum { TGNH_FLAG_MERGE_SCALE_KE = 1,   /* fuse the end-of-step rescale with the next step's KE pass */
+       TGNH_FLAG_DEFER_SCALE = 2 };    /* apply the end-of-step rescale lazily */
+
+typedef struct tgnh_desc {
+    uint32_t struct_size;         /* sizeof(tgnh_desc), ABI check */
+    int32_t mode;                 /* TGNH_MODE_* */
+    int32_t precision;            /* TGNH_PREC_* */
+    int32_t flags;                /* TGNH_FLAG_* */
+    int32_t device;               /* HIP device ordinal */
+    int32_t num_particles;        /* N: particle slots owned by this handle */
+    int32_t padded_num_particles; /* stride of the 3 force planes (OpenMM PADDED_NUM_ATOMS), >= N */
+    int32_t num_pairs;            /* P: Drude pairs, DrudeForce order */
+    int32_t num_groups;           /* G: getNumTempGroups() (TGNH mode) */
+    int32_t num_residues;         /* R: getNumResidues()   (TGNH mode) */
+    int32_t num_constraints;
+    int32_t has_cm_motion_remover;
+    const double* mass;           /* [N] System::getParticleMass */
+    const int32_t* pair_drude;    /* [P] DrudeForce::getParticleParameters p  */
+    const int32_t* pair_parent;   /* [P] DrudeForce::getParticleParameters p1 */
+    const int32_t* group;         /* [N] getParticleTempGroup (TGNH mode; may be NULL in DUALNH) */
+    const int32_t* resid;         /* [N] getParticleResId     (TGNH mode; may be NULL in DUALNH) */
+    const int32_t* constraint_i;  /* [num_constraints] or NULL */
+    const int32_t* constraint_j;
+    double kB;                    /* OpenMM BOLTZ, kJ/mol/K */
+    double temperature, coupling_time;
+    double drude_temperature, drude_coupling_time;
+    double step_size;
+    int32_t drude_steps_per_real_step;
+    int32_t num_nh_chains;
+    int32_t use_drude_nh_chains;
+    int32_t use_com_temp_group;
+    double max_drude_distance;    /* 0 = hard wall off */
+} tgnh_desc;
+
+typedef struct tgnh_context* tgnh_handle;
+
+/* Collective hook for particle-sharded runs: in-place sum of `count` doubles
+ * at device pointer `buf` over all ranks, enqueued on `stream` (an RCCL
+ * ncclAllReduce in the glue / a torch.distributed all_reduce in the harness).
+ * Must not synchronise the host. */
+typedef int (*tgnh_allreduce_fn)(void* buf, int count, void* stream, void* user);
+
+const char* tgnh_last_error(void);
+int tgnh_abi_version(void);
+
+tgnh_status tgnh_create(const tgnh_desc* desc, tgnh_handle* out);
+tgnh_status tgnh_destroy(tgnh_handle h);
+
+/* OpenMM device arrays (raw device pointers).  posq_correction only in MIXED
+ * mode, pos_delta only for the constrained (split) path; pass NULL otherwise.
+ *   posq   real4  [N]  (x,y,z,q)
+ *   velm   mixed4 [N]  (vx,vy,vz,1/m)   -- w is read as the inverse mass
+ *   force  int64  [3*padded]  fixed point x 2^32, planes x|y|z
+ *   pos_delta mixed4 [N] */
+tgnh_status tgnh_bind_buffers(tgnh_handle h, void* posq, void* posq_correction, void* velm,
+                              const void* force, void* pos_delta);
+
+/* Integrator scalars re-read every step by the reference. */
+tgnh_status tgnh_set_step_size(tgnh_handle h, double dt);
+tgnh_status tgnh_set_drude_steps_per_real_step(tgnh_handle h, int n);
+tgnh_status tgnh_set_max_drude_distance(tgnh_handle h, double d);
+
+/* Particle sharding: dof terms are additive over ranks.  terms = per-thermostat
+ * degrees of freedom before the global CMMotionRemover correction
+ * (DUALNH: 2 values; TGNH: G+2).  Sum them over ranks and hand them back. */
+tgnh_status tgnh_get_local_dof_terms(tgnh_handle h, double* terms, int* count);
+tgnh_status tgnh_set_global_dof_terms(tgnh_handle h, const double* terms, int count);
+tgnh_status tgnh_set_allreduce(tgnh_handle h, tgnh_allreduce_fn fn, void* user);
+
+/* One time step, split at the force call-out:
+ *   begin: [KE -> chain ->] rescale, half kick, drift, hard wall
+ *   (caller: virtual sites, calcForcesAndEnergy)
+ *   end:   half kick, KE -> chain -> rescale, time += dt */
+tgnh_status tgnh_step_begin(tgnh_handle h, void* stream);
+tgnh_status tgnh_step_end(tgnh_handle h, void* stream);
+/* Split variants around OpenMM's constraint call-outs (posDelta path):
+ *   begin_kick:  [KE -> chain ->] rescale, half kick, posDelta = dt*v        (CudaDrudeTGNHKernels.cpp:336-360)
+ *   (caller: applyConstraints on posDelta)
+ *   begin_move:  pos += posDelta, v = posDelta/dt, hard wall                 (:366-376)
+ *   end_kick:    half kick                                                   (:384-388)
+ *   (caller: applyVelocityConstraints)
+ *   end_thermo:  KE -> chain -> rescale, time += dt                          (:394-406) */
+tgnh_status tgnh_step_begin_kick(tgnh_handle h, void* stream);
+tgnh_status tgnh_step_begin_move(tgnh_handle h, void* stream);
+tgnh_status tgnh_step_end_kick(tgnh_handle h, void* stream);
+tgnh_status tgnh_step_end_thermo(tgnh_handle h, void* stream);
+/* Apply any rescale still pending (TGNH_FLAG_DEFER_SCALE) so velm is the
+ * reference's end-of-step state; call before anything else reads velm. */
+tgnh_status tgnh_flush(tgnh_handle h, void* stream);
+/* Velocities were changed behind the integrator's back (setVelocities, CMMotionRemover,
+ * barostat): cached kinetic energies are stale.  DrudeTGNHIntegrator.cpp:166-170 */
+tgnh_status tgnh_state_changed(tgnh_handle h);
+
+/* Host-visible results (synchronise `stream`). */
+tgnh_status tgnh_get_kinetic_energy(tgnh_handle h, int ke_sum_valid, void* stream, double* out);
+tgnh_status tgnh_get_num_thermostats(tgnh_handle h, int* count);               /* DUALNH 2, TGNH G+2 */
+tgnh_status tgnh_get_last_kinetic_energies(tgnh_handle h, void* stream, double* ke);   /* no 1/2; before the chain */
+tgnh_status tgnh_get_last_scale_factors(tgnh_handle h, void* stream, double* scale);
+tgnh_status tgnh_get_status_flags(tgnh_handle h, void* stream, uint32_t* flags);   /* bit0: Drude beyond 2x hard wall */
+tgnh_status tgnh_get_time(tgnh_handle h, double* time, int64_t* step_count);
+tgnh_status tgnh_get_dof(tgnh_handle h, double* dof, double* nkt);
+
+/* Thermostat state (checkpoint/resume, absent in the reference: SURVEY.md 5).
+ * which: 0 eta, 1 etaDot, 2 etaDotDot, 3 etaMass.  Layout: DUALNH = the
+ * reference's interleaved vectors; TGNH = [thermostat][link], etaDot rows of C+1. */
+tgnh_status tgnh_get_thermostat_len(tgnh_handle h, int which, int* len);
+tgnh_status tgnh_get_thermostat_state(tgnh_handle h, int which, void* stream, double* out);
+tgnh_status tgnh_set_thermostat_state(tgnh_handle h, int which, void* stream, const double* in);
+
+/* Topology the kernels were built from, for bit-exact index parity (A1).
+ * which: 0 normalParticles, 1 pair drude, 2 pair parent, 3 particleTempGroup,
+ * 4 particleResId, 5 particlesInResidues.count, 6 particlesInResidues.first,
+ * 7 tile starts (num_tiles+1), 8 packed per-slot meta words. */
+tgnh_status tgnh_get_topology_len(tgnh_handle h, int which, int* len);
+tgnh_status tgnh_get_topology(tgnh_handle h, int which, int32_t* out);
+
+/* Pieces of the step, exposed for parity tests of the single kernels. */
+tgnh_status tgnh_compute_kinetic_energies(tgnh_handle h, void* stream);          /* A3/A4 only -> last_kinetic_energies */
+tgnh_status tgnh_half_kick(tgnh_handle h, void* stream);                         /* A7 only */
+
+/* Harness force (bench/test workload, not part of the reference): Drude spring
+ * + tether to sites x0 (mixed4 [N] device array), written in OpenMM's
+ * fixed-point layout into `force_out` (int64 [3*padded]). */
+tgnh_status tgnh_harness_force(tgnh_handle h, const void* x0, double k_drude, double k_tether,
+                               void* force_out, void* stream);
+/* nsteps x { step_begin, harness force into the bound force buffer, step_end }
+ * enqueued back to back with no host synchronisation. */
+tgnh_status tgnh_run_harness(tgnh_handle h, const void* x0, double k_drude, double k_tether,
+                             int nsteps, void* stream);
+
+/* Per-kernel launch statistics gathered with HIP events on `stream` while
+ * enabled (bench.py's live roofline).  kernel: 0 scale+kick+drift, 1 kick+KE,
+ * 2 rescale(+KE), 3 KE, 4 chain, 5 harness force. */
+tgnh_status tgnh_timing_enable(tgnh_handle h, int on);
+tgnh_status tgnh_timing_read(tgnh_handle h, int kernel, double* total_ms, int64_t* launches);
+/* Algorithmic HBM bytes of one launch of `kernel` (SURVEY.md 8d model: state arrays only). */
+tgnh_status tgnh_algorithmic_bytes(tgnh_handle h, int kernel, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,850 @@
+// tgnh_host.cpp -- host side of the C ABI (include/drude_tgnh.h): topology and
+// tile construction (A1), degrees of freedom and thermostat masses (A2), step
+// orchestration (A11) and the queries.  Kernels live in tgnh_kernels.hip.
+//
+// Reference semantics followed (scychon/openmm_drudeNose):
+//   Ref = platforms/reference/src/ReferenceDrudeTGNHKernels.cpp
+//   Cu  = platforms/cuda/src/CudaDrudeTGNHKernels.cpp
+//   API = openmmapi/src/DrudeTGNHIntegrator.cpp
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "tgnh_internal.h"
+
+using namespace tgnh;
+
+static thread_local std::string g_err;
+extern "C" const char* tgnh_last_error(void) { return g_err.c_str(); }
+extern "C" int tgnh_abi_version(void) { return TGNH_ABI_VERSION; }
+
+static tgnh_status fail(tgnh_status code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_OK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(TGNH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+#define CHECK_H(h)                                                 \
+    do {                                                           \
+        if (!(h)) return fail(TGNH_ERR_ARG, "null handle");        \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// A1: topology + tiles
+// ---------------------------------------------------------------------------
+static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
+    const int N = d->num_particles, P = d->num_pairs;
+    const bool tg = d->mode == TGNH_MODE_TGNH;
+    const bool com = tg && d->use_com_temp_group;
+    c->mass.assign(d->mass, d->mass + N);
+    c->pair_drude.assign(d->pair_drude, d->pair_drude + P);
+    c->pair_parent.assign(d->pair_parent, d->pair_parent + P);
+    if (d->group) c->group.assign(d->group, d->group + N); else c->group.assign(N, 0);
+    if (d->resid) c->resid.assign(d->resid, d->resid + N); else c->resid.clear();
+
+    // pair membership; normalParticles = ascending indices in no pair (Ref :113-137, Cu :111-151)
+    std::vector<int> role(N, (int)ROLE_NORMAL), partner(N, -1);
+    for (int i = 0; i < P; i++) {
+        const int p = c->pair_drude[i], p1 = c->pair_parent[i];
+        if (p < 0 || p >= N || p1 < 0 || p1 >= N || p == p1) return fail(TGNH_ERR_ARG, "Drude pair index out of range");
+        if (partner[p] != -1 || partner[p1] != -1)
+            return fail(TGNH_ERR_UNSUPPORTED, "a particle belongs to more than one Drude pair");
+        if (c->mass[p] == 0.0 || c->mass[p1] == 0.0)
+            return fail(TGNH_ERR_UNSUPPORTED, "massless Drude particle or parent (the reference's pair arithmetic divides by it)");
+        role[p] = ROLE_DRUDE; role[p1] = ROLE_PARENT;
+        partner[p] = p1; partner[p1] = p;
+        if (tg && c->group[p] != c->group[p1])                                // Cu :145-146
+            return fail(TGNH_ERR_GROUP_MISMATCH, "Temperature group for drude particle must be the same as the parent particle");
+    }
+    c->normal.clear();
+    for (int i = 0; i < N; i++) if (role[i] == (int)ROLE_NORMAL) c->normal.push_back(i);
+    if (tg) {
+        for (int i = 0; i < N; i++)
+            if (c->group[i] < 0 || c->group[i] >= d->num_groups) return fail(TGNH_ERR_ARG, "temperature group index out of range");
+        if (d->num_groups > MAX_GROUPS)
+            return fail(TGNH_ERR_UNSUPPORTED, "more than 8 temperature groups are not supported by this build");
+        for (int i = 0; i < d->num_constraints; i++) {                        // Cu :186-193
+            if (!d->constraint_i || !d->constraint_j) break;
+            const int a = d->constraint_i[i], b = d->constraint_j[i];
+            if (a < 0 || a >= N || b < 0 || b >= N) return fail(TGNH_ERR_ARG, "constraint index out of range");
+            if (c->group[a] != c->group[b])
+                return fail(TGNH_ERR_GROUP_MISMATCH, "Temperature group of constrained particles must be the same");
+        }
+    }
+
+    // residue table (count, first) as the reference builds it (Cu :87-89, :119-125)
+    const int R = tg ? d->num_residues : 0;
+    c->res_count.assign(R, 0);
+    c->res_first.assign(R, -1);
+    std::vector<int> res_order;        // residues in order of first appearance (internal index)
+    std::vector<int> res_internal(R, -1);
+    if (tg) {
+        if ((int)c->resid.size() != N) return fail(TGNH_ERR_ARG, "TGNH mode needs resid[N]");
+        int prev = -1;
+        for (int i = 0; i < N; i++) {
+            const int r = c->resid[i];
+            if (r < 0 || r >= R) return fail(TGNH_ERR_ARG, "residue index out of range");
+            c->res_count[r] += 1;
+            if (prev != r) {
+                if (com && c->res_first[r] != -1)
+                    return fail(TGNH_ERR_UNSUPPORTED, "particles of a residue are not contiguous");
+                c->res_first[r] = i;
+                if (res_internal[r] == -1) { res_internal[r] = (int)res_order.size(); res_order.push_back(r); }
+                prev = r;
+            }
+        }
+    }
+
+    // allowed tile cuts: never through a pair, never through a residue when the COM is needed
+    std::vector<int> forbid(N + 2, 0);
+    for (int i = 0; i < P; i++) {
+        const int lo = std::min(c->pair_drude[i], c->pair_parent[i]), hi = std::max(c->pair_drude[i], c->pair_parent[i]);
+        forbid[lo + 1] += 1; forbid[hi + 1] -= 1;
+    }
+    if (com) {
+        for (int r : res_order) {
+            const int lo = c->res_first[r], hi = lo + c->res_count[r] - 1;
+            forbid[lo + 1] += 1; forbid[hi + 1] -= 1;
+        }
+    }
+    for (int i = 1; i <= N + 1; i++) forbid[i] += forbid[i - 1];
+    std::vector<int> res_starts_before(N + 1, 0);      // # residues whose first slot < i
+    if (com) {
+        std::vector<char> is_start(N, 0);
+        for (int r : res_order) is_start[c->res_first[r]] = 1;
+        for (int i = 0; i < N; i++) res_starts_before[i + 1] = res_starts_before[i] + is_start[i];
+    }
+    int align = 1;
+    if (const char* e = getenv("TGNH_TILE_ALIGN")) { align = atoi(e); if (align < 1) align = 1; }
+    c->tile_start.clear(); c->tile_res.clear();
+    int start = 0;
+    while (start < N) {
+        int end = std::min(start + TILE_SLOTS, N);
+        auto ok = [&](int e) {
+            if (e < N && forbid[e] > 0) return false;
+            if (com && res_starts_before[e] - res_starts_before[start] > TILE_RES) return false;
+            return true;
+        };
+        while (end > start && !ok(end)) end--;
+        if (end == start)
+            return fail(TGNH_ERR_UNSUPPORTED, "a Drude pair or molecule spans more than one 512-slot tile");
+        if (align > 1 && end < N) {           // prefer a cut on an `align`-slot boundary close by
+            for (int e = end; e > start && e > end - 64; e--)
+                if (e % align == 0 && ok(e)) { end = e; break; }
+        }
+        c->tile_start.push_back(start);
+        c->tile_res.push_back(com ? res_starts_before[start] : 0);
+        start = end;
+    }
+    c->tile_start.push_back(N);
+    c->tile_res.push_back(com ? res_starts_before[N] : 0);
+    c->num_tiles = (int)c->tile_start.size() - 1;
+
+    // packed per-slot words
+    c->meta.assign(N, 0);
+    {
+        int t = 0;
+        for (int i = 0; i < N; i++) {
+            while (i >= c->tile_start[t + 1]) t++;
+            int local_res = 0;
+            if (com) local_res = res_internal[c->resid[i]] - c->tile_res[t];
+            int off = 0;
+            if (partner[i] >= 0) {
+                off = partner[i] - i;
+                if (partner[i] < c->tile_start[t] || partner[i] >= c->tile_start[t + 1] || off < -1024 || off > 1023)
+                    return fail(TGNH_ERR_UNSUPPORTED, "internal: Drude partner outside its tile");
+            }
+            c->meta[i] = pack_meta((uint32_t)role[i], (uint32_t)c->group[i], off, (uint32_t)local_res);
+        }
+    }
+    // device copies
+    HIP_OK(hipMalloc(&c->d_meta, sizeof(uint32_t) * std::max(N, 1)));
+    HIP_OK(hipMemcpy(c->d_meta, c->meta.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc(&c->d_tile_start, sizeof(int) * c->tile_start.size()));
+    HIP_OK(hipMemcpy(c->d_tile_start, c->tile_start.data(), sizeof(int) * c->tile_start.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc(&c->d_tile_res, sizeof(int) * c->tile_res.size()));
+    HIP_OK(hipMemcpy(c->d_tile_res, c->tile_res.data(), sizeof(int) * c->tile_res.size(), hipMemcpyHostToDevice));
+    std::vector<int2> rt(std::max<size_t>(res_order.size(), 1));
+    for (size_t k = 0; k < res_order.size(); k++) rt[k] = make_int2(c->res_count[res_order[k]], c->res_first[res_order[k]]);
+    HIP_OK(hipMalloc(&c->d_res_table, sizeof(int2) * rt.size()));
+    HIP_OK(hipMemcpy(c->d_res_table, rt.data(), sizeof(int2) * rt.size(), hipMemcpyHostToDevice));
+    return TGNH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// A2: degrees of freedom (additive local terms) and thermostat block
+// ---------------------------------------------------------------------------
+static void local_dof_terms(tgnh_context* c) {
+    const tgnh_desc& d = c->d;
+    const int N = d.num_particles, P = d.num_pairs;
+    const int NT = c->L.NT;
+    c->local_terms.assign(NT, 0.0);
+    if (d.mode == TGNH_MODE_DUALNH) {
+        double real = 0;
+        for (int i = 0; i < N; i++) real += (c->mass[i] == 0.0 ? 0 : 3);      // Ref :119
+        real -= 3.0 * P;                                                      // Ref :133
+        real -= d.num_constraints;                                            // Ref :157
+        c->local_terms[0] = real;
+        c->local_terms[2] = 3.0 * P;                                          // Ref :134
+        return;
+    }
+    const int G = d.num_groups, R = d.num_residues;
+    std::vector<double> resInv(R, 0.0);                                       // API :147-153
+    {
+        std::vector<double> rm(R, 0.0);
+        for (int i = 0; i < N; i++) rm[c->resid[i]] += c->mass[i];
+        for (int r = 0; r < R; r++) resInv[r] = 1.0 / rm[r];
+    }
+    std::vector<double> dof(G, 0.0), red(G, 0.0);
+    for (int i = 0; i < N; i++) {                                             // Cu :126-133
+        if (c->mass[i] != 0.0) {
+            dof[c->group[i]] += 3;
+            if (d.use_com_temp_group) red[c->group[i]] += 3 * c->mass[i] * resInv[c->resid[i]];
+        }
+    }
+    for (int i = 0; i < P; i++) dof[c->group[c->pair_drude[i]]] -= 3;         // Cu :148
+    for (int i = 0; i < d.num_constraints; i++) {                             // Cu :195
+        if (d.constraint_i) dof[c->group[d.constraint_i[i]]] -= 1; else dof[0] -= 1;
+    }
+    for (int g = 0; g < G; g++) c->local_terms[g] = dof[g] - red[g];          // Cu :219
+    c->local_terms[G] = d.use_com_temp_group ? 3.0 * R : 0.0;                 // Cu :197-199
+    c->local_terms[G + 1] = 3.0 * P;                                          // Cu :149, :201
+}
+
+static tgnh_status finalize_thermostat(tgnh_context* c) {
+    const tgnh_desc& d = c->d;
+    ChainLayout& L = c->L;
+    const int NT = L.NT, C = L.C;
+    c->dof = c->global_terms;
+    if (d.has_cm_motion_remover) {
+        if (d.mode == TGNH_MODE_DUALNH) c->dof[0] -= 3;                       // Ref :158-165
+        else if (d.use_com_temp_group) c->dof[L.G] -= 3;                      // Cu :204-212
+    }
+    c->nkbt.assign(NT, 0.0);
+    std::vector<double> st(L.total, 0.0);
+    const double tau2 = std::pow(d.coupling_time, 2), tauD2 = std::pow(d.drude_coupling_time, 2);
+    if (d.mode == TGNH_MODE_DUALNH) {
+        const double realNkbT = c->dof[0] * c->realkbT, drudeNkbT = c->dof[2] * c->drudekbT;   // Ref :168-169
+        c->nkbt[0] = realNkbT; c->nkbt[2] = drudeNkbT;
+        double* etaMass = st.data() + L.off_etaMass;
+        double* etaDot = st.data() + L.off_etaDot;
+        double* etaDotDot = st.data() + L.off_etaDotDot;
+        etaMass[0] = realNkbT * tau2;                                         // Ref :170-171
+        etaMass[1] = drudeNkbT * tauD2;
+        const int ntg = L.numTempGroup;
+        if (L.use_drude_chains) {                                             // Ref :192-205
+            for (int ich = 1; ich < C; ich++) {
+                etaMass[2 * ich] = c->realkbT * tau2;
+                etaMass[2 * ich + 1] = c->drudekbT * tauD2;
+                etaDotDot[ich * ntg] = (etaMass[(ich - 1) * ntg] * etaDot[(ich - 1) * ntg] * etaDot[(ich - 1) * ntg] - c->realkbT) / etaMass[ich * ntg];
+                etaDotDot[ich * ntg + 1] = (etaMass[(ich - 1) * ntg + 1] * etaDot[(ich - 1) * ntg + 1] * etaDot[(ich - 1) * ntg + 1] - c->drudekbT) / etaMass[ich * ntg + 1];
+            }
+        } else {                                                              // Ref :206-214
+            for (int ich = 1; ich < C; ich++) {
+                etaMass[ich + 1] = c->realkbT * tau2;
+                etaDotDot[ich * ntg + 1] = (etaMass[(ich - 1) * ntg + 1] * etaDot[(ich - 1) * ntg + 1] * etaDot[(ich - 1) * ntg + 1] - c->realkbT) / etaMass[ich * ntg + 1];
+            }
+        }
+    } else {
+        const int G = L.G;
+        const double realUnit = c->realkbT * tau2, drudeUnit = c->drudekbT * tauD2;   // Cu :216-217
+        for (int i = 0; i < G + 1; i++) {                                     // Cu :218-225
+            c->nkbt[i] = c->dof[i] * c->realkbT;
+            double* em = st.data() + L.off_etaMass + i * C;
+            double* edd = st.data() + L.off_etaDotDot + i * C;
+            em[0] = c->dof[i] * realUnit;
+            for (int ich = 1; ich < C; ich++) { em[ich] = realUnit; edd[ich] = (em[ich - 1] * 0.0 - c->realkbT) / em[ich]; }
+        }
+        const int itg = G + 1;                                                // Cu :227-235
+        c->nkbt[itg] = c->dof[itg] * c->drudekbT;
+        double* em = st.data() + L.off_etaMass + itg * C;
+        double* edd = st.data() + L.off_etaDotDot + itg * C;
+        em[0] = c->dof[itg] * drudeUnit;
+        for (int ich = 1; ich < C; ich++) {
+            em[ich] = drudeUnit;
+            if (L.use_drude_chains) edd[ich] = (em[ich - 1] * 0.0 - c->drudekbT) / em[ich];
+        }
+    }
+    for (int i = 0; i < NT; i++) {
+        st[L.off_nkbt + i] = c->nkbt[i];
+        st[L.off_scale + i] = 1.0; st[L.off_scale_a + i] = 1.0; st[L.off_scale_b + i] = 1.0;
+    }
+    HIP_OK(hipMemcpy(c->d_state, st.data(), sizeof(double) * L.total, hipMemcpyHostToDevice));
+    c->ke_valid = false; c->scale_pending = false; c->first_half_done = false;
+    return TGNH_OK;
+}
+
+static void make_layout(tgnh_context* c) {
+    const tgnh_desc& d = c->d;
+    ChainLayout& L = c->L;
+    L.mode = d.mode;
+    L.C = d.num_nh_chains;
+    L.use_drude_chains = d.use_drude_nh_chains ? 1 : 0;
+    if (d.mode == TGNH_MODE_DUALNH) {
+        L.G = 1; L.NT = 3;
+        const int C = L.C;
+        if (L.use_drude_chains) { L.numTempGroup = 2; L.idxMaxNHChains = 2 * C - 1; L.iNumNHChains = 2 * C; }   // Ref :139-154
+        else { L.numTempGroup = 1; L.idxMaxNHChains = C; L.iNumNHChains = C + 1; }
+        const int n = L.use_drude_chains ? 2 * C : C + 1;
+        L.len_eta = n; L.len_etaDotDot = n; L.len_etaMass = n; L.len_etaDot = n + 2;          // Ref :216-217
+    } else {
+        L.G = d.num_groups; L.NT = L.G + 2;
+        L.len_eta = L.NT * L.C; L.len_etaDotDot = L.NT * L.C; L.len_etaMass = L.NT * L.C;     // Cu :94-97
+        L.len_etaDot = L.NT * (L.C + 1);
+        L.numTempGroup = L.idxMaxNHChains = L.iNumNHChains = 0;
+    }
+    int o = 0;
+    L.off_eta = o; o += L.len_eta;
+    L.off_etaDot = o; o += L.len_etaDot;
+    L.off_etaDotDot = o; o += L.len_etaDotDot;
+    L.off_etaMass = o; o += L.len_etaMass;
+    L.off_nkbt = o; o += L.NT;
+    L.off_ke = o; o += L.NT;
+    o = (o + 1) & ~1;                         // 16-byte aligned: this one is handed to the all-reduce hook
+    L.off_ke_red = o; o += L.NT;
+    L.off_scale = o; o += L.NT;
+    L.off_scale_a = o; o += L.NT;
+    L.off_scale_b = o; o += L.NT;
+    L.off_kesum = o; o += 1;
+    L.off_ke_post = o; o += L.NT;
+    L.total = o;
+}
+
+// ---------------------------------------------------------------------------
+// create / destroy
+// ---------------------------------------------------------------------------
+static void free_device(tgnh_context* c) {
+    if (c->d_meta) (void)hipFree(c->d_meta);
+    if (c->d_tile_start) (void)hipFree(c->d_tile_start);
+    if (c->d_tile_res) (void)hipFree(c->d_tile_res);
+    if (c->d_res_table) (void)hipFree(c->d_res_table);
+    if (c->d_partials) (void)hipFree(c->d_partials);
+    if (c->d_state) (void)hipFree(c->d_state);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->d_scalar) (void)hipFree(c->d_scalar);
+    for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    c->ev_pool.clear();
+}
+
+extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
+    if (!d || !out) return fail(TGNH_ERR_ARG, "null argument");
+    if (d->struct_size != sizeof(tgnh_desc)) return fail(TGNH_ERR_ARG, "tgnh_desc size mismatch (ABI)");
+    if (d->mode != TGNH_MODE_DUALNH && d->mode != TGNH_MODE_TGNH) return fail(TGNH_ERR_ARG, "bad mode");
+    if (d->precision < TGNH_PREC_SINGLE || d->precision > TGNH_PREC_DOUBLE) return fail(TGNH_ERR_ARG, "bad precision");
+    if (d->num_particles < 1 || d->num_pairs < 0 || !d->mass || (d->num_pairs && (!d->pair_drude || !d->pair_parent)))
+        return fail(TGNH_ERR_ARG, "bad particle / pair arrays");
+    if (d->padded_num_particles < d->num_particles) return fail(TGNH_ERR_ARG, "padded_num_particles < num_particles");
+    if (d->num_nh_chains < 1 || d->drude_steps_per_real_step < 1) return fail(TGNH_ERR_ARG, "numNHChains and drudeStepsPerRealStep must be >= 1");
+    if (d->mode == TGNH_MODE_TGNH && (d->num_groups < 1 || d->num_residues < 1 || !d->group || !d->resid))
+        return fail(TGNH_ERR_ARG, "TGNH mode needs temperature groups and residues");
+    if (d->max_drude_distance < 0) return fail(TGNH_ERR_ARG, "setMaxDrudeDistance: Distance cannot be negative");   // API :98-99
+    if (d->step_size <= 0) return fail(TGNH_ERR_ARG, "step size must be positive");
+    int ndev = 0;
+    HIP_OK(hipGetDeviceCount(&ndev));
+    if (d->device < 0 || d->device >= ndev) return fail(TGNH_ERR_HIP, "no such HIP device (the HIP path needs an MI355X; there is no CPU fallback)");
+    HIP_OK(hipSetDevice(d->device));
+
+    tgnh_context* c = new tgnh_context();
+    c->d = *d;
+    c->device = d->device;
+    c->realkbT = d->kB * d->temperature;                                      // Ref :107-108, Cu :80-81
+    c->drudekbT = d->kB * d->drude_temperature;
+    make_layout(c);
+    tgnh_status rc = build_topology(c, d);
+    if (rc != TGNH_OK) { free_device(c); delete c; return rc; }
+    if ((d->flags & TGNH_FLAG_DEFER_SCALE) && d->mode == TGNH_MODE_TGNH && d->use_com_temp_group) {
+        // s^2 KE is the exact post-rescale KE only if no molecule spans two temperature groups
+        for (int r = 0; r < d->num_residues; r++) {
+            int g0 = -1;
+            for (int j = 0; j < c->res_count[r]; j++) {
+                const int i = c->res_first[r] + j;
+                if (c->mass[i] == 0.0) continue;
+                if (g0 == -1) g0 = c->group[i];
+                else if (g0 != c->group[i]) { free_device(c); delete c; return fail(TGNH_ERR_UNSUPPORTED, "DEFER_SCALE needs every molecule inside one temperature group"); }
+            }
+        }
+    }
+    local_dof_terms(c);
+    c->global_terms = c->local_terms;
+    // constraint arrays are only needed during create
+    c->d.mass = nullptr; c->d.pair_drude = c->d.pair_parent = c->d.group = c->d.resid = nullptr;
+    c->d.constraint_i = c->d.constraint_j = nullptr;
+
+    c->grid = std::min(c->num_tiles, GRID_CAP);
+    if (const char* e = getenv("TGNH_GRID")) { int g = atoi(e); if (g >= 1) c->grid = std::min(c->num_tiles, g); }
+    c->gb = c->L.G <= 1 ? 1 : (c->L.G <= 4 ? 4 : 8);
+    auto alloc = [&]() -> tgnh_status {
+        HIP_OK(hipMalloc(&c->d_partials, sizeof(double) * (size_t)c->grid * c->L.NT));
+        HIP_OK(hipMemset(c->d_partials, 0, sizeof(double) * (size_t)c->grid * c->L.NT));
+        HIP_OK(hipMalloc(&c->d_state, sizeof(double) * c->L.total));
+        HIP_OK(hipMalloc(&c->d_status, sizeof(uint32_t)));
+        HIP_OK(hipMemset(c->d_status, 0, sizeof(uint32_t)));
+        HIP_OK(hipMalloc(&c->d_scalar, sizeof(double)));
+        return TGNH_OK;
+    };
+    rc = alloc();
+    if (rc == TGNH_OK) rc = finalize_thermostat(c);
+    if (rc != TGNH_OK) { free_device(c); delete c; return rc; }
+    *out = c;
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_destroy(tgnh_handle h) {
+    CHECK_H(h);
+    (void)hipSetDevice(h->device);
+    free_device(h);
+    delete h;
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_bind_buffers(tgnh_handle h, void* posq, void* posq_correction, void* velm,
+                                         const void* force, void* pos_delta) {
+    CHECK_H(h);
+    if (!posq || !velm || !force) return fail(TGNH_ERR_ARG, "posq, velm and force are required");
+    if (h->d.precision == TGNH_PREC_MIXED && !posq_correction) return fail(TGNH_ERR_ARG, "mixed precision needs posqCorrection");
+    h->posq = posq; h->posq_corr = posq_correction; h->velm = velm; h->force = force; h->pos_delta = pos_delta;
+    h->ke_valid = false;
+    return TGNH_OK;
+}
+
+static tgnh_status deferred_guard(tgnh_handle h, const char* what) {
+    if (h->first_half_done)
+        return fail(TGNH_ERR_STATE, std::string(what) + ": not allowed between steps with TGNH_FLAG_DEFER_SCALE (the next thermostat half step has already run)");
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_set_step_size(tgnh_handle h, double dt) {
+    CHECK_H(h);
+    if (dt <= 0) return fail(TGNH_ERR_ARG, "step size must be positive");
+    if (dt != h->d.step_size) { tgnh_status rc = deferred_guard(h, "tgnh_set_step_size"); if (rc) return rc; }
+    h->d.step_size = dt;
+    return TGNH_OK;
+}
+extern "C" tgnh_status tgnh_set_drude_steps_per_real_step(tgnh_handle h, int n) {
+    CHECK_H(h);
+    if (n < 1) return fail(TGNH_ERR_ARG, "drudeStepsPerRealStep must be >= 1");
+    if (n != h->d.drude_steps_per_real_step) { tgnh_status rc = deferred_guard(h, "tgnh_set_drude_steps_per_real_step"); if (rc) return rc; }
+    h->d.drude_steps_per_real_step = n;
+    return TGNH_OK;
+}
+extern "C" tgnh_status tgnh_set_max_drude_distance(tgnh_handle h, double dist) {
+    CHECK_H(h);
+    if (dist < 0) return fail(TGNH_ERR_ARG, "setMaxDrudeDistance: Distance cannot be negative");   // API :98-99
+    h->d.max_drude_distance = dist;
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_get_local_dof_terms(tgnh_handle h, double* terms, int* count) {
+    CHECK_H(h);
+    if (count) *count = h->L.NT;
+    if (terms) std::copy(h->local_terms.begin(), h->local_terms.end(), terms);
+    return TGNH_OK;
+}
+extern "C" tgnh_status tgnh_set_global_dof_terms(tgnh_handle h, const double* terms, int count) {
+    CHECK_H(h);
+    if (!terms || count != h->L.NT) return fail(TGNH_ERR_ARG, "dof term count mismatch");
+    if (h->step_count != 0) return fail(TGNH_ERR_STATE, "global dof must be set before the first step");
+    HIP_OK(hipSetDevice(h->device));
+    h->global_terms.assign(terms, terms + count);
+    return finalize_thermostat(h);
+}
+extern "C" tgnh_status tgnh_set_allreduce(tgnh_handle h, tgnh_allreduce_fn fn, void* user) {
+    CHECK_H(h);
+    h->allreduce = fn; h->allreduce_user = user;
+    return TGNH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------
+struct Timed {
+    tgnh_context* c; hipStream_t s; int kid; tgnh_context::Ev* ev = nullptr;
+    Timed(tgnh_context* c_, hipStream_t s_, int kid_) : c(c_), s(s_), kid(kid_) {
+        if (!c->timing) return;
+        if (c->ev_used == c->ev_pool.size()) {
+            tgnh_context::Ev e; e.kid = kid;
+            if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+            c->ev_pool.push_back(e);
+        }
+        ev = &c->ev_pool[c->ev_used++];
+        ev->kid = kid;
+        (void)hipEventRecord(ev->a, s);
+    }
+    ~Timed() { if (ev) (void)hipEventRecord(ev->b, s); }
+};
+
+static tgnh_status need_buffers(tgnh_handle h) {
+    if (!h->velm) return fail(TGNH_ERR_STATE, "tgnh_bind_buffers has not been called");
+    return TGNH_OK;
+}
+
+static TileArgs tile_args(tgnh_handle h, const double* scale) {
+    TileArgs a{};
+    a.posq = h->posq; a.posq_corr = h->posq_corr; a.velm = h->velm;
+    a.force = reinterpret_cast<const long long*>(h->force); a.pos_delta = h->pos_delta;
+    a.meta = h->d_meta; a.tile_start = h->d_tile_start; a.tile_res = h->d_tile_res; a.res_table = h->d_res_table;
+    a.scale = scale ? scale : h->d_state + h->L.off_scale;
+    a.partials = h->d_partials; a.status = h->d_status;
+    a.num_tiles = h->num_tiles; a.padded = h->d.padded_num_particles; a.num_groups = h->L.G;
+    a.use_com = (h->d.mode == TGNH_MODE_TGNH && h->d.use_com_temp_group) ? 1 : 0;
+    a.hardwall = h->d.max_drude_distance > 0 ? 1 : 0;                         // Ref :299, Cu :372
+    a.dt = h->d.step_size; a.max_dist = h->d.max_drude_distance;
+    a.hw_scale = std::sqrt(h->d.kB * h->d.drude_temperature);                 // Ref :300, Cu :299
+    return a;
+}
+
+static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, const double* scale = nullptr) {
+    TileArgs a = tile_args(h, scale);
+    if ((ops & (OP_POSDELTA | OP_MOVE)) && !h->pos_delta) return fail(TGNH_ERR_STATE, "posDelta buffer not bound");
+    const size_t lds = tile_lds_bytes(h->d.precision, ops, a.hardwall != 0, a.use_com != 0);
+    Timed t(h, s, kid);
+    HIP_OK(launch_tile(h->d.precision, ops, h->gb, a, h->grid, lds, s));
+    return TGNH_OK;
+}
+
+static ChainArgs chain_args(tgnh_handle h) {
+    ChainArgs a{};
+    a.L = h->L; a.st = h->d_state; a.partials = h->d_partials; a.nparts = h->grid;
+    a.dt = h->d.step_size; a.S = h->d.drude_steps_per_real_step;
+    a.realkbT = h->realkbT; a.drudekbT = h->drudekbT;
+    return a;
+}
+
+// sum the work-group partials, all-reduce across ranks when sharded, run the chain
+static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
+    ChainArgs a = chain_args(h);
+    a.chain_twice = twice ? 1 : 0;
+    if (h->allreduce) {
+        a.do_sum = 1; a.do_chain = 0;
+        { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
+        if (h->allreduce(h->d_state + h->L.off_ke_red, h->L.NT, (void*)s, h->allreduce_user) != 0)
+            return fail(TGNH_ERR_HIP, "all-reduce hook failed");
+        a.do_sum = 0; a.do_chain = 1;
+        { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
+    } else {
+        a.do_sum = 1; a.do_chain = 1;
+        Timed t(h, s, KID_CHAIN);
+        HIP_OK(launch_chain(a, s));
+    }
+    return TGNH_OK;
+}
+
+// make scale[] hold the first thermostat half step for the current velocities (Ref :231, Cu :336)
+static tgnh_status first_half(tgnh_handle h, hipStream_t s) {
+    if (h->first_half_done) return TGNH_OK;               // DEFER_SCALE: already folded into scale[]
+    if (!h->ke_valid) { tgnh_status rc = run_tile(h, OP_KE, KID_KE, s); if (rc) return rc; }
+    h->ke_valid = false;
+    return run_chain(h, s, false);
+}
+
+extern "C" tgnh_status tgnh_step_begin(tgnh_handle h, void* stream) {
+    CHECK_H(h);
+    tgnh_status rc = need_buffers(h); if (rc) return rc;
+    HIP_OK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    rc = first_half(h, s); if (rc) return rc;
+    rc = run_tile(h, OP_SCALE | OP_KICK | OP_DRIFT, KID_SKD, s); if (rc) return rc;   // Cu :351-376 fused
+    h->scale_pending = false; h->first_half_done = false; h->ke_valid = false;
+    return TGNH_OK;
+}
+
+static tgnh_status second_half(tgnh_handle h, hipStream_t s, int kick_ops) {
+    tgnh_status rc = run_tile(h, kick_ops | OP_KE, kick_ops ? KID_KICK_KE : KID_KE, s); if (rc) return rc;   // Cu :384-388 + :474-488
+    const int flags = h->d.flags;
+    if (flags & TGNH_FLAG_DEFER_SCALE) {
+        rc = run_chain(h, s, true); if (rc) return rc;
+        h->scale_pending = true; h->first_half_done = true;
+    } else if (flags & TGNH_FLAG_MERGE_SCALE_KE) {
+        rc = run_chain(h, s, false); if (rc) return rc;
+        rc = run_tile(h, OP_SCALE | OP_KE, KID_SCALE, s); if (rc) return rc;       // Cu :402 + next step's :474-488
+        h->ke_valid = true;
+    } else {
+        rc = run_chain(h, s, false); if (rc) return rc;                            // Cu :394-395
+        rc = run_tile(h, OP_SCALE, KID_SCALE, s); if (rc) return rc;               // Cu :402
+    }
+    h->time += h->d.step_size;                                                     // Cu :405-406 ; Ref :413-414
+    h->step_count += 1;
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_step_end(tgnh_handle h, void* stream) {
+    CHECK_H(h);
+    tgnh_status rc = need_buffers(h); if (rc) return rc;
+    HIP_OK(hipSetDevice(h->device));
+    return second_half(h, (hipStream_t)stream, OP_KICK);
+}
+
+extern "C" tgnh_status tgnh_step_begin_kick(tgnh_handle h, void* stream) {
+    CHECK_H(h);
+    tgnh_status rc = need_buffers(h); if (rc) return rc;
+    HIP_OK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    rc = first_half(h, s); if (rc) return rc;
+    rc = run_tile(h, OP_SCALE | OP_KICK | OP_POSDELTA, KID_OTHER, s); if (rc) return rc;   // Cu :351-360
+    h->scale_pending = false; h->first_half_done = false; h->ke_valid = false;
+    return TGNH_OK;
+}
+extern "C" tgnh_status tgnh_step_begin_move(tgnh_handle h, void* stream) {
+    CHECK_H(h);
+    tgnh_status rc = need_buffers(h); if (rc) return rc;
+    HIP_OK(hipSetDevice(h->device));
+    return run_tile(h, OP_MOVE, KID_OTHER, (hipStream_t)stream);                   // Cu :366-376
+}
+extern "C" tgnh_status tgnh_step_end_kick(tgnh_handle h, void* stream) {
+    CHECK_H(h);
+    tgnh_status rc = need_buffers(h); if (rc) return rc;
+    HIP_OK(hipSetDevice(h->device));
+    return run_tile(h, OP_KICK, KID_OTHER, (hipStream_t)stream);                   // Cu :384-388
+}
+extern "C" tgnh_status tgnh_step_end_thermo(tgnh_handle h, void* stream) {
+    CHECK_H(h);
+    tgnh_status rc = need_buffers(h); if (rc) return rc;
+    HIP_OK(hipSetDevice(h->device));
+    return second_half(h, (hipStream_t)stream, 0);                                 // Cu :394-406
+}
+extern "C" tgnh_status tgnh_half_kick(tgnh_handle h, void* stream) { return tgnh_step_end_kick(h, stream); }
+
+extern "C" tgnh_status tgnh_flush(tgnh_handle h, void* stream) {
+    CHECK_H(h);
+    if (!h->scale_pending) return TGNH_OK;
+    tgnh_status rc = need_buffers(h); if (rc) return rc;
+    HIP_OK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    rc = run_tile(h, OP_SCALE, KID_SCALE, s, h->d_state + h->L.off_scale_a); if (rc) return rc;
+    HIP_OK(hipMemcpyAsync(h->d_state + h->L.off_scale, h->d_state + h->L.off_scale_b, sizeof(double) * h->L.NT,
+                          hipMemcpyDeviceToDevice, s));
+    h->scale_pending = false;      // first_half_done stays: scale[] now holds only the pre-run half step
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_state_changed(tgnh_handle h) {
+    CHECK_H(h);
+    tgnh_status rc = deferred_guard(h, "tgnh_state_changed"); if (rc) return rc;
+    h->ke_valid = false;
+    return TGNH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// queries
+// ---------------------------------------------------------------------------
+static tgnh_status read_state(tgnh_handle h, int off, int n, hipStream_t s, double* out) {
+    HIP_OK(hipSetDevice(h->device));
+    HIP_OK(hipMemcpyAsync(out, h->d_state + off, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_get_kinetic_energy(tgnh_handle h, int ke_sum_valid, void* stream, double* out) {
+    CHECK_H(h);
+    if (!out) return fail(TGNH_ERR_ARG, "null out");
+    hipStream_t s = (hipStream_t)stream;
+    if (h->d.mode == TGNH_MODE_TGNH && ke_sum_valid)                               // Cu :654-658
+        return read_state(h, h->L.off_kesum, 1, s, out);
+    tgnh_status rc = need_buffers(h); if (rc) return rc;
+    rc = tgnh_flush(h, stream); if (rc) return rc;
+    HIP_OK(hipSetDevice(h->device));
+    const double ts = h->d.mode == TGNH_MODE_DUALNH ? 0.5 * h->d.step_size : 0.0; // Ref :587 ; Cu :656
+    HIP_OK(launch_plain_ke(h->d.precision, h->velm, reinterpret_cast<const long long*>(h->force), h->d.num_particles,
+                           h->d.padded_num_particles, ts, h->d_scalar, s));
+    HIP_OK(hipMemcpyAsync(out, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_get_num_thermostats(tgnh_handle h, int* count) {
+    CHECK_H(h);
+    if (count) *count = h->L.NT;
+    return TGNH_OK;
+}
+extern "C" tgnh_status tgnh_get_last_kinetic_energies(tgnh_handle h, void* stream, double* ke) {
+    CHECK_H(h);
+    return read_state(h, h->L.off_ke, h->L.NT, (hipStream_t)stream, ke);
+}
+extern "C" tgnh_status tgnh_get_last_scale_factors(tgnh_handle h, void* stream, double* scale) {
+    CHECK_H(h);
+    return read_state(h, h->L.off_scale_a, h->L.NT, (hipStream_t)stream, scale);
+}
+extern "C" tgnh_status tgnh_get_status_flags(tgnh_handle h, void* stream, uint32_t* flags) {
+    CHECK_H(h);
+    HIP_OK(hipSetDevice(h->device));
+    HIP_OK(hipMemcpyAsync(flags, h->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    if ((*flags & 1u) && h->d.mode == TGNH_MODE_DUALNH)                            // Ref :311-312
+        return fail(TGNH_ERR_HARDWALL, "Drude particle moved too far beyond hard wall constraint");
+    return TGNH_OK;
+}
+extern "C" tgnh_status tgnh_get_time(tgnh_handle h, double* time, int64_t* step_count) {
+    CHECK_H(h);
+    if (time) *time = h->time;
+    if (step_count) *step_count = h->step_count;
+    return TGNH_OK;
+}
+extern "C" tgnh_status tgnh_get_dof(tgnh_handle h, double* dof, double* nkt) {
+    CHECK_H(h);
+    if (dof) std::copy(h->dof.begin(), h->dof.end(), dof);
+    if (nkt) std::copy(h->nkbt.begin(), h->nkbt.end(), nkt);
+    return TGNH_OK;
+}
+
+static bool chain_section(tgnh_handle h, int which, int* off, int* len) {
+    switch (which) {
+        case 0: *off = h->L.off_eta; *len = h->L.len_eta; return true;
+        case 1: *off = h->L.off_etaDot; *len = h->L.len_etaDot; return true;
+        case 2: *off = h->L.off_etaDotDot; *len = h->L.len_etaDotDot; return true;
+        case 3: *off = h->L.off_etaMass; *len = h->L.len_etaMass; return true;
+        default: return false;
+    }
+}
+extern "C" tgnh_status tgnh_get_thermostat_len(tgnh_handle h, int which, int* len) {
+    CHECK_H(h);
+    int off;
+    if (!chain_section(h, which, &off, len)) return fail(TGNH_ERR_ARG, "bad thermostat array id");
+    return TGNH_OK;
+}
+extern "C" tgnh_status tgnh_get_thermostat_state(tgnh_handle h, int which, void* stream, double* out) {
+    CHECK_H(h);
+    int off, len;
+    if (!chain_section(h, which, &off, &len)) return fail(TGNH_ERR_ARG, "bad thermostat array id");
+    return read_state(h, off, len, (hipStream_t)stream, out);
+}
+extern "C" tgnh_status tgnh_set_thermostat_state(tgnh_handle h, int which, void* stream, const double* in) {
+    CHECK_H(h);
+    int off, len;
+    if (!chain_section(h, which, &off, &len)) return fail(TGNH_ERR_ARG, "bad thermostat array id");
+    tgnh_status rc = deferred_guard(h, "tgnh_set_thermostat_state"); if (rc) return rc;
+    HIP_OK(hipSetDevice(h->device));
+    HIP_OK(hipMemcpyAsync(h->d_state + off, in, sizeof(double) * len, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    return TGNH_OK;
+}
+
+static const std::vector<int>* topo_vec(tgnh_handle h, int which) {
+    switch (which) {
+        case 0: return &h->normal;
+        case 1: return &h->pair_drude;
+        case 2: return &h->pair_parent;
+        case 3: return &h->group;
+        case 4: return &h->resid;
+        case 5: return &h->res_count;
+        case 6: return &h->res_first;
+        case 7: return &h->tile_start;
+        default: return nullptr;
+    }
+}
+extern "C" tgnh_status tgnh_get_topology_len(tgnh_handle h, int which, int* len) {
+    CHECK_H(h);
+    if (which == 8) { *len = (int)h->meta.size(); return TGNH_OK; }
+    const std::vector<int>* v = topo_vec(h, which);
+    if (!v) return fail(TGNH_ERR_ARG, "bad topology array id");
+    *len = (int)v->size();
+    return TGNH_OK;
+}
+extern "C" tgnh_status tgnh_get_topology(tgnh_handle h, int which, int32_t* out) {
+    CHECK_H(h);
+    if (which == 8) { std::memcpy(out, h->meta.data(), sizeof(uint32_t) * h->meta.size()); return TGNH_OK; }
+    const std::vector<int>* v = topo_vec(h, which);
+    if (!v) return fail(TGNH_ERR_ARG, "bad topology array id");
+    std::copy(v->begin(), v->end(), out);
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_compute_kinetic_energies(tgnh_handle h, void* stream) {
+    CHECK_H(h);
+    tgnh_status rc = need_buffers(h); if (rc) return rc;
+    HIP_OK(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    rc = run_tile(h, OP_KE, KID_KE, s); if (rc) return rc;
+    ChainArgs a = chain_args(h);
+    a.do_sum = 1; a.do_chain = 0;
+    HIP_OK(launch_chain(a, s));
+    if (h->allreduce && h->allreduce(h->d_state + h->L.off_ke_red, h->L.NT, (void*)s, h->allreduce_user) != 0)
+        return fail(TGNH_ERR_HIP, "all-reduce hook failed");
+    HIP_OK(hipMemcpyAsync(h->d_state + h->L.off_ke, h->d_state + h->L.off_ke_red, sizeof(double) * h->L.NT,
+                          hipMemcpyDeviceToDevice, s));
+    return TGNH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// harness
+// ---------------------------------------------------------------------------
+extern "C" tgnh_status tgnh_harness_force(tgnh_handle h, const void* x0, double k_drude, double k_tether,
+                                          void* force_out, void* stream) {
+    CHECK_H(h);
+    tgnh_status rc = need_buffers(h); if (rc) return rc;
+    if (!x0 || !force_out) return fail(TGNH_ERR_ARG, "null x0 / force_out");
+    HIP_OK(hipSetDevice(h->device));
+    ForceArgs a{};
+    a.posq = h->posq; a.posq_corr = h->posq_corr; a.x0 = x0; a.velm = h->velm; a.meta = h->d_meta;
+    a.force = reinterpret_cast<long long*>(force_out);
+    a.n = h->d.num_particles; a.padded = h->d.padded_num_particles;
+    a.k_drude = k_drude; a.k_tether = k_tether;
+    Timed t(h, (hipStream_t)stream, KID_FORCE);
+    HIP_OK(launch_force(h->d.precision, a, (hipStream_t)stream));
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_run_harness(tgnh_handle h, const void* x0, double k_drude, double k_tether,
+                                        int nsteps, void* stream) {
+    CHECK_H(h);
+    for (int i = 0; i < nsteps; i++) {
+        tgnh_status rc = tgnh_step_begin(h, stream); if (rc) return rc;
+        rc = tgnh_harness_force(h, x0, k_drude, k_tether, const_cast<void*>(h->force), stream); if (rc) return rc;   // Cu :380 call-out
+        rc = tgnh_step_end(h, stream); if (rc) return rc;
+    }
+    return TGNH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// timing / roofline bookkeeping
+// ---------------------------------------------------------------------------
+static void drain_events(tgnh_handle h) {
+    for (size_t i = 0; i < h->ev_used; i++) {
+        auto& e = h->ev_pool[i];
+        if (hipEventSynchronize(e.b) != hipSuccess) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { h->t_total[e.kid] += ms; h->t_count[e.kid] += 1; }
+    }
+    h->ev_used = 0;
+}
+extern "C" tgnh_status tgnh_timing_enable(tgnh_handle h, int on) {
+    CHECK_H(h);
+    HIP_OK(hipSetDevice(h->device));
+    if (!on) drain_events(h);
+    else { for (int k = 0; k < KID_COUNT; k++) { h->t_total[k] = 0; h->t_count[k] = 0; } h->ev_used = 0; }
+    h->timing = on != 0;
+    return TGNH_OK;
+}
+extern "C" tgnh_status tgnh_timing_read(tgnh_handle h, int kernel, double* total_ms, int64_t* launches) {
+    CHECK_H(h);
+    if (kernel < 0 || kernel >= KID_COUNT) return fail(TGNH_ERR_ARG, "bad kernel id");
+    HIP_OK(hipSetDevice(h->device));
+    drain_events(h);
+    if (total_ms) *total_ms = h->t_total[kernel];
+    if (launches) *launches = h->t_count[kernel];
+    return TGNH_OK;
+}
+extern "C" tgnh_status tgnh_algorithmic_bytes(tgnh_handle h, int kernel, double* bytes) {
+    CHECK_H(h);
+    // state arrays only.  V = velocity vec4, F = 3 x int64, X = position (+correction) per direction.
+    const double N = h->d.num_particles;
+    const double V = h->d.precision == TGNH_PREC_SINGLE ? 16 : 32;
+    const double F = 24;
+    const double X = h->d.precision == TGNH_PREC_SINGLE ? 16 : 32;   // mixed: 16 posq + 16 correction; double: 32
+    double b = 0;
+    switch (kernel) {
+        case KID_SKD: b = N * (2 * V + F + 2 * X); break;       // scale+kick+drift: V r/w, F r, X r/w
+        case KID_KICK_KE: b = N * (2 * V + F); break;           // kick+KE: V r/w, F r
+        case KID_SCALE: b = N * (2 * V); break;                 // rescale (+KE): V r/w
+        case KID_KE: b = N * V; break;                          // KE: V r
+        case KID_FORCE: b = N * (X + F); break;                 // harness: X r, F w (x0 excluded)
+        default: b = 0;
+    }
+    *bytes = b;
+    return TGNH_OK;
+}

@@ -1,0 +1,169 @@
+// tgnh_internal.h -- shared between the host side (tgnh_host.cpp) and the
+// gfx950 kernels (tgnh_kernels.hip).  Not part of the ABI.
+#ifndef TGNH_INTERNAL_H_
+#define TGNH_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/drude_tgnh.h"
+
+namespace tgnh {
+
+// ---- tile geometry ---------------------------------------------------------
+// One 256-thread work-group (4 wavefronts of 64) owns a tile of up to TILE_SLOTS
+// consecutive particle slots whose ends never cut a Drude pair or (TGNH+COM) a
+// residue, so partner and molecular-COM look-ups stay inside the tile's LDS image.
+constexpr int BLOCK = 256;
+constexpr int SPT = 2;                       // slots per thread
+constexpr int TILE_SLOTS = BLOCK * SPT;      // 512
+constexpr int TILE_RES = TILE_SLOTS / 2;     // residues per tile the LDS COM table holds
+constexpr int GRID_CAP = 2048;               // persistent grid, multiple of 8 (XCD round-robin)
+constexpr int MAX_GROUPS = 8;                // per-thread KE bins are registers (GB template 1/4/8)
+
+// ---- packed per-slot topology word ----------------------------------------
+//  bits  0..1  role: 0 normal, 1 Drude particle (pair.x), 2 parent (pair.y)
+//  bits  2..9  temperature group
+//  bits 10..20 partner offset + 1024 (partner slot = slot + offset)
+//  bits 21..31 residue index local to the tile
+constexpr uint32_t ROLE_NORMAL = 0, ROLE_DRUDE = 1, ROLE_PARENT = 2;
+inline uint32_t pack_meta(uint32_t role, uint32_t group, int partner_off, uint32_t local_res) {
+    return role | (group << 2) | ((uint32_t)(partner_off + 1024) << 10) | (local_res << 21);
+}
+
+// ---- operation mask of the tile kernel --------------------------------------
+enum : int {
+    OP_SCALE = 1,      // A6  velocity rescale          (K integrateDrudeTGNHChain)
+    OP_KICK = 2,       // A7  half kick                 (K integrateDrudeTGNHVelocities)
+    OP_DRIFT = 4,      // A8  x += dt v (no constraints)
+    OP_KE = 8,         // A3/A4 kinetic-energy partial sums
+    OP_POSDELTA = 16,  // write posDelta = dt v         (constrained path)
+    OP_MOVE = 32       // x += posDelta, v = posDelta/dt (K integrateDrudeTGNHPositions)
+};
+
+// kernel ids for timing / algorithmic bytes (include/drude_tgnh.h)
+enum : int { KID_SKD = 0, KID_KICK_KE = 1, KID_SCALE = 2, KID_KE = 3, KID_CHAIN = 4, KID_FORCE = 5,
+             KID_OTHER = 6, KID_COUNT = 7 };
+
+struct TileArgs {
+    void* posq;
+    void* posq_corr;
+    void* velm;
+    const long long* force;
+    void* pos_delta;
+    const uint32_t* meta;
+    const int* tile_start;     // [num_tiles+1]
+    const int* tile_res;       // [num_tiles+1] first residue of each tile
+    const int2* res_table;     // [R] (count, first slot)
+    const double* scale;       // [NT] velocity scale factors (device)
+    double* partials;          // [grid][NT] per-work-group KE partial sums
+    uint32_t* status;          // bit0: Drude beyond 2x hard wall
+    int num_tiles;
+    int padded;
+    int num_groups;            // G (internal layout: NT = G+2, [G]=COM, [G+1]=Drude)
+    int use_com;
+    int hardwall;
+    double dt;
+    double max_dist;
+    double hw_scale;           // sqrt(kB*T_drude)
+};
+
+// thermostat block in device memory (doubles), offsets in doubles
+struct ChainLayout {
+    int mode, G, NT, C, use_drude_chains;
+    int len_eta, len_etaDot, len_etaDotDot, len_etaMass;
+    int off_eta, off_etaDot, off_etaDotDot, off_etaMass;
+    int off_nkbt;      // [NT]
+    int off_ke;        // [NT] last KE (before the chain)
+    int off_ke_red;    // [NT] summed KE buffer (all-reduced in place when sharded)
+    int off_scale;     // [NT] factors the next rescale applies (= scale_a * scale_b)
+    int off_scale_a;   // [NT] factors of the chain call itself
+    int off_scale_b;   // [NT] DEFER_SCALE: factors of the pre-run first half of the next step (else 1)
+    int off_kesum;     // [1]
+    int off_ke_post;   // [NT] KE after the chain (KE * prod exp)
+    int total;
+    // dualNH bookkeeping (Ref :139-154)
+    int numTempGroup, idxMaxNHChains, iNumNHChains;
+};
+
+struct ChainArgs {
+    ChainLayout L;
+    double* st;                // thermostat block
+    const double* partials;    // [nparts][NT] or nullptr when ke_red already holds the sums
+    int nparts;
+    int do_sum;                // sum partials -> ke_red
+    int do_chain;              // run the chain from ke_red
+    int chain_twice;           // DEFER_SCALE: second half of step n and first half of step n+1 back to back
+    double dt;
+    int S;
+    double realkbT, drudekbT;
+};
+
+struct ForceArgs {
+    const void* posq;
+    const void* posq_corr;
+    const void* x0;            // mixed4 [N]
+    const void* velm;          // inverse masses (w)
+    const uint32_t* meta;
+    long long* force;
+    int n, padded;
+    double k_drude, k_tether;
+};
+
+// launchers (tgnh_kernels.hip)
+hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s);
+hipError_t launch_chain(const ChainArgs& a, hipStream_t s);
+hipError_t launch_force(int precision, const ForceArgs& a, hipStream_t s);
+hipError_t launch_plain_ke(int precision, const void* velm, const long long* force, int n, int padded,
+                           double time_shift, double* out /*[1] device, zeroed inside*/, hipStream_t s);
+size_t tile_lds_bytes(int precision, int ops, bool hardwall, bool use_com);
+
+}  // namespace tgnh
+
+struct tgnh_context {
+    tgnh_desc d;                      // scalars only; pointers are nulled after create
+    int device = 0;
+    // host topology (A1), kept for parity queries
+    std::vector<double> mass;
+    std::vector<int> pair_drude, pair_parent, group, resid, normal;
+    std::vector<int> res_count, res_first;
+    std::vector<int> tile_start, tile_res;
+    std::vector<uint32_t> meta;
+    // dof bookkeeping (A2)
+    std::vector<double> local_terms, global_terms;   // per thermostat, before CMM correction
+    std::vector<double> dof, nkbt;
+    double realkbT = 0, drudekbT = 0;
+    tgnh::ChainLayout L{};
+    // device
+    uint32_t* d_meta = nullptr;
+    int* d_tile_start = nullptr;
+    int* d_tile_res = nullptr;
+    int2* d_res_table = nullptr;
+    double* d_partials = nullptr;
+    double* d_state = nullptr;        // thermostat block
+    uint32_t* d_status = nullptr;
+    double* d_scalar = nullptr;       // plain KE result
+    int grid = 0, num_tiles = 0, gb = 1;
+    // bound buffers
+    void *posq = nullptr, *posq_corr = nullptr, *velm = nullptr, *pos_delta = nullptr;
+    const void* force = nullptr;
+    // run state
+    bool ke_valid = false;            // ke_red/scale hold the thermostat half-step for the current velocities
+    bool scale_pending = false;       // DEFER_SCALE: velm lags by scale[]
+    bool first_half_done = false;     // DEFER_SCALE: chain for the coming step's first half already run
+    double time = 0;
+    int64_t step_count = 0;
+    tgnh_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+    // timing
+    bool timing = false;
+    struct Ev { hipEvent_t a, b; int kid; };
+    std::vector<Ev> ev_pool;
+    size_t ev_used = 0;
+    double t_total[tgnh::KID_COUNT] = {0};
+    int64_t t_count[tgnh::KID_COUNT] = {0};
+};
+
+#endif

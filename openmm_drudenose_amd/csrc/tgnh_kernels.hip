@@ -1,0 +1,774 @@
+// tgnh_kernels.hip -- gfx950 (CDNA4) kernels of the DrudeTGNHIntegrator step.
+//
+// Design (DESIGN.md "Kernels"): the whole per-particle part of a thermostat or
+// velocity-Verlet half step is ONE streaming pass of `tile_kernel`.  A 256-thread
+// work-group (4 wavefronts x 64 lanes) owns a tile of <= 512 consecutive slots whose
+// ends never cut a Drude pair or a molecule, loads it with one coalesced 16/32-byte
+// access per lane, keeps the velocity image in LDS so the Drude partner and the
+// molecular centre of mass are LDS look-ups, and leaves with fp64 per-group kinetic
+// energy sums reduced by 64-lane shuffles + one LDS hop.  Which of
+// {rescale, half kick, drift, hard wall, KE} a launch performs is a compile-time mask,
+// so e.g. rescale+kick+drift touches each array once.  The Nose-Hoover chains run
+// on the device (chain_kernel, fp64), so a step has no host round trip.
+//
+// Reference semantics followed (scychon/openmm_drudeNose):
+//   K  = platforms/cuda/src/kernels/drudeTGNH.cu
+//   Cu = platforms/cuda/src/CudaDrudeTGNHKernels.cpp
+//   Ref= platforms/reference/src/ReferenceDrudeTGNHKernels.cpp
+#include "tgnh_internal.h"
+
+namespace tgnh {
+
+template <int PREC> struct Prec;
+template <> struct Prec<TGNH_PREC_SINGLE> { typedef float real; typedef float mixed; typedef float4 real4; typedef float4 mixed4; };
+template <> struct Prec<TGNH_PREC_MIXED>  { typedef float real; typedef double mixed; typedef float4 real4; typedef double4 mixed4; };
+template <> struct Prec<TGNH_PREC_DOUBLE> { typedef double real; typedef double mixed; typedef double4 real4; typedef double4 mixed4; };
+
+__device__ __forceinline__ float4 mk4(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
+__device__ __forceinline__ double4 mk4(double x, double y, double z, double w) { return make_double4(x, y, z, w); }
+__device__ __forceinline__ float rcp_(float x) { return 1.0f / x; }
+__device__ __forceinline__ double rcp_(double x) { return 1.0 / x; }
+__device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
+__device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
+__device__ __forceinline__ float abs_(float x) { return fabsf(x); }
+__device__ __forceinline__ double abs_(double x) { return fabs(x); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+size_t tile_lds_bytes(int precision, int ops, bool hardwall, bool use_com) {
+    (void)use_com;
+    const size_t m4 = (precision == TGNH_PREC_SINGLE) ? 16 : 32;
+    const bool hw = hardwall && (ops & (OP_DRIFT | OP_MOVE));
+    size_t b = (size_t)(BLOCK / 64) * (MAX_GROUPS + 2) * 8;          // KE reduction scratch
+    if ((ops & (OP_SCALE | OP_KE)) || hw) b = m4 * (TILE_SLOTS + TILE_RES);   // sv + scom (fixed carve)
+    if (hw) b += m4 * TILE_SLOTS;                                     // sx
+    return b;
+}
+
+// ---------------------------------------------------------------------------
+// tile_kernel
+// ---------------------------------------------------------------------------
+template <int PREC, int OPS, int GB>
+__global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
+    typedef typename Prec<PREC>::real real;
+    typedef typename Prec<PREC>::mixed mixed;
+    typedef typename Prec<PREC>::real4 real4;
+    typedef typename Prec<PREC>::mixed4 mixed4;
+    constexpr bool DO_SCALE = OPS & OP_SCALE, DO_KICK = OPS & OP_KICK, DO_DRIFT = OPS & OP_DRIFT;
+    constexpr bool DO_KE = OPS & OP_KE, DO_PD = OPS & OP_POSDELTA, DO_MOVE = OPS & OP_MOVE;
+    constexpr bool POS = DO_DRIFT || DO_MOVE;            // positions are read and written
+    constexpr bool VEL_W = DO_SCALE || DO_KICK || DO_MOVE;   // velocities are written
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    mixed4* sv = reinterpret_cast<mixed4*>(smem);        // [TILE_SLOTS] velocity image
+    mixed4* scom = sv + TILE_SLOTS;                      // [TILE_RES]   molecular COM velocity, w = 1/M
+    mixed4* sx = scom + TILE_RES;                        // [TILE_SLOTS] position image (hard wall only)
+
+    const int tid = threadIdx.x;
+    const bool use_com = a.use_com != 0;
+    const bool hardwall = POS && (a.hardwall != 0);
+    const int G = a.num_groups;
+
+    mixed4* __restrict__ velm = reinterpret_cast<mixed4*>(a.velm);
+    real4* __restrict__ posq = reinterpret_cast<real4*>(a.posq);
+    float4* __restrict__ pcorr = reinterpret_cast<float4*>(a.posq_corr);
+    mixed4* __restrict__ pdelta = reinterpret_cast<mixed4*>(a.pos_delta);
+
+    double ke_g[GB];
+#pragma unroll
+    for (int b = 0; b < GB; b++) ke_g[b] = 0.0;
+    double ke_com = 0.0, ke_drude = 0.0;
+
+    // scale factors: uniform loads, tiny
+    mixed s_com = 1, s_drude = 1;
+    if (DO_SCALE) { s_com = (mixed)a.scale[G]; s_drude = (mixed)a.scale[G + 1]; }
+    const mixed dt = (mixed)a.dt;
+    const mixed fscale = (mixed)(0.5 * a.dt / 4294967296.0);     // Cu :295
+
+    for (int t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
+        const int ts = a.tile_start[t], te = a.tile_start[t + 1];
+        const int rs = a.tile_res[t], nres = a.tile_res[t + 1] - rs;
+
+        mixed4 v[SPT];
+        uint32_t meta[SPT];
+        long long fx[SPT], fy[SPT], fz[SPT];
+        mixed px[SPT], py[SPT], pz[SPT];
+        real pq[SPT];
+        mixed4 pd[SPT];
+        bool ok[SPT];
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            const int idx = ts + k * BLOCK + tid;
+            ok[k] = idx < te;
+            if (ok[k]) {
+                v[k] = velm[idx];
+                meta[k] = a.meta[idx];
+                if (DO_KICK) {
+                    fx[k] = a.force[idx];
+                    fy[k] = a.force[idx + a.padded];
+                    fz[k] = a.force[idx + 2 * a.padded];
+                }
+                if (POS) {
+                    real4 p = posq[idx];
+                    px[k] = p.x; py[k] = p.y; pz[k] = p.z; pq[k] = p.w;
+                    if (PREC == TGNH_PREC_MIXED) {       // K :443-445
+                        float4 c = pcorr[idx];
+                        px[k] += (mixed)c.x; py[k] += (mixed)c.y; pz[k] += (mixed)c.z;
+                    }
+                }
+                if (DO_MOVE) pd[k] = pdelta[idx];
+            } else {
+                v[k] = mk4((mixed)0, (mixed)0, (mixed)0, (mixed)0);
+                meta[k] = 0u;
+            }
+        }
+
+        bool lds_read = false;   // some lane may still be reading sv/scom of this tile
+
+        // ---------------- A6: rescale (K :249-301 ; Ref :516-541) ----------------
+        if (DO_SCALE) {
+#pragma unroll
+            for (int k = 0; k < SPT; k++) sv[k * BLOCK + tid] = v[k];
+            __syncthreads();
+            if (use_com) {
+                for (int r = tid; r < nres; r += BLOCK) {            // K :86-111
+                    const int2 rt = a.res_table[rs + r];
+                    const int first = rt.y - ts;
+                    mixed cx = 0, cy = 0, cz = 0, cm = 0;
+                    for (int j = 0; j < rt.x; j++) {
+                        const mixed4 u = sv[first + j];
+                        if (u.w != 0) {
+                            const mixed m = rcp_(u.w);
+                            cx += u.x * m; cy += u.y * m; cz += u.z * m; cm += m;
+                        }
+                    }
+                    const mixed w = rcp_(cm);
+                    scom[r] = mk4(cx * w, cy * w, cz * w, w);
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int k = 0; k < SPT; k++) {
+                const uint32_t m = meta[k];
+                const uint32_t role = m & 3u, g = (m >> 2) & 255u;
+                mixed cx = 0, cy = 0, cz = 0;
+                if (use_com) { const mixed4 c = scom[m >> 21]; cx = c.x; cy = c.y; cz = c.z; }
+                const mixed s_g = (mixed)a.scale[g];
+                if (role == ROLE_NORMAL) {
+                    if (v[k].w != 0) {                               // K :260-265
+                        const mixed rx = v[k].x - cx, ry = v[k].y - cy, rz = v[k].z - cz;
+                        v[k].x = s_g * rx + s_com * (v[k].x - rx);
+                        v[k].y = s_g * ry + s_com * (v[k].y - ry);
+                        v[k].z = s_g * rz + s_com * (v[k].z - rz);
+                    }
+                } else {                                             // K :270-300
+                    const int pl = k * BLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
+                    const mixed4 u = sv[pl];
+                    const bool is_d = role == ROLE_DRUDE;
+                    const mixed4 v1 = is_d ? v[k] : u;               // particles.x (Drude)
+                    const mixed4 v2 = is_d ? u : v[k];               // particles.y (parent)
+                    const mixed r1x = v1.x - cx, r1y = v1.y - cy, r1z = v1.z - cz;
+                    const mixed r2x = v2.x - cx, r2y = v2.y - cy, r2z = v2.z - cz;
+                    const mixed mass1 = rcp_(v1.w), mass2 = rcp_(v2.w);
+                    const mixed invTot = rcp_(mass1 + mass2);
+                    const mixed m1f = invTot * mass1, m2f = invTot * mass2;
+                    const mixed cmx = s_g * (r1x * m1f + r2x * m2f);
+                    const mixed cmy = s_g * (r1y * m1f + r2y * m2f);
+                    const mixed cmz = s_g * (r1z * m1f + r2z * m2f);
+                    const mixed rlx = s_drude * (r2x - r1x), rly = s_drude * (r2y - r1y), rlz = s_drude * (r2z - r1z);
+                    if (is_d) {
+                        v[k].x = cmx - rlx * m2f + s_com * (v1.x - r1x);
+                        v[k].y = cmy - rly * m2f + s_com * (v1.y - r1y);
+                        v[k].z = cmz - rlz * m2f + s_com * (v1.z - r1z);
+                    } else {
+                        v[k].x = cmx + rlx * m1f + s_com * (v2.x - r2x);
+                        v[k].y = cmy + rly * m1f + s_com * (v2.y - r2y);
+                        v[k].z = cmz + rlz * m1f + s_com * (v2.z - r2z);
+                    }
+                }
+            }
+            lds_read = true;
+        }
+
+        // ---------------- A8 (constrained path): x += posDelta, v = posDelta/dt (K :435-466) ---
+        if (DO_MOVE) {
+            const double invStep = 1.0 / a.dt;                       // K :436
+#pragma unroll
+            for (int k = 0; k < SPT; k++) {
+                if (v[k].w != 0) {
+                    px[k] += pd[k].x; py[k] += pd[k].y; pz[k] += pd[k].z;
+                    v[k].x = (mixed)(invStep * pd[k].x);
+                    v[k].y = (mixed)(invStep * pd[k].y);
+                    v[k].z = (mixed)(invStep * pd[k].z);
+                }
+            }
+        }
+
+        // ---------------- A7: half kick (K :307-365 ; Ref :548-584) ----------------
+        // Per-particle form v += (dt/2) F/m.  The reference writes the pair kick in
+        // COM/relative coordinates; that is algebraically the same update
+        // (tests/test_oracle.py::test_pair_kick_identity), so no partner access is needed here.
+        if (DO_KICK) {
+#pragma unroll
+            for (int k = 0; k < SPT; k++) {
+                if (v[k].w != 0) {
+                    const mixed c = fscale * v[k].w;
+                    v[k].x += c * (mixed)fx[k];
+                    v[k].y += c * (mixed)fy[k];
+                    v[k].z += c * (mixed)fz[k];
+                }
+            }
+        }
+
+        // ---------------- A8: drift (Ref :253-258 ; K :322-324, :450-452) ----------------
+        if (DO_DRIFT) {
+#pragma unroll
+            for (int k = 0; k < SPT; k++) {
+                if (v[k].w != 0) {
+                    px[k] += dt * v[k].x; py[k] += dt * v[k].y; pz[k] += dt * v[k].z;
+                }
+            }
+        }
+        if (DO_PD) {
+#pragma unroll
+            for (int k = 0; k < SPT; k++) {
+                const int idx = ts + k * BLOCK + tid;
+                if (ok[k]) {
+                    const bool mv = v[k].w != 0;
+                    pdelta[idx] = mk4(mv ? dt * v[k].x : (mixed)0, mv ? dt * v[k].y : (mixed)0, mv ? dt * v[k].z : (mixed)0, (mixed)0);
+                }
+            }
+        }
+
+        // ---------------- A10: hard wall (K :471-574 ; Ref :298-363) ----------------
+        if (POS && hardwall) {
+            if (lds_read) __syncthreads();
+#pragma unroll
+            for (int k = 0; k < SPT; k++) {
+                sv[k * BLOCK + tid] = v[k];
+                sx[k * BLOCK + tid] = mk4(px[k], py[k], pz[k], (mixed)0);
+            }
+            __syncthreads();
+            const mixed maxd = (mixed)a.max_dist, hws = (mixed)a.hw_scale;
+#pragma unroll
+            for (int k = 0; k < SPT; k++) {
+                const uint32_t m = meta[k];
+                const uint32_t role = m & 3u;
+                if (role != ROLE_NORMAL) {
+                    const int pl = k * BLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
+                    const mixed4 uv = sv[pl], ux = sx[pl];
+                    const bool is_d = role == ROLE_DRUDE;
+                    const mixed4 vel1 = is_d ? v[k] : uv, vel2 = is_d ? uv : v[k];
+                    const mixed p1x = is_d ? px[k] : ux.x, p1y = is_d ? py[k] : ux.y, p1z = is_d ? pz[k] : ux.z;
+                    const mixed p2x = is_d ? ux.x : px[k], p2y = is_d ? ux.y : py[k], p2z = is_d ? ux.z : pz[k];
+                    const mixed dx = p1x - p2x, dy = p1y - p2y, dz = p1z - p2z;
+                    const mixed r = sqrt_(dx * dx + dy * dy + dz * dz);
+                    const mixed rInv = rcp_(r);
+                    if (rInv * maxd < 1) {
+                        if (rInv * maxd < (mixed)0.5) atomicOr(a.status, 1u);     // Ref :311-312
+                        const mixed bx = dx * rInv, by = dy * rInv, bz = dz * rInv;
+                        const mixed mass1 = rcp_(vel1.w), mass2 = rcp_(vel2.w);
+                        const mixed deltaR = r - maxd;
+                        mixed deltaT = dt;
+                        mixed dotvr1 = vel1.x * bx + vel1.y * by + vel1.z * bz;
+                        const mixed vp1x = vel1.x - bx * dotvr1, vp1y = vel1.y - by * dotvr1, vp1z = vel1.z - bz * dotvr1;
+                        if (vel2.w == 0) {                            // K :504-526 massless parent
+                            if (dotvr1 != 0) deltaT = deltaR / abs_(dotvr1);
+                            if (deltaT > dt) deltaT = dt;
+                            dotvr1 = -dotvr1 * hws / (abs_(dotvr1) * sqrt_(mass1));
+                            const mixed dr = -deltaR + deltaT * dotvr1;
+                            if (is_d) {
+                                px[k] += bx * dr; py[k] += by * dr; pz[k] += bz * dr;
+                                v[k].x = vp1x + bx * dotvr1; v[k].y = vp1y + by * dotvr1; v[k].z = vp1z + bz * dotvr1;
+                            }
+                        } else {                                      // K :527-571
+                            const mixed invTot = rcp_(mass1 + mass2);
+                            mixed dotvr2 = vel2.x * bx + vel2.y * by + vel2.z * bz;
+                            const mixed vp2x = vel2.x - bx * dotvr2, vp2y = vel2.y - by * dotvr2, vp2z = vel2.z - bz * dotvr2;
+                            const mixed vbCMass = (mass1 * dotvr1 + mass2 * dotvr2) * invTot;
+                            dotvr1 -= vbCMass;
+                            dotvr2 -= vbCMass;
+                            if (dotvr1 != dotvr2) deltaT = deltaR / abs_(dotvr1 - dotvr2);
+                            if (deltaT > dt) deltaT = dt;
+                            const mixed vBond = hws / sqrt_(mass1);
+                            dotvr1 = -dotvr1 * vBond * mass2 * invTot / abs_(dotvr1);
+                            dotvr2 = -dotvr2 * vBond * mass1 * invTot / abs_(dotvr2);
+                            const mixed dr1 = -deltaR * mass2 * invTot + deltaT * dotvr1;
+                            const mixed dr2 = deltaR * mass1 * invTot + deltaT * dotvr2;
+                            dotvr1 += vbCMass;
+                            dotvr2 += vbCMass;
+                            if (is_d) {
+                                px[k] += bx * dr1; py[k] += by * dr1; pz[k] += bz * dr1;
+                                v[k].x = vp1x + bx * dotvr1; v[k].y = vp1y + by * dotvr1; v[k].z = vp1z + bz * dotvr1;
+                            } else {
+                                px[k] += bx * dr2; py[k] += by * dr2; pz[k] += bz * dr2;
+                                v[k].x = vp2x + bx * dotvr2; v[k].y = vp2y + by * dotvr2; v[k].z = vp2z + bz * dotvr2;
+                            }
+                        }
+                    }
+                }
+            }
+            lds_read = true;
+        }
+
+        // ---------------- stores ----------------
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            const int idx = ts + k * BLOCK + tid;
+            if (ok[k]) {
+                if (VEL_W || (POS && hardwall)) velm[idx] = v[k];
+                if (POS) {
+                    if (PREC == TGNH_PREC_MIXED) {                   // K :457-458
+                        const float hx = (float)px[k], hy = (float)py[k], hz = (float)pz[k];
+                        posq[idx] = mk4((real)hx, (real)hy, (real)hz, pq[k]);
+                        pcorr[idx] = make_float4((float)(px[k] - hx), (float)(py[k] - hy), (float)(pz[k] - hz), 0.0f);
+                    } else {
+                        posq[idx] = mk4((real)px[k], (real)py[k], (real)pz[k], pq[k]);
+                    }
+                }
+            }
+        }
+
+        // ---------------- A3/A4: kinetic energies (K :82-200 ; Ref :439-460) ----------------
+        if (DO_KE) {
+            if (lds_read) __syncthreads();
+#pragma unroll
+            for (int k = 0; k < SPT; k++) sv[k * BLOCK + tid] = v[k];
+            __syncthreads();
+            if (use_com) {
+                for (int r = tid; r < nres; r += BLOCK) {            // K :86-111, :152-158
+                    const int2 rt = a.res_table[rs + r];
+                    const int first = rt.y - ts;
+                    mixed cx = 0, cy = 0, cz = 0, cm = 0;
+                    for (int j = 0; j < rt.x; j++) {
+                        const mixed4 u = sv[first + j];
+                        if (u.w != 0) {
+                            const mixed m = rcp_(u.w);
+                            cx += u.x * m; cy += u.y * m; cz += u.z * m; cm += m;
+                        }
+                    }
+                    const mixed w = rcp_(cm);
+                    cx *= w; cy *= w; cz *= w;
+                    scom[r] = mk4(cx, cy, cz, w);
+                    ke_com += ((double)cx * cx + (double)cy * cy + (double)cz * cz) / (double)w;
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int k = 0; k < SPT; k++) {
+                const uint32_t m = meta[k];
+                const uint32_t role = m & 3u, g = (m >> 2) & 255u;
+                double cx = 0, cy = 0, cz = 0;
+                if (use_com) { const mixed4 c = scom[m >> 21]; cx = c.x; cy = c.y; cz = c.z; }
+                double val = 0.0;
+                if (role == ROLE_NORMAL) {
+                    if (v[k].w != 0) {                               // K :161-168
+                        const double rx = v[k].x - cx, ry = v[k].y - cy, rz = v[k].z - cz;
+                        val = (rx * rx + ry * ry + rz * rz) / (double)v[k].w;
+                    }
+                } else if (role == ROLE_DRUDE) {                     // K :171-186 (one lane per pair)
+                    const int pl = k * BLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
+                    const mixed4 u = sv[pl];
+                    const double w1 = v[k].w, w2 = u.w;
+                    const double r1x = v[k].x - cx, r1y = v[k].y - cy, r1z = v[k].z - cz;
+                    const double r2x = u.x - cx, r2y = u.y - cy, r2z = u.z - cz;
+                    const double mass1 = 1.0 / w1, mass2 = 1.0 / w2;
+                    const double invTot = 1.0 / (mass1 + mass2);
+                    const double invRed = (mass1 + mass2) * w1 * w2;
+                    const double m1f = invTot * mass1, m2f = invTot * mass2;
+                    const double cmx = r1x * m1f + r2x * m2f, cmy = r1y * m1f + r2y * m2f, cmz = r1z * m1f + r2z * m2f;
+                    const double rlx = r2x - r1x, rly = r2y - r1y, rlz = r2z - r1z;
+                    val = (cmx * cmx + cmy * cmy + cmz * cmz) * (mass1 + mass2);
+                    ke_drude += (rlx * rlx + rly * rly + rlz * rlz) * (1.0 / invRed);
+                }
+#pragma unroll
+                for (int b = 0; b < GB; b++) ke_g[b] += (g == (uint32_t)b) ? val : 0.0;
+            }
+            lds_read = true;
+        }
+        if (lds_read) __syncthreads();       // LDS image is reused by the next tile
+    }
+
+    // ---- work-group reduction of the fp64 KE bins: 64-lane butterflies, then one LDS hop ----
+    if (DO_KE) {
+        double* sred = reinterpret_cast<double*>(smem);              // [BLOCK/64][GB+2]
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int b = 0; b < GB; b++) ke_g[b] = wave_sum(ke_g[b]);
+        ke_com = wave_sum(ke_com);
+        ke_drude = wave_sum(ke_drude);
+        if (lane == 0) {
+#pragma unroll
+            for (int b = 0; b < GB; b++) sred[wv * (GB + 2) + b] = ke_g[b];
+            sred[wv * (GB + 2) + GB] = ke_com;
+            sred[wv * (GB + 2) + GB + 1] = ke_drude;
+        }
+        __syncthreads();
+        if (tid < GB + 2) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < BLOCK / 64; w++) s += sred[w * (GB + 2) + tid];   // fixed order
+            const int NT = G + 2;
+            if (tid < GB) { if (tid < G) a.partials[(size_t)blockIdx.x * NT + tid] = s; }
+            else a.partials[(size_t)blockIdx.x * NT + G + (tid - GB)] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// chain_kernel: cross-work-group KE sum (fixed order) + Nose-Hoover chain (A5)
+// One work-group.  TGNH: lane itg owns thermostat itg (Cu :558-650).
+// dualNH: lane 0 runs the reference's coupled, interleaved arrays (Ref :467-504),
+// including its indexing quirk when useDrudeNHChains is false.
+// ---------------------------------------------------------------------------
+#pragma clang fp contract(off)
+
+__device__ void chain_tgnh_real(const ChainArgs& a, int itg, double ke, double* scale_out, double* ke_out) {
+    const ChainLayout& L = a.L;
+    const int C = L.C;
+    double* eta = a.st + L.off_eta + itg * C;
+    double* etaDot = a.st + L.off_etaDot + itg * (C + 1);
+    double* etaDotDot = a.st + L.off_etaDotDot + itg * C;
+    const double* etaMass = a.st + L.off_etaMass + itg * C;
+    const double nkbt = a.st[L.off_nkbt + itg];
+    const double dtc = a.dt / a.S;                                   // Cu :440-443
+    const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
+    double scale = 1.0, expfac = 1.0;
+    if (etaMass[0] > 0) etaDotDot[0] = (ke - nkbt) / etaMass[0];     // Cu :561-563
+    for (int iter = 0; iter < a.S; iter++) {
+        for (int i = C - 1; i >= 0; i--) {                           // Cu :566-571
+            expfac = exp(-dtc8 * etaDot[i + 1]);
+            etaDot[i] *= expfac;
+            etaDot[i] += etaDotDot[i] * dtc4;
+            etaDot[i] *= expfac;
+        }
+        scale *= exp(-dtc2 * etaDot[0]);                             // Cu :573-574
+        ke *= exp(-dtc * etaDot[0]);
+        for (int i = 0; i < C; i++) eta[i] += dtc2 * etaDot[i];      // Cu :575-577
+        if (etaMass[0] > 0) etaDotDot[0] = (ke - nkbt) / etaMass[0]; // Cu :579-581
+        etaDot[0] *= expfac;                                         // Cu :583-585
+        etaDot[0] += etaDotDot[0] * dtc4;
+        etaDot[0] *= expfac;
+        for (int i = 1; i < C; i++) {                                // Cu :586-592
+            expfac = exp(-dtc8 * etaDot[i + 1]);
+            etaDot[i] *= expfac;
+            etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - a.realkbT) / etaMass[i];
+            etaDot[i] += etaDotDot[i] * dtc4;
+            etaDot[i] *= expfac;
+        }
+    }
+    *scale_out = scale;
+    *ke_out = ke;
+}
+
+__device__ void chain_tgnh_drude(const ChainArgs& a, int itg, double ke, double* scale_out, double* ke_out) {
+    const ChainLayout& L = a.L;
+    const int C = L.C;
+    const bool chains = L.use_drude_chains != 0;
+    double* eta = a.st + L.off_eta + itg * C;
+    double* etaDot = a.st + L.off_etaDot + itg * (C + 1);
+    double* etaDotDot = a.st + L.off_etaDotDot + itg * C;
+    const double* etaMass = a.st + L.off_etaMass + itg * C;
+    const double nkbt = a.st[L.off_nkbt + itg];
+    const double dtc = a.dt / a.S;
+    const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
+    double scale = 1.0, expfac = 1.0;
+    etaDotDot[0] = (ke - nkbt) / etaMass[0];                         // Cu :605
+    for (int iter = 0; iter < a.S; iter++) {                         // Cu :606-642
+        if (chains) {
+            for (int i = C - 1; i > 0; i--) {
+                expfac = exp(-dtc8 * etaDot[i + 1]);
+                etaDot[i] *= expfac;
+                etaDot[i] += etaDotDot[i] * dtc4;
+                etaDot[i] *= expfac;
+            }
+        }
+        expfac = exp(-dtc8 * etaDot[1]);
+        etaDot[0] *= expfac;
+        etaDot[0] += etaDotDot[0] * dtc4;
+        etaDot[0] *= expfac;
+        scale *= exp(-dtc2 * etaDot[0]);
+        ke *= exp(-dtc * etaDot[0]);
+        eta[0] += dtc2 * etaDot[0];
+        if (chains) for (int i = 1; i < C; i++) eta[i] += dtc2 * etaDot[i];
+        etaDotDot[0] = (ke - nkbt) / etaMass[0];
+        etaDot[0] *= expfac;
+        etaDot[0] += etaDotDot[0] * dtc4;
+        etaDot[0] *= expfac;
+        if (chains) {
+            for (int i = 1; i < C; i++) {
+                expfac = exp(-dtc8 * etaDot[i + 1]);
+                etaDot[i] *= expfac;
+                etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - a.drudekbT) / etaMass[i];
+                etaDot[i] += etaDotDot[i] * dtc4;
+                etaDot[i] *= expfac;
+            }
+        }
+    }
+    *scale_out = scale;
+    *ke_out = ke;
+}
+
+__device__ void chain_dualnh(const ChainArgs& a, double realKE, double drudeKE,
+                             double* sReal, double* sDrude, double* keReal, double* keDrude) {
+    const ChainLayout& L = a.L;
+    double* eta = a.st + L.off_eta;
+    double* etaDot = a.st + L.off_etaDot;
+    double* etaDotDot = a.st + L.off_etaDotDot;
+    const double* etaMass = a.st + L.off_etaMass;
+    const double realNkbT = a.st[L.off_nkbt + 0], drudeNkbT = a.st[L.off_nkbt + 2];
+    const double dtc = a.dt / a.S;                                   // Ref :432-435
+    const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
+    double scaleReal = 1.0, scaleDrude = 1.0, expfac = 1.0;
+    etaDotDot[0] = (realKE - realNkbT) / etaMass[0];                 // Ref :471-472
+    etaDotDot[1] = (drudeKE - drudeNkbT) / etaMass[1];
+    for (int iter = 0; iter < a.S; iter++) {
+        for (int i = L.idxMaxNHChains; i >= 0; i--) {                // Ref :476-481
+            expfac = exp(-dtc8 * etaDot[i + L.numTempGroup]);
+            etaDot[i] *= expfac;
+            etaDot[i] += etaDotDot[i] * dtc4;
+            etaDot[i] *= expfac;
+        }
+        scaleReal *= exp(-dtc2 * etaDot[0]);                         // Ref :483-486
+        scaleDrude *= exp(-dtc2 * etaDot[1]);
+        realKE *= exp(-dtc * etaDot[0]);
+        drudeKE *= exp(-dtc * etaDot[1]);
+        for (int i = 0; i < L.iNumNHChains; i++) eta[i] += dtc2 * etaDot[i];   // Ref :487-489
+        etaDotDot[0] = (realKE - realNkbT) / etaMass[0];             // Ref :491-492
+        etaDotDot[1] = (drudeKE - drudeNkbT) / etaMass[1];
+        for (int i = 0; i < L.iNumNHChains; i++) {                   // Ref :494-503
+            expfac = exp(-dtc8 * etaDot[i + 2]);
+            etaDot[i] *= expfac;
+            if (i > 1) {
+                const double dofkbT = (i % 2 == 0 ? a.realkbT : a.drudekbT);
+                etaDotDot[i] = (etaMass[i - 2] * etaDot[i - 2] * etaDot[i - 2] - dofkbT) / etaMass[i];
+            }
+            etaDot[i] += etaDotDot[i] * dtc4;
+            etaDot[i] *= expfac;
+        }
+    }
+    *sReal = scaleReal; *sDrude = scaleDrude; *keReal = realKE; *keDrude = drudeKE;
+}
+
+__global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
+    __shared__ double sred[BLOCK / 64][MAX_GROUPS + 2];
+    const ChainLayout& L = a.L;
+    const int NT = L.NT, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double* st = a.st;
+    if (a.do_sum) {
+        // per-lane strided partial sums, 64-lane butterfly, 4-wave LDS hop: fixed order => deterministic
+        for (int b = 0; b < NT; b++) {
+            double s = 0.0;
+            for (int p = tid; p < a.nparts; p += BLOCK) s += a.partials[(size_t)p * NT + b];
+            s = wave_sum(s);
+            if (lane == 0) sred[wv][b] = s;
+        }
+        __syncthreads();
+        if (tid < NT) {
+            double s = 0.0;
+            for (int w = 0; w < BLOCK / 64; w++) s += sred[w][tid];
+            st[L.off_ke_red + tid] = s;
+        }
+        __syncthreads();
+    }
+    if (!a.do_chain) return;
+    const int reps = a.chain_twice ? 2 : 1;
+    if (L.mode == TGNH_MODE_TGNH) {
+        if (tid < NT) {
+            double ke = st[L.off_ke_red + tid];
+            st[L.off_ke + tid] = ke;                                 // KE before the chain (Cu :490)
+            double total = 1.0;
+            for (int rep = 0; rep < reps; rep++) {
+                double sc, kep;
+                if (tid < NT - 1) chain_tgnh_real(a, tid, ke, &sc, &kep);
+                else chain_tgnh_drude(a, tid, ke, &sc, &kep);
+                if (rep == 0) { st[L.off_scale_a + tid] = sc; st[L.off_ke_post + tid] = kep; }
+                else st[L.off_scale_b + tid] = sc;
+                total *= sc;
+                ke = kep;
+            }
+            if (reps == 1) st[L.off_scale_b + tid] = 1.0;
+            st[L.off_scale + tid] = total;
+        }
+        __syncthreads();
+        if (tid == 0) {                                              // Cu :493-497
+            double s = 0.0;
+            for (int i = 0; i < NT; i++) s += st[L.off_ke + i];
+            st[L.off_kesum] = 0.5 * s;
+        }
+    } else {
+        if (tid == 0) {
+            double keR = st[L.off_ke_red + 0], keD = st[L.off_ke_red + 2];
+            st[L.off_ke + 0] = keR; st[L.off_ke + 1] = st[L.off_ke_red + 1]; st[L.off_ke + 2] = keD;
+            double totR = 1.0, totD = 1.0;
+            for (int rep = 0; rep < reps; rep++) {
+                double sR, sD, kR, kD;
+                chain_dualnh(a, keR, keD, &sR, &sD, &kR, &kD);
+                if (rep == 0) {
+                    st[L.off_scale_a + 0] = sR; st[L.off_scale_a + 1] = 1.0; st[L.off_scale_a + 2] = sD;
+                    st[L.off_ke_post + 0] = kR; st[L.off_ke_post + 1] = 0.0; st[L.off_ke_post + 2] = kD;
+                } else {
+                    st[L.off_scale_b + 0] = sR; st[L.off_scale_b + 1] = 1.0; st[L.off_scale_b + 2] = sD;
+                }
+                totR *= sR; totD *= sD; keR = kR; keD = kD;
+            }
+            if (reps == 1) { st[L.off_scale_b + 0] = 1.0; st[L.off_scale_b + 1] = 1.0; st[L.off_scale_b + 2] = 1.0; }
+            st[L.off_scale + 0] = totR; st[L.off_scale + 1] = 1.0; st[L.off_scale + 2] = totD;
+            st[L.off_kesum] = 0.5 * (st[L.off_ke + 0] + st[L.off_ke + 2]);
+        }
+    }
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------
+// harness force (bench/test workload; not part of the reference)
+// ---------------------------------------------------------------------------
+template <int PREC>
+__global__ __launch_bounds__(BLOCK) void force_kernel(const ForceArgs a) {
+    typedef typename Prec<PREC>::real4 real4;
+    typedef typename Prec<PREC>::mixed mixed;
+    typedef typename Prec<PREC>::mixed4 mixed4;
+    const real4* __restrict__ posq = reinterpret_cast<const real4*>(a.posq);
+    const float4* __restrict__ pcorr = reinterpret_cast<const float4*>(a.posq_corr);
+    const mixed4* __restrict__ x0 = reinterpret_cast<const mixed4*>(a.x0);
+    const mixed4* __restrict__ velm = reinterpret_cast<const mixed4*>(a.velm);
+    const mixed kd = (mixed)a.k_drude, kt = (mixed)a.k_tether;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += gridDim.x * BLOCK) {
+        const uint32_t m = a.meta[i];
+        const uint32_t role = m & 3u;
+        const real4 p = posq[i];
+        mixed x = p.x, y = p.y, z = p.z;
+        if (PREC == TGNH_PREC_MIXED) { const float4 c = pcorr[i]; x += (mixed)c.x; y += (mixed)c.y; z += (mixed)c.z; }
+        mixed fx = 0, fy = 0, fz = 0;
+        const bool massive = velm[i].w != 0;
+        if (role == ROLE_NORMAL) {
+            if (massive) { const mixed4 s = x0[i]; fx = -kt * (x - s.x); fy = -kt * (y - s.y); fz = -kt * (z - s.z); }
+        } else {
+            const int j = i + (int)((m >> 10) & 2047u) - 1024;
+            const real4 q = posq[j];
+            mixed ox = q.x, oy = q.y, oz = q.z;
+            if (PREC == TGNH_PREC_MIXED) { const float4 c = pcorr[j]; ox += (mixed)c.x; oy += (mixed)c.y; oz += (mixed)c.z; }
+            if (role == ROLE_DRUDE) {
+                fx = -kd * (x - ox); fy = -kd * (y - oy); fz = -kd * (z - oz);
+            } else {
+                const mixed4 s = x0[i];
+                fx = kd * (ox - x) - kt * (x - s.x); fy = kd * (oy - y) - kt * (y - s.y); fz = kd * (oz - z) - kt * (z - s.z);
+            }
+        }
+        a.force[i] = (long long)(fx * (mixed)4294967296.0);
+        a.force[i + a.padded] = (long long)(fy * (mixed)4294967296.0);
+        a.force[i + 2 * a.padded] = (long long)(fz * (mixed)4294967296.0);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// plain / time-shifted kinetic energy (A12): 1/2 sum (v + F ts /m)^2 m
+// Cu :656 (ts = 0) ; Ref :70-98 (ts = dt/2, no constraints)
+// ---------------------------------------------------------------------------
+template <int PREC>
+__global__ __launch_bounds__(BLOCK) void plain_ke_kernel(const void* velm_, const long long* force, int n, int padded,
+                                                         double ts, double* out) {
+    typedef typename Prec<PREC>::mixed4 mixed4;
+    __shared__ double sred[BLOCK / 64];
+    const mixed4* __restrict__ velm = reinterpret_cast<const mixed4*>(velm_);
+    const double fs = ts / 4294967296.0;
+    double e = 0.0;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const mixed4 v = velm[i];
+        if (v.w != 0) {
+            double vx = v.x, vy = v.y, vz = v.z;
+            if (ts != 0.0) {
+                const double c = fs * (double)v.w;
+                vx += c * (double)force[i]; vy += c * (double)force[i + padded]; vz += c * (double)force[i + 2 * padded];
+            }
+            e += (vx * vx + vy * vy + vz * vz) / (double)v.w;
+        }
+    }
+    e = wave_sum(e);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < BLOCK / 64; w++) s += sred[w];
+        atomicAdd(out, 0.5 * s);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+template <int PREC, int OPS>
+static hipError_t launch_tile_gb(int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s) {
+    if constexpr ((OPS & OP_KE) != 0) {
+        if (gb <= 1) hipLaunchKernelGGL((tile_kernel<PREC, OPS, 1>), dim3(grid), dim3(BLOCK), lds, s, a);
+        else if (gb <= 4) hipLaunchKernelGGL((tile_kernel<PREC, OPS, 4>), dim3(grid), dim3(BLOCK), lds, s, a);
+        else hipLaunchKernelGGL((tile_kernel<PREC, OPS, 8>), dim3(grid), dim3(BLOCK), lds, s, a);
+    } else {
+        hipLaunchKernelGGL((tile_kernel<PREC, OPS, 1>), dim3(grid), dim3(BLOCK), lds, s, a);
+    }
+    return hipGetLastError();
+}
+
+template <int PREC>
+static hipError_t launch_tile_ops(int ops, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s) {
+    switch (ops) {
+        case OP_KE: return launch_tile_gb<PREC, OP_KE>(gb, a, grid, lds, s);
+        case OP_SCALE: return launch_tile_gb<PREC, OP_SCALE>(gb, a, grid, lds, s);
+        case OP_SCALE | OP_KE: return launch_tile_gb<PREC, OP_SCALE | OP_KE>(gb, a, grid, lds, s);
+        case OP_SCALE | OP_KICK | OP_DRIFT: return launch_tile_gb<PREC, OP_SCALE | OP_KICK | OP_DRIFT>(gb, a, grid, lds, s);
+        case OP_KICK | OP_KE: return launch_tile_gb<PREC, OP_KICK | OP_KE>(gb, a, grid, lds, s);
+        case OP_KICK: return launch_tile_gb<PREC, OP_KICK>(gb, a, grid, lds, s);
+        case OP_SCALE | OP_KICK | OP_POSDELTA: return launch_tile_gb<PREC, OP_SCALE | OP_KICK | OP_POSDELTA>(gb, a, grid, lds, s);
+        case OP_MOVE: return launch_tile_gb<PREC, OP_MOVE>(gb, a, grid, lds, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s) {
+    switch (precision) {
+        case TGNH_PREC_SINGLE: return launch_tile_ops<TGNH_PREC_SINGLE>(ops, gb, a, grid, lds, s);
+        case TGNH_PREC_MIXED: return launch_tile_ops<TGNH_PREC_MIXED>(ops, gb, a, grid, lds, s);
+        case TGNH_PREC_DOUBLE: return launch_tile_ops<TGNH_PREC_DOUBLE>(ops, gb, a, grid, lds, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_force(int precision, const ForceArgs& a, hipStream_t s) {
+    int grid = (a.n + BLOCK - 1) / BLOCK;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    switch (precision) {
+        case TGNH_PREC_SINGLE: hipLaunchKernelGGL((force_kernel<TGNH_PREC_SINGLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_MIXED: hipLaunchKernelGGL((force_kernel<TGNH_PREC_MIXED>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_DOUBLE: hipLaunchKernelGGL((force_kernel<TGNH_PREC_DOUBLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_plain_ke(int precision, const void* velm, const long long* force, int n, int padded,
+                           double time_shift, double* out, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), s);
+    if (e != hipSuccess) return e;
+    int grid = (n + BLOCK - 1) / BLOCK;
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    switch (precision) {
+        case TGNH_PREC_SINGLE: hipLaunchKernelGGL((plain_ke_kernel<TGNH_PREC_SINGLE>), dim3(grid), dim3(BLOCK), 0, s, velm, force, n, padded, time_shift, out); break;
+        case TGNH_PREC_MIXED: hipLaunchKernelGGL((plain_ke_kernel<TGNH_PREC_MIXED>), dim3(grid), dim3(BLOCK), 0, s, velm, force, n, padded, time_shift, out); break;
+        case TGNH_PREC_DOUBLE: hipLaunchKernelGGL((plain_ke_kernel<TGNH_PREC_DOUBLE>), dim3(grid), dim3(BLOCK), 0, s, velm, force, n, padded, time_shift, out); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace tgnh

@@ -1,0 +1,437 @@
+"""Host-side mirror of the reference's Python surface over the HIP C ABI.
+
+`DrudeTGNHIntegrator` keeps the method names, argument meaning, defaults and error
+behaviour of the SWIG class (python/drudetgnhplugin.i:60-92 of scychon/openmm_drudeNose,
+C++ side openmmapi/src/DrudeTGNHIntegrator.cpp).  OpenMM is not available here, so
+`HipContext` stands where OpenMM's Context + HIP platform would: it owns the device
+arrays in OpenMM's layouts (posq real4, velm mixed4 with w = 1/m, force int64 x 2^32 in
+three planes, posqCorrection in mixed precision) and drives the C ABI.  torch is used
+for device memory, streams and torch.distributed only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (MODE_DUALNH, MODE_TGNH, PREC_SINGLE, PREC_MIXED, PREC_DOUBLE,  # noqa: F401
+                   FLAG_MERGE_SCALE_KE, FLAG_DEFER_SCALE)
+from .synth import KB
+
+_PREC = {"single": PREC_SINGLE, "mixed": PREC_MIXED, "double": PREC_DOUBLE}
+_MODE = {"dualNH": MODE_DUALNH, "TGNH": MODE_TGNH}
+
+
+class TgnhError(RuntimeError):
+    """Stands for OpenMMException; .status is the C-ABI status code."""
+
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+def _check(rc):
+    if rc != _lib.TGNH_OK:
+        raise TgnhError(rc, _lib.load().tgnh_last_error().decode())
+
+
+class DrudeTGNHIntegrator:
+    """Same constructor and methods as the reference's SWIG class (drudetgnhplugin.i:60-92).
+    Note the Python default useDrudeNHChains=True (the C++ default is false,
+    DrudeTGNHIntegrator.h:71)."""
+
+    def __init__(self, temperature, couplingTime, drudeTemperature, drudeCouplingTime, stepSize,
+                 drudeStepsPerRealStep=20, numNHChains=1, useDrudeNHChains=True, useCOMTempGroup=True):
+        self._temperature = float(temperature)
+        self._couplingTime = float(couplingTime)
+        self._drudeTemperature = float(drudeTemperature)
+        self._drudeCouplingTime = float(drudeCouplingTime)
+        self._maxDrudeDistance = 0.0
+        self._stepSize = float(stepSize)
+        self._drudeSteps = int(drudeStepsPerRealStep)
+        self._numNHChains = int(numNHChains)
+        self._useDrudeNHChains = bool(useDrudeNHChains)
+        self._useCOMTempGroup = bool(useCOMTempGroup)
+        self._constraintTolerance = 1e-5                     # DrudeTGNHIntegrator.cpp:58
+        self._tempGroups = []
+        self._particleTempGroup = []
+        self._context = None
+
+    # --- scalar properties (DrudeTGNHIntegrator.h:77-211) ---
+    def getTemperature(self): return self._temperature
+    def setTemperature(self, temp): self._temperature = float(temp)
+    def getCouplingTime(self): return self._couplingTime
+    def setCouplingTime(self, tau): self._couplingTime = float(tau)
+    def getDrudeTemperature(self): return self._drudeTemperature
+    def setDrudeTemperature(self, temp): self._drudeTemperature = float(temp)
+    def getDrudeCouplingTime(self): return self._drudeCouplingTime
+    def setDrudeCouplingTime(self, tau): self._drudeCouplingTime = float(tau)
+    def getMaxDrudeDistance(self): return self._maxDrudeDistance
+
+    def setMaxDrudeDistance(self, distance):
+        if distance < 0:                                     # DrudeTGNHIntegrator.cpp:97-100
+            raise TgnhError(_lib.ERR_ARG, "setMaxDrudeDistance: Distance cannot be negative")
+        self._maxDrudeDistance = float(distance)
+        if self._context is not None:
+            self._context._push_scalars()
+
+    def getStepSize(self): return self._stepSize
+
+    def setStepSize(self, dt):
+        self._stepSize = float(dt)
+        if self._context is not None:
+            self._context._push_scalars()
+
+    def getConstraintTolerance(self): return self._constraintTolerance
+    def setConstraintTolerance(self, tol): self._constraintTolerance = float(tol)
+    def getDrudeStepsPerRealStep(self): return self._drudeSteps
+
+    def setDrudeStepsPerRealStep(self, drudeSteps):
+        self._drudeSteps = int(drudeSteps)
+        if self._context is not None:
+            self._context._push_scalars()
+
+    def getNumNHChains(self): return self._numNHChains
+    def setNumNHChains(self, numChains): self._numNHChains = int(numChains)
+    def getUseDrudeNHChains(self): return int(self._useDrudeNHChains)
+    def setUseDrudeNHChains(self, use): self._useDrudeNHChains = bool(use)
+    def getUseCOMTempGroup(self): return int(self._useCOMTempGroup)
+    def setUseCOMTempGroup(self, use): self._useCOMTempGroup = bool(use)
+
+    # --- temperature groups (DrudeTGNHIntegrator.cpp:61-86) ---
+    def getNumTempGroups(self): return len(self._tempGroups)
+
+    def addTempGroup(self):
+        self._tempGroups.append(len(self._tempGroups))
+        return len(self._tempGroups) - 1
+
+    def addParticleTempGroup(self, tempGroup):
+        if not 0 <= tempGroup < len(self._tempGroups):       # ASSERT_VALID_INDEX
+            raise TgnhError(_lib.ERR_ARG, "Index out of range")
+        self._particleTempGroup.append(int(tempGroup))
+        return len(self._particleTempGroup) - 1
+
+    def setParticleTempGroup(self, particle, tempGroup):
+        if not 0 <= particle < len(self._particleTempGroup) or not 0 <= tempGroup < len(self._tempGroups):
+            raise TgnhError(_lib.ERR_ARG, "Index out of range")
+        self._particleTempGroup[particle] = int(tempGroup)
+
+    def getParticleTempGroup(self, particle):
+        if not 0 <= particle < len(self._particleTempGroup):
+            raise TgnhError(_lib.ERR_ARG, "Index out of range")
+        return self._particleTempGroup[particle]
+
+    # --- stepping (DrudeTGNHIntegrator.cpp:182-194) ---
+    def step(self, steps):
+        if self._context is None:
+            raise TgnhError(_lib.ERR_STATE, "This Integrator is not bound to a context!")
+        self._context.step(steps)
+
+    def computeKineticEnergy(self):
+        return self._context.kinetic_energy()
+
+    def _resolve_groups(self, num_particles):
+        """DrudeTGNHIntegrator.cpp:126-134: default everything to one group; else the count must match."""
+        if len(self._particleTempGroup) == 0:
+            if len(self._tempGroups) == 0:
+                self._tempGroups.append(0)
+            self._particleTempGroup = [0] * num_particles
+        elif len(self._particleTempGroup) != num_particles:
+            raise TgnhError(_lib.ERR_ARG, "Number of particles assigned with temperature groups does not match the number of system particles")
+        return np.asarray(self._particleTempGroup, np.int32), len(self._tempGroups)
+
+
+class HipContext:
+    """Device state + handle: what OpenMM's Context / HIP platform data are to the reference kernel.
+
+    force_fn(ctx) is the force call-out (calcForcesAndEnergy); the default is the
+    harness force (Drude spring + tether) computed by the library's own kernel.
+    """
+
+    def __init__(self, system, integrator, mode="TGNH", precision="mixed", device=0, flags=0, kB=KB,
+                 k_drude=None, k_tether=None, allreduce=None, global_dof_sum=None):
+        import torch
+        self.torch = torch
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("the DrudeTGNH HIP path needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.system, self.integrator = system, integrator
+        self.mode, self.precision = _MODE[mode], _PREC[precision]
+        self.dev = torch.device("cuda", device)
+        n = system.num_particles
+        self.n = n
+        self.padded = (n + 31) // 32 * 32                    # OpenMM PADDED_NUM_ATOMS (TileSize 32)
+        group, ngroups = integrator._resolve_groups(n)
+        self.group, self.num_groups = group, ngroups
+        from .synth import K_DRUDE, K_TETHER
+        self.k_drude = K_DRUDE if k_drude is None else k_drude
+        self.k_tether = K_TETHER if k_tether is None else k_tether
+
+        d = _lib.TgnhDesc()
+        d.struct_size = C.sizeof(_lib.TgnhDesc)
+        d.mode, d.precision, d.flags, d.device = self.mode, self.precision, int(flags), device
+        d.num_particles, d.padded_num_particles = n, self.padded
+        d.num_pairs, d.num_groups, d.num_residues = system.num_pairs, ngroups, system.num_residues
+        d.num_constraints = len(system.constraints)
+        d.has_cm_motion_remover = int(system.has_cm_motion_remover)
+        keep = [system.mass, system.pair_drude, system.pair_parent, group, system.resid]
+        ci = np.ascontiguousarray(system.constraints[:, 0]) if len(system.constraints) else None
+        cj = np.ascontiguousarray(system.constraints[:, 1]) if len(system.constraints) else None
+        d.mass = system.mass.ctypes.data_as(_lib.c_f64p)
+        d.pair_drude = system.pair_drude.ctypes.data_as(_lib.c_i32p)
+        d.pair_parent = system.pair_parent.ctypes.data_as(_lib.c_i32p)
+        d.group = group.ctypes.data_as(_lib.c_i32p)
+        d.resid = system.resid.ctypes.data_as(_lib.c_i32p)
+        if ci is not None:
+            d.constraint_i = ci.ctypes.data_as(_lib.c_i32p)
+            d.constraint_j = cj.ctypes.data_as(_lib.c_i32p)
+        d.kB = kB
+        d.temperature, d.coupling_time = integrator.getTemperature(), integrator.getCouplingTime()
+        d.drude_temperature, d.drude_coupling_time = integrator.getDrudeTemperature(), integrator.getDrudeCouplingTime()
+        d.step_size = integrator.getStepSize()
+        d.drude_steps_per_real_step = integrator.getDrudeStepsPerRealStep()
+        d.num_nh_chains = integrator.getNumNHChains()
+        d.use_drude_nh_chains = integrator.getUseDrudeNHChains()
+        d.use_com_temp_group = integrator.getUseCOMTempGroup()
+        d.max_drude_distance = integrator.getMaxDrudeDistance()
+        h = C.c_void_p()
+        with torch.cuda.device(self.dev):
+            _check(self.lib.tgnh_create(C.byref(d), C.byref(h)))
+        del keep
+        self.h = h
+        self._hook = None
+        if global_dof_sum is not None:                       # particle sharding: dof terms are additive over ranks
+            terms = self.local_dof_terms()
+            total = np.ascontiguousarray(global_dof_sum(terms), np.float64)
+            _check(self.lib.tgnh_set_global_dof_terms(self.h, total.ctypes.data_as(_lib.c_f64p), len(total)))
+        if allreduce is not None:
+            self.set_allreduce(allreduce)
+
+        rdt = torch.float32 if self.precision != PREC_DOUBLE else torch.float64
+        mdt = torch.float32 if self.precision == PREC_SINGLE else torch.float64
+        self.rdt, self.mdt = rdt, mdt
+        self.posq = torch.zeros((n, 4), dtype=rdt, device=self.dev)
+        self.posq_corr = torch.zeros((n, 4), dtype=torch.float32, device=self.dev) if self.precision == PREC_MIXED else None
+        self.velm = torch.zeros((n, 4), dtype=mdt, device=self.dev)
+        self.force = torch.zeros(3 * self.padded, dtype=torch.int64, device=self.dev)
+        self.pos_delta = torch.zeros((n, 4), dtype=mdt, device=self.dev)
+        self.x0 = torch.zeros((n, 4), dtype=mdt, device=self.dev)
+        inv = np.where(system.mass == 0.0, 0.0, 1.0 / np.where(system.mass == 0.0, 1.0, system.mass))
+        self.velm[:, 3] = torch.from_numpy(inv).to(self.dev, mdt)
+        _check(self.lib.tgnh_bind_buffers(self.h, self.posq.data_ptr(),
+                                          self.posq_corr.data_ptr() if self.posq_corr is not None else None,
+                                          self.velm.data_ptr(), self.force.data_ptr(), self.pos_delta.data_ptr()))
+        integrator._context = self
+        self.force_fn = None
+        self.ke_sum_valid = False
+        if system.positions is not None:
+            self.setPositions(system.positions)
+            self.set_sites(system.positions)
+        if system.velocities is not None:
+            self.setVelocities(system.velocities)
+        if system.positions is not None:
+            self.compute_forces()
+
+    # ---- plumbing ----
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _push_scalars(self):
+        i = self.integrator
+        _check(self.lib.tgnh_set_step_size(self.h, i.getStepSize()))
+        _check(self.lib.tgnh_set_drude_steps_per_real_step(self.h, i.getDrudeStepsPerRealStep()))
+        _check(self.lib.tgnh_set_max_drude_distance(self.h, i.getMaxDrudeDistance()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.torch.cuda.synchronize(self.dev)
+            self.lib.tgnh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_allreduce(self, fn):
+        """fn(tensor_view) must sum the float64 device tensor in place over all ranks (stream-ordered)."""
+        torch = self.torch
+
+        def _hook(buf, count, stream, user):
+            try:
+                t = self._ke_view(buf, count)
+                fn(t)
+                return 0
+            except Exception as e:     # never unwind through C
+                print("all-reduce hook failed:", e)
+                return 1
+        self._hook = _lib.ALLREDUCE_FN(_hook)
+        self._views = {}
+        _check(self.lib.tgnh_set_allreduce(self.h, self._hook, None))
+
+    def _ke_view(self, ptr, count):
+        key = (ptr, count)
+        v = self._views.get(key)
+        if v is None:
+            torch = self.torch
+
+            class _Holder:
+                pass
+            hold = _Holder()
+            hold.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+            v = torch.as_tensor(hold, device=self.dev)
+            self._views[key] = v
+        return v
+
+    def local_dof_terms(self):
+        n = C.c_int()
+        _check(self.lib.tgnh_get_local_dof_terms(self.h, None, C.byref(n)))
+        out = np.zeros(n.value)
+        _check(self.lib.tgnh_get_local_dof_terms(self.h, out.ctypes.data_as(_lib.c_f64p), C.byref(n)))
+        return out
+
+    # ---- state (Context::setPositions / setVelocities / getState) ----
+    def setPositions(self, pos):
+        torch = self.torch
+        p = torch.from_numpy(np.ascontiguousarray(pos, np.float64)).to(self.dev)
+        if self.precision == PREC_DOUBLE:
+            self.posq[:, :3] = p
+        else:
+            hi = p.to(torch.float32)
+            self.posq[:, :3] = hi
+            if self.posq_corr is not None:
+                self.posq_corr[:, :3] = (p - hi.to(torch.float64)).to(torch.float32)
+        self._state_changed()
+
+    def set_sites(self, x0):
+        self.x0[:, :3] = self.torch.from_numpy(np.ascontiguousarray(x0, np.float64)).to(self.dev, self.mdt)
+
+    def setVelocities(self, vel):
+        self.velm[:, :3] = self.torch.from_numpy(np.ascontiguousarray(vel, np.float64)).to(self.dev, self.mdt)
+        self._state_changed()
+
+    def _state_changed(self):                                # DrudeTGNHIntegrator.cpp:166-170
+        self.ke_sum_valid = False
+        _check(self.lib.tgnh_state_changed(self.h))
+
+    def getPositions(self):
+        p = self.posq[:, :3].to(self.torch.float64)
+        if self.posq_corr is not None:
+            p = p + self.posq_corr[:, :3].to(self.torch.float64)
+        return p.cpu().numpy()
+
+    def getVelocities(self):
+        _check(self.lib.tgnh_flush(self.h, self._stream()))
+        return self.velm[:, :3].to(self.torch.float64).cpu().numpy()
+
+    def getForces(self):
+        f = self.force.view(3, self.padded)[:, :self.n].to(self.torch.float64) / 4294967296.0
+        return f.t().contiguous().cpu().numpy()
+
+    def setForces(self, f):
+        """Forces in kJ/mol/nm -> OpenMM fixed point (long long)(f * 2^32)."""
+        t = self.torch.from_numpy(np.ascontiguousarray(f, np.float64)).to(self.dev)
+        self.force.view(3, self.padded)[:, :self.n] = (t * 4294967296.0).to(self.torch.int64).t()
+
+    # ---- the step ----
+    def compute_forces(self):
+        if self.force_fn is not None:
+            self.force_fn(self)
+        else:
+            _check(self.lib.tgnh_harness_force(self.h, self.x0.data_ptr(), self.k_drude, self.k_tether,
+                                               self.force.data_ptr(), self._stream()))
+
+    def step_begin(self):
+        _check(self.lib.tgnh_step_begin(self.h, self._stream()))
+
+    def step_end(self):
+        _check(self.lib.tgnh_step_end(self.h, self._stream()))
+        self.ke_sum_valid = True                             # DrudeTGNHIntegrator.cpp:192
+
+    def step(self, steps):
+        if self.force_fn is None:
+            _check(self.lib.tgnh_run_harness(self.h, self.x0.data_ptr(), self.k_drude, self.k_tether, int(steps), self._stream()))
+            if steps > 0:
+                self.ke_sum_valid = True
+            return
+        for _ in range(steps):
+            self.step_begin()
+            self.compute_forces()
+            self.step_end()
+
+    def check(self):
+        """Raises if the device flagged a Drude beyond 2x the hard wall (dualNH mode, Ref :311-312)."""
+        flags = C.c_uint32()
+        _check(self.lib.tgnh_get_status_flags(self.h, self._stream(), C.byref(flags)))
+        return flags.value
+
+    # ---- queries ----
+    def num_thermostats(self):
+        n = C.c_int()
+        _check(self.lib.tgnh_get_num_thermostats(self.h, C.byref(n)))
+        return n.value
+
+    def _vec(self, fn, n):
+        out = np.zeros(n)
+        _check(fn(self.h, self._stream(), out.ctypes.data_as(_lib.c_f64p)))
+        return out
+
+    def last_kinetic_energies(self):
+        return self._vec(self.lib.tgnh_get_last_kinetic_energies, self.num_thermostats())
+
+    def last_scale_factors(self):
+        return self._vec(self.lib.tgnh_get_last_scale_factors, self.num_thermostats())
+
+    def compute_kinetic_energies(self):
+        _check(self.lib.tgnh_compute_kinetic_energies(self.h, self._stream()))
+        return self.last_kinetic_energies()
+
+    def half_kick(self):
+        _check(self.lib.tgnh_half_kick(self.h, self._stream()))
+
+    def kinetic_energy(self):
+        out = C.c_double()
+        _check(self.lib.tgnh_get_kinetic_energy(self.h, int(self.ke_sum_valid), self._stream(), C.byref(out)))
+        return out.value
+
+    def dof(self):
+        n = self.num_thermostats()
+        dof, nkt = np.zeros(n), np.zeros(n)
+        _check(self.lib.tgnh_get_dof(self.h, dof.ctypes.data_as(_lib.c_f64p), nkt.ctypes.data_as(_lib.c_f64p)))
+        return dof, nkt
+
+    def thermostat_state(self, which):
+        n = C.c_int()
+        _check(self.lib.tgnh_get_thermostat_len(self.h, which, C.byref(n)))
+        out = np.zeros(n.value)
+        _check(self.lib.tgnh_get_thermostat_state(self.h, which, self._stream(), out.ctypes.data_as(_lib.c_f64p)))
+        return out
+
+    def set_thermostat_state(self, which, arr):
+        arr = np.ascontiguousarray(arr, np.float64)
+        _check(self.lib.tgnh_set_thermostat_state(self.h, which, self._stream(), arr.ctypes.data_as(_lib.c_f64p)))
+
+    def topology(self, which):
+        n = C.c_int()
+        _check(self.lib.tgnh_get_topology_len(self.h, which, C.byref(n)))
+        out = np.zeros(n.value, np.int32)
+        _check(self.lib.tgnh_get_topology(self.h, which, out.ctypes.data_as(_lib.c_i32p)))
+        return out
+
+    def time(self):
+        t, k = C.c_double(), C.c_int64()
+        _check(self.lib.tgnh_get_time(self.h, C.byref(t), C.byref(k)))
+        return t.value, k.value
+
+    def timing(self, on):
+        _check(self.lib.tgnh_timing_enable(self.h, int(on)))
+
+    def timing_read(self, kid):
+        ms, n = C.c_double(), C.c_int64()
+        _check(self.lib.tgnh_timing_read(self.h, kid, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def algorithmic_bytes(self, kid):
+        b = C.c_double()
+        _check(self.lib.tgnh_algorithmic_bytes(self.h, kid, C.byref(b)))
+        return b.value

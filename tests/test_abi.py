@@ -1,0 +1,93 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/drude_tgnh.h declares,
+argument validation fails loudly, and the host-side mirror keeps the reference's API behaviour.
+No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from openmm_drudenose_amd import _lib, synth
+from openmm_drudenose_amd.drudetgnhplugin import DrudeTGNHIntegrator, TgnhError
+from openmm_drudenose_amd.system import shard_bounds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "drude_tgnh.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tgnh_[a-z_0-9]+)\s*\(", text)) - {"tgnh_allreduce_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/drude_tgnh.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
+    assert lib.tgnh_abi_version() == 1
+
+
+def test_create_rejects_bad_desc():
+    lib = _lib.load()
+    d = _lib.TgnhDesc()
+    h = C.c_void_p()
+    assert lib.tgnh_create(C.byref(d), C.byref(h)) == _lib.ERR_ARG       # struct_size 0
+    assert b"size mismatch" in lib.tgnh_last_error()
+    d.struct_size = C.sizeof(d)
+    assert lib.tgnh_create(C.byref(d), C.byref(h)) == _lib.ERR_ARG
+    assert lib.tgnh_destroy(None) == _lib.ERR_ARG
+
+
+def test_integrator_api_mirror():
+    # python/drudetgnhplugin.i:62 default useDrudeNHChains=True; DrudeTGNHIntegrator.cpp:58 tolerance 1e-5
+    it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001)
+    assert it.getDrudeStepsPerRealStep() == 20 and it.getNumNHChains() == 1
+    assert it.getUseDrudeNHChains() == 1 and it.getUseCOMTempGroup() == 1
+    assert it.getConstraintTolerance() == 1e-5 and it.getMaxDrudeDistance() == 0
+    with pytest.raises(TgnhError, match="Distance cannot be negative"):      # DrudeTGNHIntegrator.cpp:97-100
+        it.setMaxDrudeDistance(-1.0)
+    # DrudeTGNHIntegrator.cpp:61-70: addTempGroup returns the running index; addParticleTempGroup is range-checked
+    assert it.getNumTempGroups() == 0
+    with pytest.raises(TgnhError):
+        it.addParticleTempGroup(0)
+    assert it.addTempGroup() == 0 and it.addTempGroup() == 1
+    assert it.addParticleTempGroup(1) == 0 and it.getParticleTempGroup(0) == 1
+    it.setParticleTempGroup(0, 0)
+    assert it.getParticleTempGroup(0) == 0
+    with pytest.raises(TgnhError):
+        it.setParticleTempGroup(3, 0)
+    with pytest.raises(TgnhError, match="does not match"):                  # :133-134
+        it._resolve_groups(5)
+    with pytest.raises(TgnhError, match="not bound to a context"):          # :183-184
+        it.step(1)
+    it2 = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001)
+    g, ng = it2._resolve_groups(7)                                          # :127-132 default: everything in group 0
+    assert ng == 1 and np.array_equal(g, np.zeros(7, np.int32))
+
+
+def test_synthetic_configs_have_the_documented_sizes():
+    s, g, ng = synth.nacl()
+    assert (s.num_particles, s.num_pairs, s.num_residues, ng) == (2500, 512, 512, 1)
+    s, g, ng = synth.water_box(6400)
+    assert (s.num_particles, s.num_pairs, ng) == (32000, 6400, 1)
+    s, g, ng = synth.ionic_liquid(22)
+    assert (s.num_particles, s.num_pairs, s.num_residues, ng) == (990, 330, 44, 2)
+    s, g, ng = synth.mixed(60, 4)
+    assert s.num_particles == 300 + 180 and ng == 4 and set(np.unique(g)) == {0, 1, 2, 3}
+    assert np.all(g[s.pair_drude] == g[s.pair_parent])
+
+
+def test_shard_bounds_cut_at_molecules():
+    s, g, ng = synth.mixed(100, 7)
+    for w in (2, 3, 4, 8):
+        b = shard_bounds(s, w)
+        assert b[0] == 0 and b[-1] == s.num_particles and all(x <= y for x, y in zip(b, b[1:]))
+        for x in b[1:-1]:
+            assert s.resid[x] != s.resid[x - 1]
+        parts = [s.slice_molecules(lo, hi) for lo, hi in zip(b, b[1:])]
+        assert sum(p.num_particles for p in parts) == s.num_particles
+        assert sum(p.num_pairs for p in parts) == s.num_pairs
