@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- integrator steps/s at 1 M Drude pairs (BASELINE.json metric) on N MI355X GPUs.
+
+A "step" is one full DrudeTGNHIntegrator time step (thermostat half step, rescale, half kick,
+drift, [force call-out], half kick, thermostat half step, rescale) over the whole synthetic
+SWM4-NDP water box of 1,000,000 molecules (5,000,000 particle slots, 1,000,000 Drude pairs),
+state resident in HBM.  The force call-out (OpenMM's calcForcesAndEnergy in a real context) is
+the harness spring kernel and is INSIDE the timed region.  N > 1 shards whole molecules over the
+ranks (strong scaling: the 1 M-pair system is fixed) with one all-reduce of the per-thermostat
+kinetic-energy sums per thermostat half step (RCCL through torch.distributed).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s measured achievable)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=1000)
+    p.add_argument("--warmup", type=int, default=100)
+    p.add_argument("--molecules", type=int, default=1_000_000, help="SWM4 molecules = Drude pairs (metric: 1,000,000)")
+    p.add_argument("--precision", default="mixed", choices=["single", "mixed", "double"])
+    p.add_argument("--mode", default="TGNH", choices=["TGNH", "dualNH"])
+    p.add_argument("--variant", default="plain", choices=["plain", "merge", "defer"],
+                   help="plain = the reference's pass structure; merge / defer = fused end-of-step rescale (DESIGN.md)")
+    p.add_argument("--chains", type=int, default=1)
+    p.add_argument("--hardwall", type=float, default=0.02, help="maxDrudeDistance nm (example/nacl_tg.py:22); 0 = off")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (rank 0, N=1)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extra", action="store_true", help="skip the extra single-precision / variant legs")
+    return p.parse_args()
+
+
+def build_context(args, system, group, ngroups, rank, world, precision, variant):
+    import torch
+    import torch.distributed as dist
+    from openmm_drudenose_amd import DrudeTGNHIntegrator, HipContext
+    from openmm_drudenose_amd.drudetgnhplugin import FLAG_MERGE_SCALE_KE, FLAG_DEFER_SCALE
+    from openmm_drudenose_amd.system import shard_bounds
+    it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, args.chains, True, True)
+    it.setMaxDrudeDistance(args.hardwall)
+    flags = {"plain": 0, "merge": FLAG_MERGE_SCALE_KE, "defer": FLAG_DEFER_SCALE}[variant]
+    local, lgroup = system, group
+    if world > 1:
+        b = shard_bounds(system, world)
+        local = system.slice_molecules(b[rank], b[rank + 1])
+        lgroup = group[b[rank]:b[rank + 1]]
+    if args.mode == "TGNH":
+        for _ in range(ngroups):
+            it.addTempGroup()
+        it._particleTempGroup = [int(x) for x in lgroup]
+    dev = torch.cuda.current_device()
+    kw = {}
+    if world > 1:
+        def dof_sum(terms):
+            t = torch.tensor(terms, dtype=torch.float64, device="cuda")
+            dist.all_reduce(t)
+            return t.cpu().numpy()
+        kw = dict(allreduce=lambda t: dist.all_reduce(t), global_dof_sum=dof_sum)
+    return HipContext(local, it, mode=args.mode, precision=precision, device=dev, flags=flags, **kw)
+
+
+def timed_run(ctx, steps, warmup, world):
+    import torch
+    import torch.distributed as dist
+    ctx.step(warmup)
+    torch.cuda.synchronize()
+    ctx.timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.step(steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ctx.timing(False)
+    return dt
+
+
+def kernel_table(ctx):
+    from openmm_drudenose_amd import _lib
+    rows = {}
+    for kid, name in _lib.KERNEL_NAMES.items():
+        ms, n = ctx.timing_read(kid)
+        if n:
+            b = ctx.algorithmic_bytes(kid)
+            avg_us = ms / n * 1e3
+            rows[name] = {"launches": n, "avg_us": round(avg_us, 3), "algorithmic_MB": round(b / 1e6, 3),
+                          "GBps": round(b / (avg_us * 1e-6) / 1e9, 1) if b else None}
+    return rows
+
+
+def cpu_baseline(args, system, group, ngroups):
+    """The CPU oracle (the restatement of the reference's algorithm, 1 thread -- the reference platform is
+    single-threaded scalar code) on the same system, same mode, same harness force; a bounded number of steps."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from openmm_drudenose_amd import synth
+    from oracle import Oracle, MODE_TGNH, MODE_DUALNH
+    mode = MODE_TGNH if args.mode == "TGNH" else MODE_DUALNH
+    g = group if args.mode == "TGNH" else np.zeros_like(group)
+    o = Oracle(system, g, ngroups if args.mode == "TGNH" else 1, mode, 300.0, 0.1, 1.0, 0.005, 0.001, 20, args.chains,
+               True, True, args.hardwall)
+    pos, vel, x0 = system.positions.copy(), system.velocities.copy(), system.positions.copy()
+    f = o.harness_force(pos, x0, synth.K_DRUDE, synth.K_TETHER)
+    t0 = time.perf_counter()
+    o.run_harness(pos, vel, f, x0, synth.K_DRUDE, synth.K_TETHER, 2)
+    per = (time.perf_counter() - t0) / 2
+    n = int(max(3, min(200, args.cpu_seconds / max(per, 1e-6))))
+    t0 = time.perf_counter()
+    o.run_harness(pos, vel, f, x0, synth.K_DRUDE, synth.K_TETHER, n)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 4), "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} steps of the same {system.num_pairs}-pair system ({system.num_particles} slots), "
+                      f"oracle/tgnh_oracle.c {args.mode} mode, fp64, gcc -O2, harness force included",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from openmm_drudenose_amd import synth, _lib
+    system, group, ngroups = synth.water_box(args.molecules)
+
+    ctx = build_context(args, system, group, ngroups, rank, world, args.precision, args.variant)
+    dt = timed_run(ctx, args.steps, args.warmup, world)
+    rows = kernel_table(ctx)
+    assert ctx.check() == 0
+    # dominant kernel: the fused rescale + half kick + drift (+ hard wall) pass
+    dom = rows.get("scale+kick+drift")
+    bytes_dom = ctx.algorithmic_bytes(_lib.KID_SKD)
+    achieved = bytes_dom / (dom["avg_us"] * 1e-6) / 1e9
+    local_slots = ctx.n
+    ctx.close()
+
+    extra = {}
+    if world == 1 and not args.no_extra:
+        for prec, var in (("single", "plain"), (args.precision, "defer")):
+            if (prec, var) == (args.precision, args.variant):
+                continue
+            c2 = build_context(args, system, group, ngroups, rank, world, prec, var)
+            d2 = timed_run(c2, args.steps, args.warmup, world)
+            r2 = kernel_table(c2)
+            extra[f"{prec}/{var}"] = {"steps_per_s": round(args.steps / d2, 2), "ms_per_step": round(d2 / args.steps * 1e3, 4),
+                                     "kernels": r2}
+            c2.close()
+
+    out = None
+    if rank == 0:
+        V = 16 if args.precision == "single" else 32
+        X = 16 if args.precision == "single" else 32
+        b_step = system.num_particles * (7 * V + 2 * 24 + 2 * X)
+        out = {
+            "metric": "integrator steps/sec at 1M Drude pairs",
+            "value": round(args.steps / dt, 3), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "single" else "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"SWM4-NDP water box, {args.molecules} molecules = {system.num_particles} particle slots, "
+                            f"{system.num_pairs} Drude pairs, 1 temperature group (+ molecular-COM and Drude thermostats), "
+                            f"{args.mode} mode, {args.precision} precision, numNHChains={args.chains}, hard wall "
+                            f"{args.hardwall} nm, harness force call-out inside the timed region",
+                "precision": args.precision, "variant": args.variant,
+                "parallelism": f"particle-sharded x{world} (whole molecules), KE all-reduce per thermostat half step",
+                "slots_per_gpu": local_slots,
+                "model_bytes_per_step": b_step,
+                "step_GBps_vs_model": round(b_step / (dt / args.steps) / 1e9 / world, 1),
+            },
+            "roofline": {"bound": "hbm", "kernel": "tile_kernel<scale+kick+drift>", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_dom, "avg_launch_us": dom["avg_us"]},
+            "kernels": rows,
+        }
+        if extra:
+            out["extra"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, system, group, ngroups)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

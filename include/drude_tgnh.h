@@ -120,7 +120,7 @@ tgnh_status tgnh_set_max_drude_distance(tgnh_handle h, double d);
 
 /* Particle sharding: dof terms are additive over ranks.  terms = per-thermostat
  * degrees of freedom before the global CMMotionRemover correction
- * (DUALNH: 2 values; TGNH: G+2).  Sum them over ranks and hand them back. */
+ * (NT values, see tgnh_get_num_thermostats).  Sum them over ranks and hand them back. */
 tgnh_status tgnh_get_local_dof_terms(tgnh_handle h, double* terms, int* count);
 tgnh_status tgnh_set_global_dof_terms(tgnh_handle h, const double* terms, int count);
 tgnh_status tgnh_set_allreduce(tgnh_handle h, tgnh_allreduce_fn fn, void* user);
@@ -151,7 +151,7 @@ tgnh_status tgnh_state_changed(tgnh_handle h);
 
 /* Host-visible results (synchronise `stream`). */
 tgnh_status tgnh_get_kinetic_energy(tgnh_handle h, int ke_sum_valid, void* stream, double* out);
-tgnh_status tgnh_get_num_thermostats(tgnh_handle h, int* count);               /* DUALNH 2, TGNH G+2 */
+tgnh_status tgnh_get_num_thermostats(tgnh_handle h, int* count);               /* NT: TGNH G+2 = [groups.., COM, Drude]; DUALNH 3 = [real, unused, Drude] */
 tgnh_status tgnh_get_last_kinetic_energies(tgnh_handle h, void* stream, double* ke);   /* no 1/2; before the chain */
 tgnh_status tgnh_get_last_scale_factors(tgnh_handle h, void* stream, double* scale);
 tgnh_status tgnh_get_status_flags(tgnh_handle h, void* stream, uint32_t* flags);   /* bit0: Drude beyond 2x hard wall */
@@ -177,8 +177,8 @@ tgnh_status tgnh_compute_kinetic_energies(tgnh_handle h, void* stream);         
 tgnh_status tgnh_half_kick(tgnh_handle h, void* stream);                         /* A7 only */
 
 /* Harness force (bench/test workload, not part of the reference): Drude spring
- * + tether to sites x0 (mixed4 [N] device array), written in OpenMM's
- * fixed-point layout into `force_out` (int64 [3*padded]). */
+ * + tether to sites x0 (real4 [N] device array: x,y,z and w = 1 for a tethered slot, 0 otherwise),
+ * written in OpenMM's fixed-point layout into `force_out` (int64 [3*padded]). */
 tgnh_status tgnh_harness_force(tgnh_handle h, const void* x0, double k_drude, double k_tether,
                                void* force_out, void* stream);
 /* nsteps x { step_begin, harness force into the bound force buffer, step_end }

@@ -345,6 +345,11 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         return fail(TGNH_ERR_ARG, "TGNH mode needs temperature groups and residues");
     if (d->max_drude_distance < 0) return fail(TGNH_ERR_ARG, "setMaxDrudeDistance: Distance cannot be negative");   // API :98-99
     if (d->step_size <= 0) return fail(TGNH_ERR_ARG, "step size must be positive");
+    {   // the chain kernel keeps chains longer than 4 links in a 2048-double LDS scratch
+        const long need = d->mode == TGNH_MODE_TGNH ? (long)(d->num_groups + 2) * (4L * d->num_nh_chains + 1)
+                                                    : 4L * (2L * d->num_nh_chains + 4);
+        if (d->num_nh_chains > 4 && need > 2048) return fail(TGNH_ERR_UNSUPPORTED, "numNHChains too large for the on-device chain");
+    }
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
     if (d->device < 0 || d->device >= ndev) return fail(TGNH_ERR_HIP, "no such HIP device (the HIP path needs an MI355X; there is no CPU fallback)");
@@ -780,7 +785,7 @@ extern "C" tgnh_status tgnh_harness_force(tgnh_handle h, const void* x0, double 
     if (!x0 || !force_out) return fail(TGNH_ERR_ARG, "null x0 / force_out");
     HIP_OK(hipSetDevice(h->device));
     ForceArgs a{};
-    a.posq = h->posq; a.posq_corr = h->posq_corr; a.x0 = x0; a.velm = h->velm; a.meta = h->d_meta;
+    a.posq = h->posq; a.posq_corr = h->posq_corr; a.x0 = x0; a.meta = h->d_meta;
     a.force = reinterpret_cast<long long*>(force_out);
     a.n = h->d.num_particles; a.padded = h->d.padded_num_particles;
     a.k_drude = k_drude; a.k_tether = k_tether;

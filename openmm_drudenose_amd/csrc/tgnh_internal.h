@@ -104,8 +104,7 @@ struct ChainArgs {
 struct ForceArgs {
     const void* posq;
     const void* posq_corr;
-    const void* x0;            // mixed4 [N]
-    const void* velm;          // inverse masses (w)
+    const void* x0;            // real4 [N]: tether site (x,y,z), w = 1 if the slot is tethered else 0
     const uint32_t* meta;
     long long* force;
     int n, padded;

@@ -424,40 +424,82 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
 // One work-group.  TGNH: lane itg owns thermostat itg (Cu :558-650).
 // dualNH: lane 0 runs the reference's coupled, interleaved arrays (Ref :467-504),
 // including its indexing quirk when useDrudeNHChains is false.
+// The chain variables are copied into registers (numNHChains <= 4, fully unrolled) or
+// LDS (longer chains) for the S-fold loop and written back once: with them left in
+// global memory every `etaDot[i] *= expfac` was a dependent HBM round trip.
 // ---------------------------------------------------------------------------
 #pragma clang fp contract(off)
 
-__device__ void chain_tgnh_real(const ChainArgs& a, int itg, double ke, double* scale_out, double* ke_out) {
-    const ChainLayout& L = a.L;
-    const int C = L.C;
-    double* eta = a.st + L.off_eta + itg * C;
-    double* etaDot = a.st + L.off_etaDot + itg * (C + 1);
-    double* etaDotDot = a.st + L.off_etaDotDot + itg * C;
-    const double* etaMass = a.st + L.off_etaMass + itg * C;
-    const double nkbt = a.st[L.off_nkbt + itg];
-    const double dtc = a.dt / a.S;                                   // Cu :440-443
-    const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
+// exp() for the chain.  The arguments are -dtc/8*etaDot and -dtc/2*etaDot: exactly 0 for the dummy link
+// (exp(-0) = 1 exactly, as libm returns) and tiny otherwise, so a short Taylor polynomial in explicit FMAs is
+// exact to double rounding: degree 6 for |x| < 2^-10 (truncation < 2^-62 relative), degree 11 for |x| < 2^-5
+// (< 2^-55); larger arguments take the library exp.  The chain is one serial fp64 dependency chain per
+// thermostat, so its latency is the number of dependent operations: this keeps an exp at 6-11 of them.
+__device__ __forceinline__ double chain_exp(double x) {
+    if (x == 0.0) return 1.0;
+    const double ax = fabs(x);
+    if (ax < 0.0009765625) {
+        double p = 1.0 / 720.0;
+        p = fma(p, x, 1.0 / 120.0);
+        p = fma(p, x, 1.0 / 24.0);
+        p = fma(p, x, 1.0 / 6.0);
+        p = fma(p, x, 0.5);
+        p = fma(p, x, 1.0);
+        return fma(p, x, 1.0);
+    }
+    if (ax < 0.03125) {
+        double p = 1.0 / 39916800.0;
+        p = fma(p, x, 1.0 / 3628800.0);
+        p = fma(p, x, 1.0 / 362880.0);
+        p = fma(p, x, 1.0 / 40320.0);
+        p = fma(p, x, 1.0 / 5040.0);
+        p = fma(p, x, 1.0 / 720.0);
+        p = fma(p, x, 1.0 / 120.0);
+        p = fma(p, x, 1.0 / 24.0);
+        p = fma(p, x, 1.0 / 6.0);
+        p = fma(p, x, 0.5);
+        p = fma(p, x, 1.0);
+        return fma(p, x, 1.0);
+    }
+    return exp(x);
+}
+
+struct ChainConst {
+    double dtc2, dtc4, dtc8;
+    int S;
+};
+
+// One real (temperature-group or COM) thermostat.  Cu :560-595.  CC > 0: compile-time chain length.
+template <int CC>
+__device__ __forceinline__ void chain_real_core(double* eta, double* etaDot, double* etaDotDot, const double* etaMass,
+                                                const int Cdyn, const ChainConst k, const double nkbt, const double kbT,
+                                                double ke, double* scale_out, double* ke_out) {
+    const int C = CC > 0 ? CC : Cdyn;
     double scale = 1.0, expfac = 1.0;
-    if (etaMass[0] > 0) etaDotDot[0] = (ke - nkbt) / etaMass[0];     // Cu :561-563
-    for (int iter = 0; iter < a.S; iter++) {
+    const bool live = etaMass[0] > 0;
+    const double invQ0 = live ? 1.0 / etaMass[0] : 0.0;              // (KE - NkT)/Q as a multiply: <= 1 ulp from the division
+    if (live) etaDotDot[0] = (ke - nkbt) * invQ0;                    // Cu :561-563
+    for (int iter = 0; iter < k.S; iter++) {
+#pragma unroll
         for (int i = C - 1; i >= 0; i--) {                           // Cu :566-571
-            expfac = exp(-dtc8 * etaDot[i + 1]);
+            expfac = chain_exp(-k.dtc8 * etaDot[i + 1]);
             etaDot[i] *= expfac;
-            etaDot[i] += etaDotDot[i] * dtc4;
+            etaDot[i] += etaDotDot[i] * k.dtc4;
             etaDot[i] *= expfac;
         }
-        scale *= exp(-dtc2 * etaDot[0]);                             // Cu :573-574
-        ke *= exp(-dtc * etaDot[0]);
-        for (int i = 0; i < C; i++) eta[i] += dtc2 * etaDot[i];      // Cu :575-577
-        if (etaMass[0] > 0) etaDotDot[0] = (ke - nkbt) / etaMass[0]; // Cu :579-581
-        etaDot[0] *= expfac;                                         // Cu :583-585
-        etaDot[0] += etaDotDot[0] * dtc4;
+        { const double e = chain_exp(-k.dtc2 * etaDot[0]); scale *= e; ke *= e * e; }   // Cu :573-574, exp(-dtc x) = e^2
+#pragma unroll
+        for (int i = 0; i < C; i++) eta[i] += k.dtc2 * etaDot[i];    // Cu :575-577
+        if (live) etaDotDot[0] = (ke - nkbt) * invQ0;                // Cu :579-581
+        etaDot[0] *= expfac;                                         // Cu :583-585 (expfac of link 0 reused)
+        etaDot[0] += etaDotDot[0] * k.dtc4;
         etaDot[0] *= expfac;
+#pragma unroll
         for (int i = 1; i < C; i++) {                                // Cu :586-592
-            expfac = exp(-dtc8 * etaDot[i + 1]);
+            expfac = chain_exp(-k.dtc8 * etaDot[i + 1]);
             etaDot[i] *= expfac;
-            etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - a.realkbT) / etaMass[i];
-            etaDot[i] += etaDotDot[i] * dtc4;
+            etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - kbT) / etaMass[i];
+            etaDot[i] += etaDotDot[i] * k.dtc4;
             etaDot[i] *= expfac;
         }
     }
@@ -465,46 +507,46 @@ __device__ void chain_tgnh_real(const ChainArgs& a, int itg, double ke, double* 
     *ke_out = ke;
 }
 
-__device__ void chain_tgnh_drude(const ChainArgs& a, int itg, double ke, double* scale_out, double* ke_out) {
-    const ChainLayout& L = a.L;
-    const int C = L.C;
-    const bool chains = L.use_drude_chains != 0;
-    double* eta = a.st + L.off_eta + itg * C;
-    double* etaDot = a.st + L.off_etaDot + itg * (C + 1);
-    double* etaDotDot = a.st + L.off_etaDotDot + itg * C;
-    const double* etaMass = a.st + L.off_etaMass + itg * C;
-    const double nkbt = a.st[L.off_nkbt + itg];
-    const double dtc = a.dt / a.S;
-    const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
+// The Drude thermostat.  Cu :597-642.
+template <int CC>
+__device__ __forceinline__ void chain_drude_core(double* eta, double* etaDot, double* etaDotDot, const double* etaMass,
+                                                 const int Cdyn, const bool chains, const ChainConst k, const double nkbt,
+                                                 const double kbT, double ke, double* scale_out, double* ke_out) {
+    const int C = CC > 0 ? CC : Cdyn;
     double scale = 1.0, expfac = 1.0;
-    etaDotDot[0] = (ke - nkbt) / etaMass[0];                         // Cu :605
-    for (int iter = 0; iter < a.S; iter++) {                         // Cu :606-642
+    const double invQ0 = 1.0 / etaMass[0];
+    etaDotDot[0] = (ke - nkbt) * invQ0;                              // Cu :605
+    for (int iter = 0; iter < k.S; iter++) {                         // Cu :606-642
         if (chains) {
+#pragma unroll
             for (int i = C - 1; i > 0; i--) {
-                expfac = exp(-dtc8 * etaDot[i + 1]);
+                expfac = chain_exp(-k.dtc8 * etaDot[i + 1]);
                 etaDot[i] *= expfac;
-                etaDot[i] += etaDotDot[i] * dtc4;
+                etaDot[i] += etaDotDot[i] * k.dtc4;
                 etaDot[i] *= expfac;
             }
         }
-        expfac = exp(-dtc8 * etaDot[1]);
+        expfac = chain_exp(-k.dtc8 * etaDot[1]);
         etaDot[0] *= expfac;
-        etaDot[0] += etaDotDot[0] * dtc4;
+        etaDot[0] += etaDotDot[0] * k.dtc4;
         etaDot[0] *= expfac;
-        scale *= exp(-dtc2 * etaDot[0]);
-        ke *= exp(-dtc * etaDot[0]);
-        eta[0] += dtc2 * etaDot[0];
-        if (chains) for (int i = 1; i < C; i++) eta[i] += dtc2 * etaDot[i];
-        etaDotDot[0] = (ke - nkbt) / etaMass[0];
+        { const double e = chain_exp(-k.dtc2 * etaDot[0]); scale *= e; ke *= e * e; }   // Cu :620-621
+        eta[0] += k.dtc2 * etaDot[0];
+        if (chains) {
+#pragma unroll
+            for (int i = 1; i < C; i++) eta[i] += k.dtc2 * etaDot[i];
+        }
+        etaDotDot[0] = (ke - nkbt) * invQ0;
         etaDot[0] *= expfac;
-        etaDot[0] += etaDotDot[0] * dtc4;
+        etaDot[0] += etaDotDot[0] * k.dtc4;
         etaDot[0] *= expfac;
         if (chains) {
+#pragma unroll
             for (int i = 1; i < C; i++) {
-                expfac = exp(-dtc8 * etaDot[i + 1]);
+                expfac = chain_exp(-k.dtc8 * etaDot[i + 1]);
                 etaDot[i] *= expfac;
-                etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - a.drudekbT) / etaMass[i];
-                etaDot[i] += etaDotDot[i] * dtc4;
+                etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - kbT) / etaMass[i];
+                etaDot[i] += etaDotDot[i] * k.dtc4;
                 etaDot[i] *= expfac;
             }
         }
@@ -513,49 +555,134 @@ __device__ void chain_tgnh_drude(const ChainArgs& a, int itg, double ke, double*
     *ke_out = ke;
 }
 
-__device__ void chain_dualnh(const ChainArgs& a, double realKE, double drudeKE,
-                             double* sReal, double* sDrude, double* keReal, double* keDrude) {
+// One TGNH thermostat (lane itg), `reps` chain calls back to back on register / LDS copies.
+template <int CC>
+__device__ __forceinline__ void run_tgnh(const ChainArgs& a, const int itg, double* lds) {
     const ChainLayout& L = a.L;
-    double* eta = a.st + L.off_eta;
-    double* etaDot = a.st + L.off_etaDot;
-    double* etaDotDot = a.st + L.off_etaDotDot;
-    const double* etaMass = a.st + L.off_etaMass;
+    const int C = L.C, NT = L.NT;
+    constexpr int CM = CC > 0 ? CC : 1;
+    double r_eta[CM], r_etaDot[CM + 1], r_etaDotDot[CM], r_etaMass[CM];
+    double *eta = r_eta, *etaDot = r_etaDot, *etaDotDot = r_etaDotDot, *etaMass = r_etaMass;
+    if (CC == 0) {                       // long chains: this lane's slice of the LDS scratch
+        eta = lds + itg * (4 * C + 1); etaDot = eta + C; etaDotDot = etaDot + C + 1; etaMass = etaDotDot + C;
+    }
+    double* g_eta = a.st + L.off_eta + itg * C;
+    double* g_etaDot = a.st + L.off_etaDot + itg * (C + 1);
+    double* g_etaDotDot = a.st + L.off_etaDotDot + itg * C;
+    const double* g_etaMass = a.st + L.off_etaMass + itg * C;
+#pragma unroll
+    for (int i = 0; i < (CC > 0 ? CC : C); i++) { eta[i] = g_eta[i]; etaDotDot[i] = g_etaDotDot[i]; etaMass[i] = g_etaMass[i]; }
+#pragma unroll
+    for (int i = 0; i < (CC > 0 ? CC : C) + 1; i++) etaDot[i] = g_etaDot[i];
+    ChainConst k;
+    const double dtc = a.dt / a.S;                                   // Cu :440-443
+    k.dtc2 = dtc / 2.0; k.dtc4 = dtc / 4.0; k.dtc8 = dtc / 8.0; k.S = a.S;
+    const double nkbt = a.st[L.off_nkbt + itg];
+    double ke = a.st[L.off_ke_red + itg];
+    a.st[L.off_ke + itg] = ke;                                       // KE before the chain (Cu :490)
+    const int reps = a.chain_twice ? 2 : 1;
+    double total = 1.0;
+    for (int rep = 0; rep < reps; rep++) {
+        double sc, kep;
+        if (itg < NT - 1) chain_real_core<CC>(eta, etaDot, etaDotDot, etaMass, C, k, nkbt, a.realkbT, ke, &sc, &kep);
+        else chain_drude_core<CC>(eta, etaDot, etaDotDot, etaMass, C, L.use_drude_chains != 0, k, nkbt, a.drudekbT, ke, &sc, &kep);
+        if (rep == 0) { a.st[L.off_scale_a + itg] = sc; a.st[L.off_ke_post + itg] = kep; }
+        else a.st[L.off_scale_b + itg] = sc;
+        total *= sc;
+        ke = kep;
+    }
+    if (reps == 1) a.st[L.off_scale_b + itg] = 1.0;
+    a.st[L.off_scale + itg] = total;
+#pragma unroll
+    for (int i = 0; i < (CC > 0 ? CC : C); i++) { g_eta[i] = eta[i]; g_etaDotDot[i] = etaDotDot[i]; }
+#pragma unroll
+    for (int i = 0; i < (CC > 0 ? CC : C) + 1; i++) g_etaDot[i] = etaDot[i];
+}
+
+// The Reference platform's coupled real/Drude chain on its interleaved vectors.  Ref :467-504.
+// LEN = compile-time bound of the vectors (2*CC+2), 0 = dynamic (LDS).
+template <int CC>
+__device__ __forceinline__ void run_dualnh(const ChainArgs& a, double* lds) {
+    const ChainLayout& L = a.L;
+    constexpr int LM = CC > 0 ? 2 * CC + 2 : 1;
+    double r_eta[LM], r_etaDot[LM], r_etaDotDot[LM], r_etaMass[LM];
+    double *eta = r_eta, *etaDot = r_etaDot, *etaDotDot = r_etaDotDot, *etaMass = r_etaMass;
+    const int n = L.len_eta, nd = L.len_etaDot;                      // n = 2C or C+1 ; nd = n+2
+    if (CC == 0) { eta = lds; etaDot = eta + nd; etaDotDot = etaDot + nd; etaMass = etaDotDot + nd; }
+    const int NB = CC > 0 ? LM : nd;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        eta[i] = i < n ? a.st[L.off_eta + i] : 0.0;
+        etaDotDot[i] = i < n ? a.st[L.off_etaDotDot + i] : 0.0;
+        etaMass[i] = i < n ? a.st[L.off_etaMass + i] : 1.0;
+        etaDot[i] = i < nd ? a.st[L.off_etaDot + i] : 0.0;
+    }
     const double realNkbT = a.st[L.off_nkbt + 0], drudeNkbT = a.st[L.off_nkbt + 2];
     const double dtc = a.dt / a.S;                                   // Ref :432-435
     const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
-    double scaleReal = 1.0, scaleDrude = 1.0, expfac = 1.0;
-    etaDotDot[0] = (realKE - realNkbT) / etaMass[0];                 // Ref :471-472
-    etaDotDot[1] = (drudeKE - drudeNkbT) / etaMass[1];
-    for (int iter = 0; iter < a.S; iter++) {
-        for (int i = L.idxMaxNHChains; i >= 0; i--) {                // Ref :476-481
-            expfac = exp(-dtc8 * etaDot[i + L.numTempGroup]);
-            etaDot[i] *= expfac;
-            etaDot[i] += etaDotDot[i] * dtc4;
-            etaDot[i] *= expfac;
-        }
-        scaleReal *= exp(-dtc2 * etaDot[0]);                         // Ref :483-486
-        scaleDrude *= exp(-dtc2 * etaDot[1]);
-        realKE *= exp(-dtc * etaDot[0]);
-        drudeKE *= exp(-dtc * etaDot[1]);
-        for (int i = 0; i < L.iNumNHChains; i++) eta[i] += dtc2 * etaDot[i];   // Ref :487-489
-        etaDotDot[0] = (realKE - realNkbT) / etaMass[0];             // Ref :491-492
-        etaDotDot[1] = (drudeKE - drudeNkbT) / etaMass[1];
-        for (int i = 0; i < L.iNumNHChains; i++) {                   // Ref :494-503
-            expfac = exp(-dtc8 * etaDot[i + 2]);
-            etaDot[i] *= expfac;
-            if (i > 1) {
-                const double dofkbT = (i % 2 == 0 ? a.realkbT : a.drudekbT);
-                etaDotDot[i] = (etaMass[i - 2] * etaDot[i - 2] * etaDot[i - 2] - dofkbT) / etaMass[i];
+    const int ntg = L.numTempGroup, idxMax = L.idxMaxNHChains, iNum = L.iNumNHChains;
+    double realKE = a.st[L.off_ke_red + 0], drudeKE = a.st[L.off_ke_red + 2];
+    a.st[L.off_ke + 0] = realKE; a.st[L.off_ke + 1] = a.st[L.off_ke_red + 1]; a.st[L.off_ke + 2] = drudeKE;
+    a.st[L.off_kesum] = 0.5 * (realKE + drudeKE);
+    const int reps = a.chain_twice ? 2 : 1;
+    double totR = 1.0, totD = 1.0;
+    for (int rep = 0; rep < reps; rep++) {
+        double scaleReal = 1.0, scaleDrude = 1.0, expfac = 1.0;
+        const double invQr = 1.0 / etaMass[0], invQd = 1.0 / etaMass[1];
+        etaDotDot[0] = (realKE - realNkbT) * invQr;                  // Ref :471-472
+        etaDotDot[1] = (drudeKE - drudeNkbT) * invQd;
+        for (int iter = 0; iter < a.S; iter++) {
+#pragma unroll
+            for (int i = NB - 3; i >= 0; i--) {                      // Ref :476-481 (i = idxMaxNHChains .. 0)
+                if (i <= idxMax) {
+                    expfac = chain_exp(-dtc8 * (ntg == 2 ? etaDot[i + 2] : etaDot[i + 1]));
+                    etaDot[i] *= expfac;
+                    etaDot[i] += etaDotDot[i] * dtc4;
+                    etaDot[i] *= expfac;
+                }
             }
-            etaDot[i] += etaDotDot[i] * dtc4;
-            etaDot[i] *= expfac;
+            { const double e = chain_exp(-dtc2 * etaDot[0]); scaleReal *= e; realKE *= e * e; }    // Ref :483-486
+            { const double e = chain_exp(-dtc2 * etaDot[1]); scaleDrude *= e; drudeKE *= e * e; }
+#pragma unroll
+            for (int i = 0; i < NB - 2; i++) if (i < iNum) eta[i] += dtc2 * etaDot[i];             // Ref :487-489
+            etaDotDot[0] = (realKE - realNkbT) * invQr;              // Ref :491-492
+            etaDotDot[1] = (drudeKE - drudeNkbT) * invQd;
+#pragma unroll
+            for (int i = 0; i < NB - 2; i++) {                       // Ref :494-503
+                if (i < iNum) {
+                    expfac = chain_exp(-dtc8 * etaDot[i + 2]);
+                    etaDot[i] *= expfac;
+                    if (i > 1) {
+                        const double dofkbT = (i % 2 == 0 ? a.realkbT : a.drudekbT);
+                        etaDotDot[i] = (etaMass[i - 2] * etaDot[i - 2] * etaDot[i - 2] - dofkbT) / etaMass[i];
+                    }
+                    etaDot[i] += etaDotDot[i] * dtc4;
+                    etaDot[i] *= expfac;
+                }
+            }
         }
+        if (rep == 0) {
+            a.st[L.off_scale_a + 0] = scaleReal; a.st[L.off_scale_a + 1] = 1.0; a.st[L.off_scale_a + 2] = scaleDrude;
+            a.st[L.off_ke_post + 0] = realKE; a.st[L.off_ke_post + 1] = 0.0; a.st[L.off_ke_post + 2] = drudeKE;
+        } else {
+            a.st[L.off_scale_b + 0] = scaleReal; a.st[L.off_scale_b + 1] = 1.0; a.st[L.off_scale_b + 2] = scaleDrude;
+        }
+        totR *= scaleReal; totD *= scaleDrude;
     }
-    *sReal = scaleReal; *sDrude = scaleDrude; *keReal = realKE; *keDrude = drudeKE;
+    if (reps == 1) { a.st[L.off_scale_b + 0] = 1.0; a.st[L.off_scale_b + 1] = 1.0; a.st[L.off_scale_b + 2] = 1.0; }
+    a.st[L.off_scale + 0] = totR; a.st[L.off_scale + 1] = 1.0; a.st[L.off_scale + 2] = totD;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        if (i < n) { a.st[L.off_eta + i] = eta[i]; a.st[L.off_etaDotDot + i] = etaDotDot[i]; }
+        if (i < nd) a.st[L.off_etaDot + i] = etaDot[i];
+    }
 }
+
+constexpr int CHAIN_LDS_DOUBLES = 2048;
 
 __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
     __shared__ double sred[BLOCK / 64][MAX_GROUPS + 2];
+    __shared__ double s_chain[CHAIN_LDS_DOUBLES];
     const ChainLayout& L = a.L;
     const int NT = L.NT, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double* st = a.st;
@@ -576,23 +703,15 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
         __syncthreads();
     }
     if (!a.do_chain) return;
-    const int reps = a.chain_twice ? 2 : 1;
     if (L.mode == TGNH_MODE_TGNH) {
         if (tid < NT) {
-            double ke = st[L.off_ke_red + tid];
-            st[L.off_ke + tid] = ke;                                 // KE before the chain (Cu :490)
-            double total = 1.0;
-            for (int rep = 0; rep < reps; rep++) {
-                double sc, kep;
-                if (tid < NT - 1) chain_tgnh_real(a, tid, ke, &sc, &kep);
-                else chain_tgnh_drude(a, tid, ke, &sc, &kep);
-                if (rep == 0) { st[L.off_scale_a + tid] = sc; st[L.off_ke_post + tid] = kep; }
-                else st[L.off_scale_b + tid] = sc;
-                total *= sc;
-                ke = kep;
+            switch (L.C) {
+                case 1: run_tgnh<1>(a, tid, s_chain); break;
+                case 2: run_tgnh<2>(a, tid, s_chain); break;
+                case 3: run_tgnh<3>(a, tid, s_chain); break;
+                case 4: run_tgnh<4>(a, tid, s_chain); break;
+                default: run_tgnh<0>(a, tid, s_chain); break;       // host checked NT*(4C+1) <= CHAIN_LDS_DOUBLES
             }
-            if (reps == 1) st[L.off_scale_b + tid] = 1.0;
-            st[L.off_scale + tid] = total;
         }
         __syncthreads();
         if (tid == 0) {                                              // Cu :493-497
@@ -600,25 +719,13 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
             for (int i = 0; i < NT; i++) s += st[L.off_ke + i];
             st[L.off_kesum] = 0.5 * s;
         }
-    } else {
-        if (tid == 0) {
-            double keR = st[L.off_ke_red + 0], keD = st[L.off_ke_red + 2];
-            st[L.off_ke + 0] = keR; st[L.off_ke + 1] = st[L.off_ke_red + 1]; st[L.off_ke + 2] = keD;
-            double totR = 1.0, totD = 1.0;
-            for (int rep = 0; rep < reps; rep++) {
-                double sR, sD, kR, kD;
-                chain_dualnh(a, keR, keD, &sR, &sD, &kR, &kD);
-                if (rep == 0) {
-                    st[L.off_scale_a + 0] = sR; st[L.off_scale_a + 1] = 1.0; st[L.off_scale_a + 2] = sD;
-                    st[L.off_ke_post + 0] = kR; st[L.off_ke_post + 1] = 0.0; st[L.off_ke_post + 2] = kD;
-                } else {
-                    st[L.off_scale_b + 0] = sR; st[L.off_scale_b + 1] = 1.0; st[L.off_scale_b + 2] = sD;
-                }
-                totR *= sR; totD *= sD; keR = kR; keD = kD;
-            }
-            if (reps == 1) { st[L.off_scale_b + 0] = 1.0; st[L.off_scale_b + 1] = 1.0; st[L.off_scale_b + 2] = 1.0; }
-            st[L.off_scale + 0] = totR; st[L.off_scale + 1] = 1.0; st[L.off_scale + 2] = totD;
-            st[L.off_kesum] = 0.5 * (st[L.off_ke + 0] + st[L.off_ke + 2]);
+    } else if (tid == 0) {
+        switch (L.C) {
+            case 1: run_dualnh<1>(a, s_chain); break;
+            case 2: run_dualnh<2>(a, s_chain); break;
+            case 3: run_dualnh<3>(a, s_chain); break;
+            case 4: run_dualnh<4>(a, s_chain); break;
+            default: run_dualnh<0>(a, s_chain); break;               // host checked 4*(2C+2) <= CHAIN_LDS_DOUBLES
         }
     }
 }
@@ -631,11 +738,9 @@ template <int PREC>
 __global__ __launch_bounds__(BLOCK) void force_kernel(const ForceArgs a) {
     typedef typename Prec<PREC>::real4 real4;
     typedef typename Prec<PREC>::mixed mixed;
-    typedef typename Prec<PREC>::mixed4 mixed4;
     const real4* __restrict__ posq = reinterpret_cast<const real4*>(a.posq);
     const float4* __restrict__ pcorr = reinterpret_cast<const float4*>(a.posq_corr);
-    const mixed4* __restrict__ x0 = reinterpret_cast<const mixed4*>(a.x0);
-    const mixed4* __restrict__ velm = reinterpret_cast<const mixed4*>(a.velm);
+    const real4* __restrict__ x0 = reinterpret_cast<const real4*>(a.x0);      // (site x,y,z ; w = 1 if tethered)
     const mixed kd = (mixed)a.k_drude, kt = (mixed)a.k_tether;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += gridDim.x * BLOCK) {
         const uint32_t m = a.meta[i];
@@ -644,20 +749,20 @@ __global__ __launch_bounds__(BLOCK) void force_kernel(const ForceArgs a) {
         mixed x = p.x, y = p.y, z = p.z;
         if (PREC == TGNH_PREC_MIXED) { const float4 c = pcorr[i]; x += (mixed)c.x; y += (mixed)c.y; z += (mixed)c.z; }
         mixed fx = 0, fy = 0, fz = 0;
-        const bool massive = velm[i].w != 0;
-        if (role == ROLE_NORMAL) {
-            if (massive) { const mixed4 s = x0[i]; fx = -kt * (x - s.x); fy = -kt * (y - s.y); fz = -kt * (z - s.z); }
-        } else {
+        if (role != ROLE_DRUDE) {                                   // tether of massive non-Drude sites
+            const real4 s = x0[i];
+            if (s.w != 0) { fx = -kt * (x - (mixed)s.x); fy = -kt * (y - (mixed)s.y); fz = -kt * (z - (mixed)s.z); }
+        }
+        if (role != ROLE_NORMAL) {                                  // Drude spring
             const int j = i + (int)((m >> 10) & 2047u) - 1024;
             const real4 q = posq[j];
             mixed ox = q.x, oy = q.y, oz = q.z;
             if (PREC == TGNH_PREC_MIXED) { const float4 c = pcorr[j]; ox += (mixed)c.x; oy += (mixed)c.y; oz += (mixed)c.z; }
-            if (role == ROLE_DRUDE) {
-                fx = -kd * (x - ox); fy = -kd * (y - oy); fz = -kd * (z - oz);
-            } else {
-                const mixed4 s = x0[i];
-                fx = kd * (ox - x) - kt * (x - s.x); fy = kd * (oy - y) - kt * (y - s.y); fz = kd * (oz - z) - kt * (z - s.z);
-            }
+            // separation Drude - parent, force -k sep on the Drude, +k sep on the parent
+            const mixed sgn = role == ROLE_DRUDE ? (mixed)-1 : (mixed)1;
+            const mixed sx = role == ROLE_DRUDE ? x - ox : ox - x, sy = role == ROLE_DRUDE ? y - oy : oy - y,
+                        sz = role == ROLE_DRUDE ? z - oz : oz - z;
+            fx += sgn * kd * sx; fy += sgn * kd * sy; fz += sgn * kd * sz;
         }
         a.force[i] = (long long)(fx * (mixed)4294967296.0);
         a.force[i + a.padded] = (long long)(fy * (mixed)4294967296.0);

@@ -214,7 +214,7 @@ class HipContext:
         self.velm = torch.zeros((n, 4), dtype=mdt, device=self.dev)
         self.force = torch.zeros(3 * self.padded, dtype=torch.int64, device=self.dev)
         self.pos_delta = torch.zeros((n, 4), dtype=mdt, device=self.dev)
-        self.x0 = torch.zeros((n, 4), dtype=mdt, device=self.dev)
+        self.x0 = torch.zeros((n, 4), dtype=rdt, device=self.dev)        # harness tether sites, w = tether flag
         inv = np.where(system.mass == 0.0, 0.0, 1.0 / np.where(system.mass == 0.0, 1.0, system.mass))
         self.velm[:, 3] = torch.from_numpy(inv).to(self.dev, mdt)
         _check(self.lib.tgnh_bind_buffers(self.h, self.posq.data_ptr(),
@@ -304,7 +304,16 @@ class HipContext:
         self._state_changed()
 
     def set_sites(self, x0):
-        self.x0[:, :3] = self.torch.from_numpy(np.ascontiguousarray(x0, np.float64)).to(self.dev, self.mdt)
+        """Harness tether sites (stored in the position type, so float-rounded unless precision is double);
+        every massive particle that is not a Drude particle is tethered."""
+        self.x0[:, :3] = self.torch.from_numpy(np.ascontiguousarray(x0, np.float64)).to(self.dev, self.rdt)
+        flag = (self.system.mass > 0)
+        flag[self.system.pair_drude] = False
+        self.x0[:, 3] = self.torch.from_numpy(flag.astype(np.float64)).to(self.dev, self.rdt)
+
+    def sites(self):
+        """The tether sites exactly as the harness kernel sees them (for the oracle)."""
+        return self.x0[:, :3].to(self.torch.float64).cpu().numpy()
 
     def setVelocities(self, vel):
         self.velm[:, :3] = self.torch.from_numpy(np.ascontiguousarray(vel, np.float64)).to(self.dev, self.mdt)

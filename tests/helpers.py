@@ -19,10 +19,11 @@ def make_oracle(system, group, ngroups, mode, integ):
     return Oracle.from_integrator(system, integ, group, ngroups, MODES[mode])
 
 
-def oracle_run(o, system, nsteps, k_drude=synth.K_DRUDE, k_tether=synth.K_TETHER, record=False):
-    """Runs the oracle with the harness force; returns final (pos, vel) and optionally per-step KE/scale."""
+def oracle_run(o, system, nsteps, k_drude=synth.K_DRUDE, k_tether=synth.K_TETHER, record=False, x0=None):
+    """Runs the oracle with the harness force; returns final (pos, vel) and optionally per-step KE/scale.
+    x0 = tether sites; pass ctx.sites() so the oracle sees the sites exactly as the HIP harness stores them."""
     pos, vel = system.positions.copy(), system.velocities.copy()
-    x0 = system.positions.copy()
+    x0 = system.positions.copy() if x0 is None else np.ascontiguousarray(x0, np.float64)
     f = o.harness_force(pos, x0, k_drude, k_tether)
     if not record:
         o.run_harness(pos, vel, f, x0, k_drude, k_tether, nsteps)
