@@ -34,9 +34,11 @@ def parse():
     p.add_argument("--molecules", type=int, default=1_000_000, help="SWM4 molecules = Drude pairs (metric: 1,000,000)")
     p.add_argument("--precision", default="mixed", choices=["single", "mixed", "double"])
     p.add_argument("--mode", default="TGNH", choices=["TGNH", "dualNH"])
-    p.add_argument("--variant", default="plain", choices=["plain", "merge", "defer"],
-                   help="plain = the reference's pass structure; merge / defer = fused end-of-step rescale (DESIGN.md)")
+    p.add_argument("--variant", default="defer", choices=["plain", "merge", "defer"],
+                   help="defer (default) = end-of-step rescale folded into the next step's first pass; "
+                        "plain = the reference's pass structure; merge = rescale fused with the next KE pass (DESIGN.md)")
     p.add_argument("--chains", type=int, default=1)
+    p.add_argument("--drude-steps", type=int, default=20, help="drudeStepsPerRealStep (reference default 20)")
     p.add_argument("--hardwall", type=float, default=0.02, help="maxDrudeDistance nm (example/nacl_tg.py:22); 0 = off")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (rank 0, N=1)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -50,7 +52,7 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
     from openmm_drudenose_amd import DrudeTGNHIntegrator, HipContext
     from openmm_drudenose_amd.drudetgnhplugin import FLAG_MERGE_SCALE_KE, FLAG_DEFER_SCALE
     from openmm_drudenose_amd.system import shard_bounds
-    it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, args.chains, True, True)
+    it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, args.drude_steps, args.chains, True, True)
     it.setMaxDrudeDistance(args.hardwall)
     flags = {"plain": 0, "merge": FLAG_MERGE_SCALE_KE, "defer": FLAG_DEFER_SCALE}[variant]
     local, lgroup = system, group
@@ -117,7 +119,7 @@ def cpu_baseline(args, system, group, ngroups):
     from oracle import Oracle, MODE_TGNH, MODE_DUALNH
     mode = MODE_TGNH if args.mode == "TGNH" else MODE_DUALNH
     g = group if args.mode == "TGNH" else np.zeros_like(group)
-    o = Oracle(system, g, ngroups if args.mode == "TGNH" else 1, mode, 300.0, 0.1, 1.0, 0.005, 0.001, 20, args.chains,
+    o = Oracle(system, g, ngroups if args.mode == "TGNH" else 1, mode, 300.0, 0.1, 1.0, 0.005, 0.001, args.drude_steps, args.chains,
                True, True, args.hardwall)
     pos, vel, x0 = system.positions.copy(), system.velocities.copy(), system.positions.copy()
     f = o.harness_force(pos, x0, synth.K_DRUDE, synth.K_TETHER)
@@ -166,7 +168,7 @@ def main():
 
     extra = {}
     if world == 1 and not args.no_extra:
-        for prec, var in (("single", "plain"), (args.precision, "defer")):
+        for prec, var in ((args.precision, "plain"), ("single", "defer")):
             if (prec, var) == (args.precision, args.variant):
                 continue
             c2 = build_context(args, system, group, ngroups, rank, world, prec, var)

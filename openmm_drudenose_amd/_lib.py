@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdrudetgnh_hip.so")
+LIB_PATH = os.environ.get("TGNH_LIB") or os.path.join(HERE, "libdrudetgnh_hip.so")   # TGNH_LIB: tuning builds (tools/build_variant.py)
 
 TGNH_OK = 0
 ERR_ARG, ERR_GROUP_MISMATCH, ERR_HARDWALL, ERR_UNSUPPORTED, ERR_HIP, ERR_STATE = -1, -2, -3, -4, -5, -6

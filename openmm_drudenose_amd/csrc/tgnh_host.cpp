@@ -381,8 +381,13 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     c->d.mass = nullptr; c->d.pair_drude = c->d.pair_parent = c->d.group = c->d.resid = nullptr;
     c->d.constraint_i = c->d.constraint_j = nullptr;
 
-    c->grid = std::min(c->num_tiles, GRID_CAP);
-    if (const char* e = getenv("TGNH_GRID")) { int g = atoi(e); if (g >= 1) c->grid = std::min(c->num_tiles, g); }
+    c->grid = GRID_CAP;                       // partials are sized for the largest grid
+    if (const char* e = getenv("TGNH_GRID")) { int g = atoi(e); if (g >= 1) c->grid_override = std::min(g, GRID_CAP); }
+    {
+        hipDeviceProp_t prop;
+        HIP_OK(hipGetDeviceProperties(&prop, d->device));
+        c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     c->gb = c->L.G <= 1 ? 1 : (c->L.G <= 4 ? 4 : 8);
     auto alloc = [&]() -> tgnh_status {
         HIP_OK(hipMalloc(&c->d_partials, sizeof(double) * (size_t)c->grid * c->L.NT));
@@ -504,18 +509,35 @@ static TileArgs tile_args(tgnh_handle h, const double* scale) {
     return a;
 }
 
+// persistent grid = the work-groups of this instantiation that are resident at once (occupancy x CUs), so every
+// work-group walks the same number of tiles (+-1) and there is no partial last wave of work-groups
+static int grid_for(tgnh_handle h, int ops, bool hardwall, size_t lds) {
+    if (h->grid_override > 0) return std::min(h->num_tiles, h->grid_override);
+    const int key = ops | (hardwall ? 1 << 16 : 0);
+    auto it = h->grid_cache.find(key);
+    if (it != h->grid_cache.end()) return it->second;
+    int per_cu = tile_blocks_per_cu(h->d.precision, ops, h->gb, lds);
+    if (per_cu < 1) per_cu = 2;
+    int g = std::min(std::min(h->num_tiles, per_cu * h->num_cus), GRID_CAP);
+    if (g < 1) g = 1;
+    h->grid_cache[key] = g;
+    return g;
+}
+
 static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, const double* scale = nullptr) {
     TileArgs a = tile_args(h, scale);
     if ((ops & (OP_POSDELTA | OP_MOVE)) && !h->pos_delta) return fail(TGNH_ERR_STATE, "posDelta buffer not bound");
     const size_t lds = tile_lds_bytes(h->d.precision, ops, a.hardwall != 0, a.use_com != 0);
+    const int grid = grid_for(h, ops, a.hardwall != 0, lds);
+    if (ops & OP_KE) h->ke_parts = grid;
     Timed t(h, s, kid);
-    HIP_OK(launch_tile(h->d.precision, ops, h->gb, a, h->grid, lds, s));
+    HIP_OK(launch_tile(h->d.precision, ops, h->gb, a, grid, lds, s));
     return TGNH_OK;
 }
 
 static ChainArgs chain_args(tgnh_handle h) {
     ChainArgs a{};
-    a.L = h->L; a.st = h->d_state; a.partials = h->d_partials; a.nparts = h->grid;
+    a.L = h->L; a.st = h->d_state; a.partials = h->d_partials; a.nparts = h->ke_parts;
     a.dt = h->d.step_size; a.S = h->d.drude_steps_per_real_step;
     a.realkbT = h->realkbT; a.drudekbT = h->drudekbT;
     return a;

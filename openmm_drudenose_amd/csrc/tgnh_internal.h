@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -16,11 +17,17 @@ namespace tgnh {
 // One 256-thread work-group (4 wavefronts of 64) owns a tile of up to TILE_SLOTS
 // consecutive particle slots whose ends never cut a Drude pair or (TGNH+COM) a
 // residue, so partner and molecular-COM look-ups stay inside the tile's LDS image.
+#ifndef TGNH_SPT
+#define TGNH_SPT 2
+#endif
+#ifndef TGNH_PREFETCH
+#define TGNH_PREFETCH 0   // software prefetch of the next tile: measured slower on MI355X (profiles/r01_tuning.md)
+#endif
 constexpr int BLOCK = 256;
-constexpr int SPT = 2;                       // slots per thread
-constexpr int TILE_SLOTS = BLOCK * SPT;      // 512
+constexpr int SPT = TGNH_SPT;                // slots per thread
+constexpr int TILE_SLOTS = BLOCK * SPT;      // 512 at SPT = 2
 constexpr int TILE_RES = TILE_SLOTS / 2;     // residues per tile the LDS COM table holds
-constexpr int GRID_CAP = 2048;               // persistent grid, multiple of 8 (XCD round-robin)
+constexpr int GRID_CAP = 2048;               // upper bound of the persistent grid (256 CUs x 8 work-groups)
 constexpr int MAX_GROUPS = 8;                // per-thread KE bins are registers (GB template 1/4/8)
 
 // ---- packed per-slot topology word ----------------------------------------
@@ -113,6 +120,7 @@ struct ForceArgs {
 
 // launchers (tgnh_kernels.hip)
 hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s);
+int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds);   // occupancy of that instantiation
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s);
 hipError_t launch_force(int precision, const ForceArgs& a, hipStream_t s);
 hipError_t launch_plain_ke(int precision, const void* velm, const long long* force, int n, int padded,
@@ -145,6 +153,8 @@ struct tgnh_context {
     uint32_t* d_status = nullptr;
     double* d_scalar = nullptr;       // plain KE result
     int grid = 0, num_tiles = 0, gb = 1;
+    int num_cus = 256, grid_override = 0, ke_parts = 0;
+    std::map<int, int> grid_cache;    // ops (+hard-wall bit) -> persistent grid size
     // bound buffers
     void *posq = nullptr, *posq_corr = nullptr, *velm = nullptr, *pos_delta = nullptr;
     const void* force = nullptr;

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
     constexpr bool DO_KE = OPS & OP_KE, DO_PD = OPS & OP_POSDELTA, DO_MOVE = OPS & OP_MOVE;
     constexpr bool POS = DO_DRIFT || DO_MOVE;            // positions are read and written
     constexpr bool VEL_W = DO_SCALE || DO_KICK || DO_MOVE;   // velocities are written
+    constexpr bool PREFETCH = TGNH_PREFETCH != 0;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     mixed4* sv = reinterpret_cast<mixed4*>(smem);        // [TILE_SLOTS] velocity image
@@ -89,9 +90,51 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
     const mixed dt = (mixed)a.dt;
     const mixed fscale = (mixed)(0.5 * a.dt / 4294967296.0);     // Cu :295
 
+    // Raw register image of one tile's global loads.  The loads of tile t+gridDim are issued before tile t is
+    // processed (software prefetch): a work-group is then never without HBM requests in flight while it
+    // sits in its LDS phases and barriers.
+    struct TileIn {
+        int ts, te, rs, nres;
+        mixed4 v[SPT];
+        uint32_t meta[SPT];
+        long long fx[SPT], fy[SPT], fz[SPT];
+        real4 p[SPT];
+        float4 c[SPT];
+        mixed4 pd[SPT];
+    };
+    auto load_tile = [&](int t, TileIn& in) {
+        in.ts = a.tile_start[t]; in.te = a.tile_start[t + 1];
+        in.rs = a.tile_res[t]; in.nres = a.tile_res[t + 1] - in.rs;
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            const int idx = in.ts + k * BLOCK + tid;
+            if (idx < in.te) {
+                in.v[k] = velm[idx];
+                in.meta[k] = a.meta[idx];
+                if (DO_KICK) {
+                    in.fx[k] = a.force[idx];
+                    in.fy[k] = a.force[idx + a.padded];
+                    in.fz[k] = a.force[idx + 2 * a.padded];
+                }
+                if (POS) {
+                    in.p[k] = posq[idx];
+                    if (PREC == TGNH_PREC_MIXED) in.c[k] = pcorr[idx];       // K :443-445
+                }
+                if (DO_MOVE) in.pd[k] = pdelta[idx];
+            } else {
+                in.v[k] = mk4((mixed)0, (mixed)0, (mixed)0, (mixed)0);       // w = 0: treated as massless, never stored
+                in.meta[k] = 0u;
+            }
+        }
+    };
+
+    TileIn cur, nxt;
+    if ((int)blockIdx.x < a.num_tiles) load_tile(blockIdx.x, cur);
     for (int t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
-        const int ts = a.tile_start[t], te = a.tile_start[t + 1];
-        const int rs = a.tile_res[t], nres = a.tile_res[t + 1] - rs;
+        const bool more = t + (int)gridDim.x < a.num_tiles;
+        if (PREFETCH && more) load_tile(t + gridDim.x, nxt);
+        const int ts = cur.ts, te = cur.te;
+        const int rs = cur.rs, nres = cur.nres;
 
         mixed4 v[SPT];
         uint32_t meta[SPT];
@@ -102,29 +145,15 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
         bool ok[SPT];
 #pragma unroll
         for (int k = 0; k < SPT; k++) {
-            const int idx = ts + k * BLOCK + tid;
-            ok[k] = idx < te;
-            if (ok[k]) {
-                v[k] = velm[idx];
-                meta[k] = a.meta[idx];
-                if (DO_KICK) {
-                    fx[k] = a.force[idx];
-                    fy[k] = a.force[idx + a.padded];
-                    fz[k] = a.force[idx + 2 * a.padded];
-                }
-                if (POS) {
-                    real4 p = posq[idx];
-                    px[k] = p.x; py[k] = p.y; pz[k] = p.z; pq[k] = p.w;
-                    if (PREC == TGNH_PREC_MIXED) {       // K :443-445
-                        float4 c = pcorr[idx];
-                        px[k] += (mixed)c.x; py[k] += (mixed)c.y; pz[k] += (mixed)c.z;
-                    }
-                }
-                if (DO_MOVE) pd[k] = pdelta[idx];
-            } else {
-                v[k] = mk4((mixed)0, (mixed)0, (mixed)0, (mixed)0);
-                meta[k] = 0u;
+            ok[k] = ts + k * BLOCK + tid < te;
+            v[k] = cur.v[k];
+            meta[k] = cur.meta[k];
+            if (DO_KICK) { fx[k] = cur.fx[k]; fy[k] = cur.fy[k]; fz[k] = cur.fz[k]; }
+            if (POS) {
+                px[k] = cur.p[k].x; py[k] = cur.p[k].y; pz[k] = cur.p[k].z; pq[k] = cur.p[k].w;
+                if (PREC == TGNH_PREC_MIXED) { px[k] += (mixed)cur.c[k].x; py[k] += (mixed)cur.c[k].y; pz[k] += (mixed)cur.c[k].z; }
             }
+            if (DO_MOVE) pd[k] = cur.pd[k];
         }
 
         bool lds_read = false;   // some lane may still be reading sv/scom of this tile
@@ -391,6 +420,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
             lds_read = true;
         }
         if (lds_read) __syncthreads();       // LDS image is reused by the next tile
+        if (more) { if (PREFETCH) cur = nxt; else load_tile(t + gridDim.x, cur); }
     }
 
     // ---- work-group reduction of the fp64 KE bins: 64-lane butterflies, then one LDS hop ----
@@ -557,7 +587,7 @@ __device__ __forceinline__ void chain_drude_core(double* eta, double* etaDot, do
 
 // One TGNH thermostat (lane itg), `reps` chain calls back to back on register / LDS copies.
 template <int CC>
-__device__ __forceinline__ void run_tgnh(const ChainArgs& a, const int itg, double* lds) {
+__device__ __forceinline__ void run_tgnh(const ChainArgs& a, const int itg, double* lds, const double ke_in) {
     const ChainLayout& L = a.L;
     const int C = L.C, NT = L.NT;
     constexpr int CM = CC > 0 ? CC : 1;
@@ -578,7 +608,7 @@ __device__ __forceinline__ void run_tgnh(const ChainArgs& a, const int itg, doub
     const double dtc = a.dt / a.S;                                   // Cu :440-443
     k.dtc2 = dtc / 2.0; k.dtc4 = dtc / 4.0; k.dtc8 = dtc / 8.0; k.S = a.S;
     const double nkbt = a.st[L.off_nkbt + itg];
-    double ke = a.st[L.off_ke_red + itg];
+    double ke = ke_in;
     a.st[L.off_ke + itg] = ke;                                       // KE before the chain (Cu :490)
     const int reps = a.chain_twice ? 2 : 1;
     double total = 1.0;
@@ -602,7 +632,7 @@ __device__ __forceinline__ void run_tgnh(const ChainArgs& a, const int itg, doub
 // The Reference platform's coupled real/Drude chain on its interleaved vectors.  Ref :467-504.
 // LEN = compile-time bound of the vectors (2*CC+2), 0 = dynamic (LDS).
 template <int CC>
-__device__ __forceinline__ void run_dualnh(const ChainArgs& a, double* lds) {
+__device__ __forceinline__ void run_dualnh(const ChainArgs& a, double* lds, const double ke0, const double ke1, const double ke2) {
     const ChainLayout& L = a.L;
     constexpr int LM = CC > 0 ? 2 * CC + 2 : 1;
     double r_eta[LM], r_etaDot[LM], r_etaDotDot[LM], r_etaMass[LM];
@@ -621,8 +651,8 @@ __device__ __forceinline__ void run_dualnh(const ChainArgs& a, double* lds) {
     const double dtc = a.dt / a.S;                                   // Ref :432-435
     const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
     const int ntg = L.numTempGroup, idxMax = L.idxMaxNHChains, iNum = L.iNumNHChains;
-    double realKE = a.st[L.off_ke_red + 0], drudeKE = a.st[L.off_ke_red + 2];
-    a.st[L.off_ke + 0] = realKE; a.st[L.off_ke + 1] = a.st[L.off_ke_red + 1]; a.st[L.off_ke + 2] = drudeKE;
+    double realKE = ke0, drudeKE = ke2;
+    a.st[L.off_ke + 0] = realKE; a.st[L.off_ke + 1] = ke1; a.st[L.off_ke + 2] = drudeKE;
     a.st[L.off_kesum] = 0.5 * (realKE + drudeKE);
     const int reps = a.chain_twice ? 2 : 1;
     double totR = 1.0, totD = 1.0;
@@ -683,49 +713,84 @@ constexpr int CHAIN_LDS_DOUBLES = 2048;
 __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
     __shared__ double sred[BLOCK / 64][MAX_GROUPS + 2];
     __shared__ double s_chain[CHAIN_LDS_DOUBLES];
+    __shared__ double s_ke[MAX_GROUPS + 2];
     const ChainLayout& L = a.L;
     const int NT = L.NT, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double* st = a.st;
     if (a.do_sum) {
-        // per-lane strided partial sums, 64-lane butterfly, 4-wave LDS hop: fixed order => deterministic
-        for (int b = 0; b < NT; b++) {
-            double s = 0.0;
-            for (int p = tid; p < a.nparts; p += BLOCK) s += a.partials[(size_t)p * NT + b];
-            s = wave_sum(s);
-            if (lane == 0) sred[wv][b] = s;
+        // Fixed-order sum of the work-group partials: lane `tid` owns partials tid, tid+256, ...; every load of a
+        // lane is issued before the first add (one memory latency, not one per partial), then a 64-lane butterfly
+        // and a 4-wave LDS hop.  The order never depends on timing, so the sums are reproducible bit for bit.
+        constexpr int PER = GRID_CAP / BLOCK;
+        double acc[MAX_GROUPS + 2];
+#pragma unroll
+        for (int b = 0; b < MAX_GROUPS + 2; b++) acc[b] = 0.0;
+        if (NT <= 4) {
+            double val[PER][4];
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                const int p = tid + j * BLOCK;
+#pragma unroll
+                for (int b = 0; b < 4; b++) val[j][b] = (p < a.nparts && b < NT) ? a.partials[(size_t)p * NT + b] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < PER; j++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[b] += val[j][b];
+        } else {
+#pragma unroll
+            for (int b = 0; b < MAX_GROUPS + 2; b++) {
+                if (b < NT) {
+                    double val[PER];
+#pragma unroll
+                    for (int j = 0; j < PER; j++) { const int p = tid + j * BLOCK; val[j] = p < a.nparts ? a.partials[(size_t)p * NT + b] : 0.0; }
+#pragma unroll
+                    for (int j = 0; j < PER; j++) acc[b] += val[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < MAX_GROUPS + 2; b++) {
+            if (b < NT) {
+                const double s = wave_sum(acc[b]);
+                if (lane == 0) sred[wv][b] = s;
+            }
         }
         __syncthreads();
         if (tid < NT) {
             double s = 0.0;
             for (int w = 0; w < BLOCK / 64; w++) s += sred[w][tid];
             st[L.off_ke_red + tid] = s;
+            s_ke[tid] = s;
         }
         __syncthreads();
+    } else if (tid < NT) {
+        s_ke[tid] = st[L.off_ke_red + tid];      // summed (and all-reduced) by an earlier launch
     }
     if (!a.do_chain) return;
+    if (!a.do_sum) __syncthreads();
     if (L.mode == TGNH_MODE_TGNH) {
         if (tid < NT) {
             switch (L.C) {
-                case 1: run_tgnh<1>(a, tid, s_chain); break;
-                case 2: run_tgnh<2>(a, tid, s_chain); break;
-                case 3: run_tgnh<3>(a, tid, s_chain); break;
-                case 4: run_tgnh<4>(a, tid, s_chain); break;
-                default: run_tgnh<0>(a, tid, s_chain); break;       // host checked NT*(4C+1) <= CHAIN_LDS_DOUBLES
+                case 1: run_tgnh<1>(a, tid, s_chain, s_ke[tid]); break;
+                case 2: run_tgnh<2>(a, tid, s_chain, s_ke[tid]); break;
+                case 3: run_tgnh<3>(a, tid, s_chain, s_ke[tid]); break;
+                case 4: run_tgnh<4>(a, tid, s_chain, s_ke[tid]); break;
+                default: run_tgnh<0>(a, tid, s_chain, s_ke[tid]); break;       // host checked NT*(4C+1) <= CHAIN_LDS_DOUBLES
             }
         }
-        __syncthreads();
         if (tid == 0) {                                              // Cu :493-497
             double s = 0.0;
-            for (int i = 0; i < NT; i++) s += st[L.off_ke + i];
+            for (int i = 0; i < NT; i++) s += s_ke[i];
             st[L.off_kesum] = 0.5 * s;
         }
     } else if (tid == 0) {
         switch (L.C) {
-            case 1: run_dualnh<1>(a, s_chain); break;
-            case 2: run_dualnh<2>(a, s_chain); break;
-            case 3: run_dualnh<3>(a, s_chain); break;
-            case 4: run_dualnh<4>(a, s_chain); break;
-            default: run_dualnh<0>(a, s_chain); break;               // host checked 4*(2C+2) <= CHAIN_LDS_DOUBLES
+            case 1: run_dualnh<1>(a, s_chain, s_ke[0], s_ke[1], s_ke[2]); break;
+            case 2: run_dualnh<2>(a, s_chain, s_ke[0], s_ke[1], s_ke[2]); break;
+            case 3: run_dualnh<3>(a, s_chain, s_ke[0], s_ke[1], s_ke[2]); break;
+            case 4: run_dualnh<4>(a, s_chain, s_ke[0], s_ke[1], s_ke[2]); break;
+            default: run_dualnh<0>(a, s_chain, s_ke[0], s_ke[1], s_ke[2]); break;               // host checked 4*(2C+2) <= CHAIN_LDS_DOUBLES
         }
     }
 }
@@ -806,40 +871,55 @@ __global__ __launch_bounds__(BLOCK) void plain_ke_kernel(const void* velm_, cons
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+typedef void (*tile_fn_t)(const TileArgs);
+
 template <int PREC, int OPS>
-static hipError_t launch_tile_gb(int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s) {
+static tile_fn_t tile_fn_gb(int gb) {
     if constexpr ((OPS & OP_KE) != 0) {
-        if (gb <= 1) hipLaunchKernelGGL((tile_kernel<PREC, OPS, 1>), dim3(grid), dim3(BLOCK), lds, s, a);
-        else if (gb <= 4) hipLaunchKernelGGL((tile_kernel<PREC, OPS, 4>), dim3(grid), dim3(BLOCK), lds, s, a);
-        else hipLaunchKernelGGL((tile_kernel<PREC, OPS, 8>), dim3(grid), dim3(BLOCK), lds, s, a);
+        if (gb <= 1) return tile_kernel<PREC, OPS, 1>;
+        if (gb <= 4) return tile_kernel<PREC, OPS, 4>;
+        return tile_kernel<PREC, OPS, 8>;
     } else {
-        hipLaunchKernelGGL((tile_kernel<PREC, OPS, 1>), dim3(grid), dim3(BLOCK), lds, s, a);
+        return tile_kernel<PREC, OPS, 1>;
     }
-    return hipGetLastError();
 }
 
 template <int PREC>
-static hipError_t launch_tile_ops(int ops, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s) {
+static tile_fn_t tile_fn_ops(int ops, int gb) {
     switch (ops) {
-        case OP_KE: return launch_tile_gb<PREC, OP_KE>(gb, a, grid, lds, s);
-        case OP_SCALE: return launch_tile_gb<PREC, OP_SCALE>(gb, a, grid, lds, s);
-        case OP_SCALE | OP_KE: return launch_tile_gb<PREC, OP_SCALE | OP_KE>(gb, a, grid, lds, s);
-        case OP_SCALE | OP_KICK | OP_DRIFT: return launch_tile_gb<PREC, OP_SCALE | OP_KICK | OP_DRIFT>(gb, a, grid, lds, s);
-        case OP_KICK | OP_KE: return launch_tile_gb<PREC, OP_KICK | OP_KE>(gb, a, grid, lds, s);
-        case OP_KICK: return launch_tile_gb<PREC, OP_KICK>(gb, a, grid, lds, s);
-        case OP_SCALE | OP_KICK | OP_POSDELTA: return launch_tile_gb<PREC, OP_SCALE | OP_KICK | OP_POSDELTA>(gb, a, grid, lds, s);
-        case OP_MOVE: return launch_tile_gb<PREC, OP_MOVE>(gb, a, grid, lds, s);
-        default: return hipErrorInvalidValue;
+        case OP_KE: return tile_fn_gb<PREC, OP_KE>(gb);
+        case OP_SCALE: return tile_fn_gb<PREC, OP_SCALE>(gb);
+        case OP_SCALE | OP_KE: return tile_fn_gb<PREC, OP_SCALE | OP_KE>(gb);
+        case OP_SCALE | OP_KICK | OP_DRIFT: return tile_fn_gb<PREC, OP_SCALE | OP_KICK | OP_DRIFT>(gb);
+        case OP_KICK | OP_KE: return tile_fn_gb<PREC, OP_KICK | OP_KE>(gb);
+        case OP_KICK: return tile_fn_gb<PREC, OP_KICK>(gb);
+        case OP_SCALE | OP_KICK | OP_POSDELTA: return tile_fn_gb<PREC, OP_SCALE | OP_KICK | OP_POSDELTA>(gb);
+        case OP_MOVE: return tile_fn_gb<PREC, OP_MOVE>(gb);
+        default: return nullptr;
+    }
+}
+
+static tile_fn_t tile_fn(int precision, int ops, int gb) {
+    switch (precision) {
+        case TGNH_PREC_SINGLE: return tile_fn_ops<TGNH_PREC_SINGLE>(ops, gb);
+        case TGNH_PREC_MIXED: return tile_fn_ops<TGNH_PREC_MIXED>(ops, gb);
+        case TGNH_PREC_DOUBLE: return tile_fn_ops<TGNH_PREC_DOUBLE>(ops, gb);
+        default: return nullptr;
     }
 }
 
 hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s) {
-    switch (precision) {
-        case TGNH_PREC_SINGLE: return launch_tile_ops<TGNH_PREC_SINGLE>(ops, gb, a, grid, lds, s);
-        case TGNH_PREC_MIXED: return launch_tile_ops<TGNH_PREC_MIXED>(ops, gb, a, grid, lds, s);
-        case TGNH_PREC_DOUBLE: return launch_tile_ops<TGNH_PREC_DOUBLE>(ops, gb, a, grid, lds, s);
-        default: return hipErrorInvalidValue;
-    }
+    tile_fn_t fn = tile_fn(precision, ops, gb);
+    if (!fn) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(BLOCK), lds, s, a);
+    return hipGetLastError();
+}
+
+int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds) {
+    tile_fn_t fn = tile_fn(precision, ops, gb);
+    int n = 0;
+    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(fn), BLOCK, lds) != hipSuccess) return 0;
+    return n;
 }
 
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {

@@ -287,6 +287,21 @@ def test_merged_and_deferred_rescale_match_plain(mode, flags):
     ref[4].close(); alt[4].close()
 
 
+@pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
+@pytest.mark.parametrize("precision", ["mixed", "double"])
+def test_100_step_parity_deferred_rescale(mode, precision):
+    """The bench default (TGNH_FLAG_DEFER_SCALE: the end-of-step rescale is applied by the next step's first
+    pass and the chain runs both thermostat half steps back to back on s^2 KE) against the oracle directly."""
+    s, g, ng, it, ctx = make("mixed", mode, precision, flags=FLAG_DEFER_SCALE, chains=3, hardwall=0.02)
+    o = make_oracle(s, g, ng, mode, it)
+    pos_o, vel_o = oracle_run(o, s, 100, x0=ctx.sites())
+    ctx.step(100)
+    ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
+    print(f"deferred {mode} {precision}: pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= TOL and ev <= TOL
+    ctx.close()
+
+
 def test_split_constraint_path_matches_fused():
     """begin_kick / begin_move / end_kick / end_thermo (the posDelta path around OpenMM's constraint
     call-outs, Cu :356-369, :384-402) with no constraints applied equals the fused step."""
