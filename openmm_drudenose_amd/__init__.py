@@ -4,7 +4,7 @@ Product code only: nothing here imports the CPU oracle (``oracle/``).  The HIP
 library must be present; there is no CPU fallback.
 """
 from .system import DrudeSystem  # noqa: F401
-from .drudetgnhplugin import DrudeTGNHIntegrator, HipContext, TgnhError  # noqa: F401
+from .drudetgnhplugin import DrudeTGNHIntegrator, HipContext, HostTopology, TgnhError  # noqa: F401
 from . import synth  # noqa: F401
 
-__all__ = ["DrudeSystem", "DrudeTGNHIntegrator", "HipContext", "TgnhError", "synth"]
+__all__ = ["DrudeSystem", "DrudeTGNHIntegrator", "HipContext", "HostTopology", "TgnhError", "synth"]

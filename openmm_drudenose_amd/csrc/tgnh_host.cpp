@@ -163,6 +163,7 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
             c->meta[i] = pack_meta((uint32_t)role[i], (uint32_t)c->group[i], off, (uint32_t)local_res);
         }
     }
+    if (c->host_only) return TGNH_OK;
     // device copies
     HIP_OK(hipMalloc(&c->d_meta, sizeof(uint32_t) * std::max(N, 1)));
     HIP_OK(hipMemcpy(c->d_meta, c->meta.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
@@ -275,7 +276,8 @@ static tgnh_status finalize_thermostat(tgnh_context* c) {
         st[L.off_nkbt + i] = c->nkbt[i];
         st[L.off_scale + i] = 1.0; st[L.off_scale_a + i] = 1.0; st[L.off_scale_b + i] = 1.0;
     }
-    HIP_OK(hipMemcpy(c->d_state, st.data(), sizeof(double) * L.total, hipMemcpyHostToDevice));
+    c->h_state = st;
+    if (!c->host_only) HIP_OK(hipMemcpy(c->d_state, st.data(), sizeof(double) * L.total, hipMemcpyHostToDevice));
     c->ke_valid = false; c->scale_pending = false; c->first_half_done = false;
     return TGNH_OK;
 }
@@ -350,12 +352,17 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
                                                     : 4L * (2L * d->num_nh_chains + 4);
         if (d->num_nh_chains > 4 && need > 2048) return fail(TGNH_ERR_UNSUPPORTED, "numNHChains too large for the on-device chain");
     }
-    int ndev = 0;
-    HIP_OK(hipGetDeviceCount(&ndev));
-    if (d->device < 0 || d->device >= ndev) return fail(TGNH_ERR_HIP, "no such HIP device (the HIP path needs an MI355X; there is no CPU fallback)");
-    HIP_OK(hipSetDevice(d->device));
+    // device == -1: host-only handle for the host logic (topology, tiles, dof); every launch on it fails
+    const bool host_only = d->device == -1;
+    if (!host_only) {
+        int ndev = 0;
+        HIP_OK(hipGetDeviceCount(&ndev));
+        if (d->device < 0 || d->device >= ndev) return fail(TGNH_ERR_HIP, "no such HIP device (the HIP path needs an MI355X; there is no CPU fallback)");
+        HIP_OK(hipSetDevice(d->device));
+    }
 
     tgnh_context* c = new tgnh_context();
+    c->host_only = host_only;
     c->d = *d;
     c->device = d->device;
     c->realkbT = d->kB * d->temperature;                                      // Ref :107-108, Cu :80-81
@@ -383,13 +390,14 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
 
     c->grid = GRID_CAP;                       // partials are sized for the largest grid
     if (const char* e = getenv("TGNH_GRID")) { int g = atoi(e); if (g >= 1) c->grid_override = std::min(g, GRID_CAP); }
-    {
+    if (!host_only) {
         hipDeviceProp_t prop;
         HIP_OK(hipGetDeviceProperties(&prop, d->device));
         c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     c->gb = c->L.G <= 1 ? 1 : (c->L.G <= 4 ? 4 : 8);
     auto alloc = [&]() -> tgnh_status {
+        if (host_only) return TGNH_OK;
         HIP_OK(hipMalloc(&c->d_partials, sizeof(double) * (size_t)c->grid * c->L.NT));
         HIP_OK(hipMemset(c->d_partials, 0, sizeof(double) * (size_t)c->grid * c->L.NT));
         HIP_OK(hipMalloc(&c->d_state, sizeof(double) * c->L.total));
@@ -407,8 +415,7 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
 
 extern "C" tgnh_status tgnh_destroy(tgnh_handle h) {
     CHECK_H(h);
-    (void)hipSetDevice(h->device);
-    free_device(h);
+    if (!h->host_only) { (void)hipSetDevice(h->device); free_device(h); }
     delete h;
     return TGNH_OK;
 }
@@ -416,6 +423,7 @@ extern "C" tgnh_status tgnh_destroy(tgnh_handle h) {
 extern "C" tgnh_status tgnh_bind_buffers(tgnh_handle h, void* posq, void* posq_correction, void* velm,
                                          const void* force, void* pos_delta) {
     CHECK_H(h);
+    if (h->host_only) return fail(TGNH_ERR_STATE, "host-only handle (device -1): no GPU work can be launched on it");
     if (!posq || !velm || !force) return fail(TGNH_ERR_ARG, "posq, velm and force are required");
     if (h->d.precision == TGNH_PREC_MIXED && !posq_correction) return fail(TGNH_ERR_ARG, "mixed precision needs posqCorrection");
     h->posq = posq; h->posq_corr = posq_correction; h->velm = velm; h->force = force; h->pos_delta = pos_delta;
@@ -460,7 +468,7 @@ extern "C" tgnh_status tgnh_set_global_dof_terms(tgnh_handle h, const double* te
     CHECK_H(h);
     if (!terms || count != h->L.NT) return fail(TGNH_ERR_ARG, "dof term count mismatch");
     if (h->step_count != 0) return fail(TGNH_ERR_STATE, "global dof must be set before the first step");
-    HIP_OK(hipSetDevice(h->device));
+    if (!h->host_only) HIP_OK(hipSetDevice(h->device));
     h->global_terms.assign(terms, terms + count);
     return finalize_thermostat(h);
 }
@@ -490,6 +498,7 @@ struct Timed {
 };
 
 static tgnh_status need_buffers(tgnh_handle h) {
+    if (h->host_only) return fail(TGNH_ERR_STATE, "host-only handle (device -1): no GPU work can be launched on it");
     if (!h->velm) return fail(TGNH_ERR_STATE, "tgnh_bind_buffers has not been called");
     return TGNH_OK;
 }
@@ -661,6 +670,7 @@ extern "C" tgnh_status tgnh_state_changed(tgnh_handle h) {
 // queries
 // ---------------------------------------------------------------------------
 static tgnh_status read_state(tgnh_handle h, int off, int n, hipStream_t s, double* out) {
+    if (h->host_only) { std::copy(h->h_state.begin() + off, h->h_state.begin() + off + n, out); return TGNH_OK; }
     HIP_OK(hipSetDevice(h->device));
     HIP_OK(hipMemcpyAsync(out, h->d_state + off, sizeof(double) * n, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
@@ -699,6 +709,7 @@ extern "C" tgnh_status tgnh_get_last_scale_factors(tgnh_handle h, void* stream, 
 }
 extern "C" tgnh_status tgnh_get_status_flags(tgnh_handle h, void* stream, uint32_t* flags) {
     CHECK_H(h);
+    if (h->host_only) { *flags = 0; return TGNH_OK; }
     HIP_OK(hipSetDevice(h->device));
     HIP_OK(hipMemcpyAsync(flags, h->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));
@@ -745,6 +756,7 @@ extern "C" tgnh_status tgnh_set_thermostat_state(tgnh_handle h, int which, void*
     int off, len;
     if (!chain_section(h, which, &off, &len)) return fail(TGNH_ERR_ARG, "bad thermostat array id");
     tgnh_status rc = deferred_guard(h, "tgnh_set_thermostat_state"); if (rc) return rc;
+    if (h->host_only) { std::copy(in, in + len, h->h_state.begin() + off); return TGNH_OK; }
     HIP_OK(hipSetDevice(h->device));
     HIP_OK(hipMemcpyAsync(h->d_state + off, in, sizeof(double) * len, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));
@@ -841,6 +853,7 @@ static void drain_events(tgnh_handle h) {
 }
 extern "C" tgnh_status tgnh_timing_enable(tgnh_handle h, int on) {
     CHECK_H(h);
+    if (h->host_only) return fail(TGNH_ERR_STATE, "host-only handle");
     HIP_OK(hipSetDevice(h->device));
     if (!on) drain_events(h);
     else { for (int k = 0; k < KID_COUNT; k++) { h->t_total[k] = 0; h->t_count[k] = 0; } h->ev_used = 0; }
@@ -850,8 +863,7 @@ extern "C" tgnh_status tgnh_timing_enable(tgnh_handle h, int on) {
 extern "C" tgnh_status tgnh_timing_read(tgnh_handle h, int kernel, double* total_ms, int64_t* launches) {
     CHECK_H(h);
     if (kernel < 0 || kernel >= KID_COUNT) return fail(TGNH_ERR_ARG, "bad kernel id");
-    HIP_OK(hipSetDevice(h->device));
-    drain_events(h);
+    if (!h->host_only) { HIP_OK(hipSetDevice(h->device)); drain_events(h); }
     if (total_ms) *total_ms = h->t_total[kernel];
     if (launches) *launches = h->t_count[kernel];
     return TGNH_OK;

@@ -132,6 +132,8 @@ size_t tile_lds_bytes(int precision, int ops, bool hardwall, bool use_com);
 struct tgnh_context {
     tgnh_desc d;                      // scalars only; pointers are nulled after create
     int device = 0;
+    bool host_only = false;           // device == -1: topology / dof only, no launches
+    std::vector<double> h_state;      // host copy of the initial thermostat block
     // host topology (A1), kept for parity queries
     std::vector<double> mass;
     std::vector<int> pair_drude, pair_parent, group, resid, normal;

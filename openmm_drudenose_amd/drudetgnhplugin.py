@@ -140,7 +140,113 @@ class DrudeTGNHIntegrator:
         return np.asarray(self._particleTempGroup, np.int32), len(self._tempGroups)
 
 
-class HipContext:
+def create_handle(lib, system, integrator, group, ngroups, mode, precision, device, flags, kB, padded):
+    """tgnh_create from a DrudeSystem + integrator mirror.  device = -1 gives a host-only handle."""
+    n = system.num_particles
+    d = _lib.TgnhDesc()
+    d.struct_size = C.sizeof(_lib.TgnhDesc)
+    d.mode, d.precision, d.flags, d.device = mode, precision, int(flags), device
+    d.num_particles, d.padded_num_particles = n, padded
+    d.num_pairs, d.num_groups, d.num_residues = system.num_pairs, ngroups, system.num_residues
+    d.num_constraints = len(system.constraints)
+    d.has_cm_motion_remover = int(system.has_cm_motion_remover)
+    group = np.ascontiguousarray(group, np.int32)
+    ci = np.ascontiguousarray(system.constraints[:, 0]) if len(system.constraints) else None
+    cj = np.ascontiguousarray(system.constraints[:, 1]) if len(system.constraints) else None
+    d.mass = system.mass.ctypes.data_as(_lib.c_f64p)
+    d.pair_drude = system.pair_drude.ctypes.data_as(_lib.c_i32p)
+    d.pair_parent = system.pair_parent.ctypes.data_as(_lib.c_i32p)
+    d.group = group.ctypes.data_as(_lib.c_i32p)
+    d.resid = system.resid.ctypes.data_as(_lib.c_i32p)
+    if ci is not None:
+        d.constraint_i = ci.ctypes.data_as(_lib.c_i32p)
+        d.constraint_j = cj.ctypes.data_as(_lib.c_i32p)
+    d.kB = kB
+    d.temperature, d.coupling_time = integrator.getTemperature(), integrator.getCouplingTime()
+    d.drude_temperature, d.drude_coupling_time = integrator.getDrudeTemperature(), integrator.getDrudeCouplingTime()
+    d.step_size = integrator.getStepSize()
+    d.drude_steps_per_real_step = integrator.getDrudeStepsPerRealStep()
+    d.num_nh_chains = integrator.getNumNHChains()
+    d.use_drude_nh_chains = integrator.getUseDrudeNHChains()
+    d.use_com_temp_group = integrator.getUseCOMTempGroup()
+    d.max_drude_distance = integrator.getMaxDrudeDistance()
+    h = C.c_void_p()
+    _check(lib.tgnh_create(C.byref(d), C.byref(h)))
+    return h
+
+
+class _HandleQueries:
+    """Queries shared by device contexts and host-only handles."""
+
+    def _stream(self):
+        return None
+
+    def local_dof_terms(self):
+        n = C.c_int()
+        _check(self.lib.tgnh_get_local_dof_terms(self.h, None, C.byref(n)))
+        out = np.zeros(n.value)
+        _check(self.lib.tgnh_get_local_dof_terms(self.h, out.ctypes.data_as(_lib.c_f64p), C.byref(n)))
+        return out
+
+    def set_global_dof_terms(self, total):
+        total = np.ascontiguousarray(total, np.float64)
+        _check(self.lib.tgnh_set_global_dof_terms(self.h, total.ctypes.data_as(_lib.c_f64p), len(total)))
+
+    def num_thermostats(self):
+        n = C.c_int()
+        _check(self.lib.tgnh_get_num_thermostats(self.h, C.byref(n)))
+        return n.value
+
+    def dof(self):
+        n = self.num_thermostats()
+        dof, nkt = np.zeros(n), np.zeros(n)
+        _check(self.lib.tgnh_get_dof(self.h, dof.ctypes.data_as(_lib.c_f64p), nkt.ctypes.data_as(_lib.c_f64p)))
+        return dof, nkt
+
+    def thermostat_state(self, which):
+        n = C.c_int()
+        _check(self.lib.tgnh_get_thermostat_len(self.h, which, C.byref(n)))
+        out = np.zeros(n.value)
+        _check(self.lib.tgnh_get_thermostat_state(self.h, which, self._stream(), out.ctypes.data_as(_lib.c_f64p)))
+        return out
+
+    def set_thermostat_state(self, which, arr):
+        arr = np.ascontiguousarray(arr, np.float64)
+        _check(self.lib.tgnh_set_thermostat_state(self.h, which, self._stream(), arr.ctypes.data_as(_lib.c_f64p)))
+
+    def topology(self, which):
+        n = C.c_int()
+        _check(self.lib.tgnh_get_topology_len(self.h, which, C.byref(n)))
+        out = np.zeros(n.value, np.int32)
+        _check(self.lib.tgnh_get_topology(self.h, which, out.ctypes.data_as(_lib.c_i32p)))
+        return out
+
+
+class HostTopology(_HandleQueries):
+    """Host-only handle (device -1): the library's topology / tile / dof logic without a GPU.  Used by the CPU
+    tests; it cannot launch anything."""
+
+    def __init__(self, system, integrator, mode="TGNH", precision="mixed", flags=0, kB=KB):
+        self.lib = _lib.load()
+        group, ngroups = integrator._resolve_groups(system.num_particles)
+        self.group, self.num_groups = group, ngroups
+        n = system.num_particles
+        self.h = create_handle(self.lib, system, integrator, group, ngroups, _MODE[mode], _PREC[precision], -1, flags, kB,
+                               (n + 31) // 32 * 32)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tgnh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipContext(_HandleQueries):
     """Device state + handle: what OpenMM's Context / HIP platform data are to the reference kernel.
 
     force_fn(ctx) is the force call-out (calcForcesAndEnergy); the default is the
@@ -166,43 +272,13 @@ class HipContext:
         self.k_drude = K_DRUDE if k_drude is None else k_drude
         self.k_tether = K_TETHER if k_tether is None else k_tether
 
-        d = _lib.TgnhDesc()
-        d.struct_size = C.sizeof(_lib.TgnhDesc)
-        d.mode, d.precision, d.flags, d.device = self.mode, self.precision, int(flags), device
-        d.num_particles, d.padded_num_particles = n, self.padded
-        d.num_pairs, d.num_groups, d.num_residues = system.num_pairs, ngroups, system.num_residues
-        d.num_constraints = len(system.constraints)
-        d.has_cm_motion_remover = int(system.has_cm_motion_remover)
-        keep = [system.mass, system.pair_drude, system.pair_parent, group, system.resid]
-        ci = np.ascontiguousarray(system.constraints[:, 0]) if len(system.constraints) else None
-        cj = np.ascontiguousarray(system.constraints[:, 1]) if len(system.constraints) else None
-        d.mass = system.mass.ctypes.data_as(_lib.c_f64p)
-        d.pair_drude = system.pair_drude.ctypes.data_as(_lib.c_i32p)
-        d.pair_parent = system.pair_parent.ctypes.data_as(_lib.c_i32p)
-        d.group = group.ctypes.data_as(_lib.c_i32p)
-        d.resid = system.resid.ctypes.data_as(_lib.c_i32p)
-        if ci is not None:
-            d.constraint_i = ci.ctypes.data_as(_lib.c_i32p)
-            d.constraint_j = cj.ctypes.data_as(_lib.c_i32p)
-        d.kB = kB
-        d.temperature, d.coupling_time = integrator.getTemperature(), integrator.getCouplingTime()
-        d.drude_temperature, d.drude_coupling_time = integrator.getDrudeTemperature(), integrator.getDrudeCouplingTime()
-        d.step_size = integrator.getStepSize()
-        d.drude_steps_per_real_step = integrator.getDrudeStepsPerRealStep()
-        d.num_nh_chains = integrator.getNumNHChains()
-        d.use_drude_nh_chains = integrator.getUseDrudeNHChains()
-        d.use_com_temp_group = integrator.getUseCOMTempGroup()
-        d.max_drude_distance = integrator.getMaxDrudeDistance()
-        h = C.c_void_p()
         with torch.cuda.device(self.dev):
-            _check(self.lib.tgnh_create(C.byref(d), C.byref(h)))
-        del keep
+            h = create_handle(self.lib, system, integrator, group, ngroups, self.mode, self.precision, device, flags, kB,
+                              self.padded)
         self.h = h
         self._hook = None
         if global_dof_sum is not None:                       # particle sharding: dof terms are additive over ranks
-            terms = self.local_dof_terms()
-            total = np.ascontiguousarray(global_dof_sum(terms), np.float64)
-            _check(self.lib.tgnh_set_global_dof_terms(self.h, total.ctypes.data_as(_lib.c_f64p), len(total)))
+            self.set_global_dof_terms(global_dof_sum(self.local_dof_terms()))
         if allreduce is not None:
             self.set_allreduce(allreduce)
 
@@ -282,13 +358,6 @@ class HipContext:
             v = torch.as_tensor(hold, device=self.dev)
             self._views[key] = v
         return v
-
-    def local_dof_terms(self):
-        n = C.c_int()
-        _check(self.lib.tgnh_get_local_dof_terms(self.h, None, C.byref(n)))
-        out = np.zeros(n.value)
-        _check(self.lib.tgnh_get_local_dof_terms(self.h, out.ctypes.data_as(_lib.c_f64p), C.byref(n)))
-        return out
 
     # ---- state (Context::setPositions / setVelocities / getState) ----
     def setPositions(self, pos):
@@ -375,11 +444,6 @@ class HipContext:
         return flags.value
 
     # ---- queries ----
-    def num_thermostats(self):
-        n = C.c_int()
-        _check(self.lib.tgnh_get_num_thermostats(self.h, C.byref(n)))
-        return n.value
-
     def _vec(self, fn, n):
         out = np.zeros(n)
         _check(fn(self.h, self._stream(), out.ctypes.data_as(_lib.c_f64p)))
@@ -402,30 +466,6 @@ class HipContext:
         out = C.c_double()
         _check(self.lib.tgnh_get_kinetic_energy(self.h, int(self.ke_sum_valid), self._stream(), C.byref(out)))
         return out.value
-
-    def dof(self):
-        n = self.num_thermostats()
-        dof, nkt = np.zeros(n), np.zeros(n)
-        _check(self.lib.tgnh_get_dof(self.h, dof.ctypes.data_as(_lib.c_f64p), nkt.ctypes.data_as(_lib.c_f64p)))
-        return dof, nkt
-
-    def thermostat_state(self, which):
-        n = C.c_int()
-        _check(self.lib.tgnh_get_thermostat_len(self.h, which, C.byref(n)))
-        out = np.zeros(n.value)
-        _check(self.lib.tgnh_get_thermostat_state(self.h, which, self._stream(), out.ctypes.data_as(_lib.c_f64p)))
-        return out
-
-    def set_thermostat_state(self, which, arr):
-        arr = np.ascontiguousarray(arr, np.float64)
-        _check(self.lib.tgnh_set_thermostat_state(self.h, which, self._stream(), arr.ctypes.data_as(_lib.c_f64p)))
-
-    def topology(self, which):
-        n = C.c_int()
-        _check(self.lib.tgnh_get_topology_len(self.h, which, C.byref(n)))
-        out = np.zeros(n.value, np.int32)
-        _check(self.lib.tgnh_get_topology(self.h, which, out.ctypes.data_as(_lib.c_i32p)))
-        return out
 
     def time(self):
         t, k = C.c_double(), C.c_int64()

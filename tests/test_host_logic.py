@@ -1,0 +1,127 @@
+"""CPU tests of the library's host logic through host-only handles (device -1): topology (A1, bit-exact against
+the oracle and numpy), tiles and packed words, degrees of freedom and thermostat masses (A2), error behaviour.
+Nothing is launched (no GPU here)."""
+import numpy as np
+import pytest
+
+from openmm_drudenose_amd import synth, _lib, DrudeTGNHIntegrator, HostTopology, TgnhError
+from helpers import make_oracle, to_internal
+
+
+def integ(chains=3, drude_chains=True, com=True, group=None, ngroups=0):
+    it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, chains, drude_chains, com)
+    for _ in range(ngroups):
+        it.addTempGroup()
+    if group is not None:
+        for g in group:
+            it.addParticleTempGroup(int(g))
+    return it
+
+
+BUILDERS = {"pnm": synth.pair_normal_massless, "nacl": synth.nacl, "il": lambda: synth.ionic_liquid(30),
+            "mixed": lambda: synth.mixed(250, 12), "water": lambda: synth.water_box(700)}
+
+
+@pytest.mark.parametrize("name", list(BUILDERS))
+def test_topology_bit_exact_against_oracle(name):
+    s, g, ng = BUILDERS[name]()
+    it = integ(group=g, ngroups=ng)
+    t = HostTopology(s, it, mode="TGNH")
+    o = make_oracle(s, g, ng, "TGNH", it)
+    assert np.array_equal(t.topology(0), o.normal_particles())                  # Ref :113-137
+    assert np.array_equal(t.topology(1), s.pair_drude) and np.array_equal(t.topology(2), s.pair_parent)
+    assert np.array_equal(t.topology(3), g) and np.array_equal(t.topology(4), s.resid)
+    assert np.array_equal(t.topology(5), np.bincount(s.resid, minlength=s.num_residues))      # Cu :121
+    first = np.full(s.num_residues, -1)
+    for i in range(s.num_particles - 1, -1, -1):
+        first[s.resid[i]] = i
+    assert np.array_equal(t.topology(6), first)                                  # Cu :122-125
+    ts = t.topology(7)
+    assert ts[0] == 0 and ts[-1] == s.num_particles and np.all(np.diff(ts) > 0) and np.all(np.diff(ts) <= 512)
+    tile_of = np.searchsorted(ts, np.arange(s.num_particles), side="right") - 1
+    assert np.all(tile_of[s.pair_drude] == tile_of[s.pair_parent])
+    assert np.all(tile_of[np.r_[0, np.flatnonzero(np.diff(s.resid)) + 1]] == tile_of[np.r_[np.flatnonzero(np.diff(s.resid)), s.num_particles - 1]])
+    meta = t.topology(8).view(np.uint32)
+    assert np.array_equal(np.flatnonzero((meta & 3) == 1), np.sort(s.pair_drude))
+    assert np.array_equal(np.flatnonzero((meta & 3) == 2), np.sort(s.pair_parent))
+    assert np.array_equal(((meta >> 2) & 255).astype(np.int32), g)
+    off = ((meta >> 10) & 2047).astype(np.int64) - 1024
+    assert np.array_equal((np.arange(s.num_particles) + off)[s.pair_drude], s.pair_parent)
+    assert np.array_equal((np.arange(s.num_particles) + off)[s.pair_parent], s.pair_drude)
+    # tile-local residue index
+    res_first_of_tile = s.resid[ts[:-1]]
+    assert np.array_equal((meta >> 21).astype(np.int64), s.resid - res_first_of_tile[tile_of])
+
+
+@pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
+@pytest.mark.parametrize("com,chains,drude_chains,cmm", [(True, 1, True, False), (True, 3, False, True), (False, 4, True, True),
+                                                         (True, 6, True, False)])
+def test_dof_and_thermostat_block_match_oracle(mode, com, chains, drude_chains, cmm):
+    s, g, ng = synth.mixed(120, 9)
+    s.has_cm_motion_remover = cmm
+    if mode == "dualNH":
+        g, ng = np.zeros_like(g), 1
+    it = integ(chains=chains, drude_chains=drude_chains, com=com, group=g if mode == "TGNH" else None,
+               ngroups=ng if mode == "TGNH" else 0)
+    t = HostTopology(s, it, mode=mode)
+    o = make_oracle(s, g, ng, mode, it)
+    dof_o, nkt_o = o.dof()
+    dof, nkt = t.dof()
+    assert np.allclose(dof, to_internal(dof_o, mode), rtol=1e-14, atol=0)
+    assert np.allclose(nkt, to_internal(nkt_o, mode), rtol=1e-14, atol=0)
+    for which in range(4):                                      # eta, etaDot, etaDotDot, etaMass: same layout, same values
+        a, b = t.thermostat_state(which), o.chain(which)
+        assert a.shape == b.shape and np.allclose(a, b, rtol=1e-14, atol=0), which
+
+
+def test_constraints_reduce_group_dof_and_must_not_span_groups():
+    s, g, ng = synth.mixed(40, 3)
+    # constrain O-H1, O-H2 of every water (slots 0,2 and 0,3 of each 5-slot molecule): Cu :186-196
+    w = np.arange(40) * 5
+    s.constraints = np.stack([np.r_[w, w], np.r_[w + 2, w + 3]], 1).astype(np.int32)
+    it = integ(group=g, ngroups=ng)
+    t = HostTopology(s, it)
+    o = make_oracle(s, g, ng, "TGNH", it)
+    assert np.allclose(t.dof()[0], o.dof()[0], rtol=1e-14)
+    s.constraints = np.array([[0, 46]], np.int32)               # water of group 0 with a tagged (group 3) water
+    assert g[0] != g[46]
+    with pytest.raises(TgnhError, match="Temperature group of constrained particles") as e:
+        HostTopology(s, integ(group=g, ngroups=ng))
+    assert e.value.status == _lib.ERR_GROUP_MISMATCH
+
+
+def test_unsupported_topologies_fail_loudly():
+    s, g, ng = synth.water_box(4)
+    bad = s.resid.copy()
+    bad[[1, 6]] = bad[[6, 1]]                                   # molecule 0 and 1 interleaved
+    s2 = type(s)(mass=s.mass, pair_drude=s.pair_drude, pair_parent=s.pair_parent, resid=bad)
+    with pytest.raises(TgnhError) as e:
+        HostTopology(s2, integ())
+    assert e.value.status == _lib.ERR_UNSUPPORTED
+    s3 = type(s)(mass=s.mass, pair_drude=np.r_[s.pair_drude, 2], pair_parent=np.r_[s.pair_parent, 0], resid=s.resid)
+    with pytest.raises(TgnhError, match="more than one Drude pair"):
+        HostTopology(s3, integ())
+    m = s.mass.copy(); m[0] = 0.0                               # massless parent: the reference divides by it
+    with pytest.raises(TgnhError, match="massless"):
+        HostTopology(type(s)(mass=m, pair_drude=s.pair_drude, pair_parent=s.pair_parent, resid=s.resid), integ())
+    big = synth.DrudeSystem(mass=np.ones(600), pair_drude=np.array([1]), pair_parent=np.array([0]), resid=np.zeros(600, np.int32))
+    with pytest.raises(TgnhError, match="spans more than one"):  # one 600-slot molecule
+        HostTopology(big, integ())
+    HostTopology(big, integ(), mode="dualNH").close()           # no COM needed: tiles may cut the molecule
+
+
+def test_host_only_handle_cannot_launch():
+    s, g, ng = synth.water_box(4)
+    t = HostTopology(s, integ())
+    assert t.lib.tgnh_step_begin(t.h, None) == _lib.ERR_STATE
+    assert b"host-only" in t.lib.tgnh_last_error()
+    assert t.lib.tgnh_bind_buffers(t.h, None, None, None, None, None) == _lib.ERR_STATE
+
+
+def test_deferred_rescale_needs_single_group_molecules():
+    s, g, ng = synth.water_box(6)
+    g = g.copy(); g[2] = 1                                       # H1 of molecule 0 in another group than O
+    it = integ(group=g, ngroups=2)
+    HostTopology(s, it).close()
+    with pytest.raises(TgnhError, match="inside one temperature group"):
+        HostTopology(s, integ(group=g, ngroups=2), flags=_lib.FLAG_DEFER_SCALE)
