@@ -1,0 +1,133 @@
+// OpenMM-HIP glue (not compiled here, see HipDrudeTGNHKernels.h).  Everything with arithmetic in it lives
+// behind the C ABI; this file only translates OpenMM objects into tgnh_desc and device pointers.
+#include "HipDrudeTGNHKernels.h"
+#include "openmm/CMMotionRemover.h"
+#include "openmm/OpenMMException.h"
+#include "openmm/internal/ContextImpl.h"
+#include "SimTKOpenMMRealType.h"
+#include <typeinfo>
+#include <vector>
+
+using namespace OpenMM;
+using namespace std;
+
+void HipIntegrateDrudeTGNHStepKernel::check(tgnh_status rc) const {
+    if (rc != TGNH_OK)
+        throw OpenMMException(tgnh_last_error());       // same channel as the reference's throws
+}
+
+HipIntegrateDrudeTGNHStepKernel::~HipIntegrateDrudeTGNHStepKernel() {
+    if (handle != nullptr) {
+        ContextSelector selector(cu);
+        tgnh_destroy(handle);
+    }
+}
+
+void HipIntegrateDrudeTGNHStepKernel::initialize(const System& system, const DrudeTGNHIntegrator& integrator, const DrudeForce& force) {
+    cu.getPlatformData().initializeContexts(system);
+    ContextSelector selector(cu);
+    const int numParticles = system.getNumParticles();
+    vector<double> mass(numParticles);
+    vector<int> group(numParticles), resid(numParticles);
+    for (int i = 0; i < numParticles; i++) {
+        mass[i] = system.getParticleMass(i);
+        integrator.getParticleTempGroup(i, group[i]);
+        resid[i] = integrator.getParticleResId(i);
+    }
+    vector<int> pairDrude(force.getNumParticles()), pairParent(force.getNumParticles());
+    for (int i = 0; i < force.getNumParticles(); i++) {
+        int p, p1, p2, p3, p4;
+        double charge, polarizability, aniso12, aniso34;
+        force.getParticleParameters(i, p, p1, p2, p3, p4, charge, polarizability, aniso12, aniso34);
+        pairDrude[i] = p;
+        pairParent[i] = p1;
+    }
+    numConstraints = system.getNumConstraints();
+    vector<int> ci(numConstraints), cj(numConstraints);
+    for (int i = 0; i < numConstraints; i++) {
+        double distance;
+        system.getConstraintParameters(i, ci[i], cj[i], distance);
+    }
+    bool hasCMM = false;
+    for (int i = 0; i < system.getNumForces(); i++)
+        if (dynamic_cast<const CMMotionRemover*>(&system.getForce(i)) != nullptr)
+            hasCMM = true;
+
+    tgnh_desc d = {};
+    d.struct_size = sizeof(tgnh_desc);
+    d.mode = TGNH_MODE_TGNH;                               // the GPU platform's semantics (temperature groups + COM)
+    d.precision = cu.getUseDoublePrecision() ? TGNH_PREC_DOUBLE : (cu.getUseMixedPrecision() ? TGNH_PREC_MIXED : TGNH_PREC_SINGLE);
+    d.flags = 0;                                           // OpenMM may touch velocities between steps: keep the plain pass structure
+    d.device = cu.getDeviceIndex();
+    d.num_particles = numParticles;
+    d.padded_num_particles = cu.getPaddedNumAtoms();
+    d.num_pairs = force.getNumParticles();
+    d.num_groups = integrator.getNumTempGroups();
+    d.num_residues = integrator.getNumResidues();
+    d.num_constraints = numConstraints;
+    d.has_cm_motion_remover = hasCMM;
+    d.mass = mass.data();
+    d.pair_drude = pairDrude.data();
+    d.pair_parent = pairParent.data();
+    d.group = group.data();
+    d.resid = resid.data();
+    d.constraint_i = ci.data();
+    d.constraint_j = cj.data();
+    d.kB = BOLTZ;
+    d.temperature = integrator.getTemperature();
+    d.coupling_time = integrator.getCouplingTime();
+    d.drude_temperature = integrator.getDrudeTemperature();
+    d.drude_coupling_time = integrator.getDrudeCouplingTime();
+    d.step_size = integrator.getStepSize();
+    d.drude_steps_per_real_step = integrator.getDrudeStepsPerRealStep();
+    d.num_nh_chains = integrator.getNumNHChains();
+    d.use_drude_nh_chains = integrator.getUseDrudeNHChains();
+    d.use_com_temp_group = integrator.getUseCOMTempGroup();
+    d.max_drude_distance = integrator.getMaxDrudeDistance();
+    check(tgnh_create(&d, &handle));
+}
+
+void HipIntegrateDrudeTGNHStepKernel::execute(ContextImpl& context, const DrudeTGNHIntegrator& integrator) {
+    ContextSelector selector(cu);
+    IntegrationUtilities& integration = cu.getIntegrationUtilities();
+    void* stream = (void*) cu.getCurrentStream();
+    // values the reference re-reads every step (CudaDrudeTGNHKernels.cpp:292, :298, :437)
+    check(tgnh_set_step_size(handle, integrator.getStepSize()));
+    check(tgnh_set_drude_steps_per_real_step(handle, integrator.getDrudeStepsPerRealStep()));
+    check(tgnh_set_max_drude_distance(handle, integrator.getMaxDrudeDistance()));
+    // OpenMM may reallocate nothing here, but reordering keeps the same arrays: bind every step (cheap, no launch)
+    check(tgnh_bind_buffers(handle, (void*) cu.getPosq().getDevicePointer(),
+                            cu.getUseMixedPrecision() ? (void*) cu.getPosqCorrection().getDevicePointer() : nullptr,
+                            (void*) cu.getVelm().getDevicePointer(), (const void*) cu.getForce().getDevicePointer(),
+                            (void*) integration.getPosDelta().getDevicePointer()));
+    if (cu.getAtomsWereReordered())                         // CudaDrudeTGNHKernels.cpp:344-347
+        context.calcForcesAndEnergy(true, false);
+    if (numConstraints == 0) {
+        check(tgnh_step_begin(handle, stream));             // thermostat half, rescale, kick, drift, hard wall
+        integration.computeVirtualSites();                  // :377
+        context.calcForcesAndEnergy(true, false);           // :380
+        check(tgnh_step_end(handle, stream));               // kick, thermostat half, rescale
+    }
+    else {
+        check(tgnh_step_begin_kick(handle, stream));        // :336-360
+        integration.applyConstraints(integrator.getConstraintTolerance());          // :363
+        check(tgnh_step_begin_move(handle, stream));        // :366-376
+        integration.computeVirtualSites();
+        context.calcForcesAndEnergy(true, false);
+        check(tgnh_step_end_kick(handle, stream));          // :384-388
+        integration.applyVelocityConstraints(integrator.getConstraintTolerance());  // :391
+        check(tgnh_step_end_thermo(handle, stream));        // :394-402
+    }
+    cu.setTime(cu.getTime()+integrator.getStepSize());      // :405-407
+    cu.setStepCount(cu.getStepCount()+1);
+    cu.reorderAtoms();
+}
+
+double HipIntegrateDrudeTGNHStepKernel::computeKineticEnergy(ContextImpl& context, const DrudeTGNHIntegrator& integrator, bool isKESumValid) {
+    ContextSelector selector(cu);
+    if (!isKESumValid)                                      // CudaDrudeTGNHKernels.cpp:655-656
+        return cu.getIntegrationUtilities().computeKineticEnergy(0);
+    double ke;
+    check(tgnh_get_kinetic_energy(handle, 1, (void*) cu.getCurrentStream(), &ke));
+    return ke;
+}
