@@ -66,7 +66,7 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
         it._particleTempGroup = [int(x) for x in lgroup]
     dev = torch.cuda.current_device()
     kw = {}
-    if world > 1:
+    if world > 1 or os.environ.get("TGNH_FORCE_DIST") == "1":
         def dof_sum(terms):
             t = torch.tensor(terms, dtype=torch.float64, device="cuda")
             dist.all_reduce(t)
@@ -111,6 +111,21 @@ def kernel_table(ctx):
     return rows
 
 
+def pmc_traffic(precision, slots):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE in separate runs, gfx950 correction applied; profiles/r01_pmc_traffic.json).  PMC counters
+    cannot be collected from inside this process, so the figure is the profiled one for the same workload,
+    or None when the workload differs."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        if d.get("slots") != slots:
+            return None
+        return d["kernels"][f"tile<{precision},rescale+kick+drift>"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, system, group, ngroups):
     """The CPU oracle (the restatement of the reference's algorithm, 1 thread -- the reference platform is
     single-threaded scalar code) on the same system, same mode, same harness force; a bounded number of steps."""
@@ -148,8 +163,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # TGNH_FORCE_DIST=1 exercises the sharded code path (process group, dof all-reduce, KE all-reduce hook) on one rank
+    use_dist = world > 1 or os.environ.get("TGNH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from openmm_drudenose_amd import synth, _lib
@@ -203,7 +223,9 @@ def main():
                 "step_GBps_vs_model": round(b_step / (dt / args.steps) / 1e9 / world, 1),
             },
             "roofline": {"bound": "hbm", "kernel": "tile_kernel<scale+kick+drift>", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic(args.precision, local_slots) if world == 1 else None,
+                         "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes, bytes per launch)",
                          "algorithmic_bytes_per_launch": bytes_dom, "avg_launch_us": dom["avg_us"]},
             "kernels": rows,
         }
@@ -212,7 +234,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, system, group, ngroups)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

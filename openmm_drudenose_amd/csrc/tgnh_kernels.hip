@@ -466,9 +466,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
 // (< 2^-55); larger arguments take the library exp.  The chain is one serial fp64 dependency chain per
 // thermostat, so its latency is the number of dependent operations: this keeps an exp at 6-11 of them.
 __device__ __forceinline__ double chain_exp(double x) {
-    if (x == 0.0) return 1.0;
     const double ax = fabs(x);
-    if (ax < 0.0009765625) {
+    if (__builtin_expect(ax < 0.0009765625, 1)) {                    // also x = +-0: returns exactly 1
         double p = 1.0 / 720.0;
         p = fma(p, x, 1.0 / 120.0);
         p = fma(p, x, 1.0 / 24.0);
@@ -509,6 +508,24 @@ __device__ __forceinline__ void chain_real_core(double* eta, double* etaDot, dou
     const bool live = etaMass[0] > 0;
     const double invQ0 = live ? 1.0 / etaMass[0] : 0.0;              // (KE - NkT)/Q as a multiply: <= 1 ulp from the division
     if (live) etaDotDot[0] = (ke - nkbt) * invQ0;                    // Cu :561-563
+    if constexpr (CC == 1) {
+        // One link: link 1 is the reference's dummy that "will always have etaDot = 0" (Cu :252, Ref :215), so
+        // expfac = exp(-dtc8*0) = 1 exactly and each of Cu :568-570 / :583-585 collapses to one fused multiply-add.
+        // This is the serial critical path of a whole time step: 16 dependent fp64 operations per sub-step.
+        double ed = etaDot[0], edd = etaDotDot[0], et = eta[0];
+        for (int iter = 0; iter < k.S; iter++) {
+            ed = fma(edd, k.dtc4, ed);                               // Cu :568-570 with expfac = 1
+            const double e = chain_exp(-k.dtc2 * ed);
+            scale *= e; ke *= e * e;                                 // Cu :573-574
+            et = fma(k.dtc2, ed, et);                                // Cu :575-577
+            if (live) edd = (ke - nkbt) * invQ0;                     // Cu :579-581
+            ed = fma(edd, k.dtc4, ed);                               // Cu :583-585
+        }
+        etaDot[0] = ed; etaDotDot[0] = edd; eta[0] = et;
+        *scale_out = scale;
+        *ke_out = ke;
+        return;
+    }
     for (int iter = 0; iter < k.S; iter++) {
 #pragma unroll
         for (int i = C - 1; i >= 0; i--) {                           // Cu :566-571
@@ -546,15 +563,33 @@ __device__ __forceinline__ void chain_drude_core(double* eta, double* etaDot, do
     double scale = 1.0, expfac = 1.0;
     const double invQ0 = 1.0 / etaMass[0];
     etaDotDot[0] = (ke - nkbt) * invQ0;                              // Cu :605
+    if (CC == 1 || !chains) {
+        // Only link 0 moves (Cu :607-614, :624-628, :633-641 are skipped), so expfac = exp(-dtc8*etaDot[1]) is a
+        // constant of the whole call (1 exactly when etaDot[1] = 0, the usual case).
+        expfac = chain_exp(-k.dtc8 * etaDot[1]);                     // Cu :615
+        const double ef2 = expfac * expfac, efd = expfac * k.dtc4;
+        double ed = etaDot[0], edd = etaDotDot[0], et = eta[0];
+        const bool unit = expfac == 1.0;
+        for (int iter = 0; iter < k.S; iter++) {
+            ed = unit ? fma(edd, k.dtc4, ed) : fma(ed, ef2, edd * efd);      // Cu :616-618: (ed*ef + edd*dtc4)*ef
+            const double e = chain_exp(-k.dtc2 * ed);
+            scale *= e; ke *= e * e;                                 // Cu :620-621
+            et = fma(k.dtc2, ed, et);                                // Cu :623
+            edd = (ke - nkbt) * invQ0;                               // Cu :629
+            ed = unit ? fma(edd, k.dtc4, ed) : fma(ed, ef2, edd * efd);      // Cu :630-632
+        }
+        etaDot[0] = ed; etaDotDot[0] = edd; eta[0] = et;
+        *scale_out = scale;
+        *ke_out = ke;
+        return;
+    }
     for (int iter = 0; iter < k.S; iter++) {                         // Cu :606-642
-        if (chains) {
 #pragma unroll
-            for (int i = C - 1; i > 0; i--) {
-                expfac = chain_exp(-k.dtc8 * etaDot[i + 1]);
-                etaDot[i] *= expfac;
-                etaDot[i] += etaDotDot[i] * k.dtc4;
-                etaDot[i] *= expfac;
-            }
+        for (int i = C - 1; i > 0; i--) {
+            expfac = chain_exp(-k.dtc8 * etaDot[i + 1]);
+            etaDot[i] *= expfac;
+            etaDot[i] += etaDotDot[i] * k.dtc4;
+            etaDot[i] *= expfac;
         }
         expfac = chain_exp(-k.dtc8 * etaDot[1]);
         etaDot[0] *= expfac;
@@ -562,23 +597,19 @@ __device__ __forceinline__ void chain_drude_core(double* eta, double* etaDot, do
         etaDot[0] *= expfac;
         { const double e = chain_exp(-k.dtc2 * etaDot[0]); scale *= e; ke *= e * e; }   // Cu :620-621
         eta[0] += k.dtc2 * etaDot[0];
-        if (chains) {
 #pragma unroll
-            for (int i = 1; i < C; i++) eta[i] += k.dtc2 * etaDot[i];
-        }
+        for (int i = 1; i < C; i++) eta[i] += k.dtc2 * etaDot[i];
         etaDotDot[0] = (ke - nkbt) * invQ0;
         etaDot[0] *= expfac;
         etaDot[0] += etaDotDot[0] * k.dtc4;
         etaDot[0] *= expfac;
-        if (chains) {
 #pragma unroll
-            for (int i = 1; i < C; i++) {
-                expfac = chain_exp(-k.dtc8 * etaDot[i + 1]);
-                etaDot[i] *= expfac;
-                etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - kbT) / etaMass[i];
-                etaDot[i] += etaDotDot[i] * k.dtc4;
-                etaDot[i] *= expfac;
-            }
+        for (int i = 1; i < C; i++) {
+            expfac = chain_exp(-k.dtc8 * etaDot[i + 1]);
+            etaDot[i] *= expfac;
+            etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - kbT) / etaMass[i];
+            etaDot[i] += etaDotDot[i] * k.dtc4;
+            etaDot[i] *= expfac;
         }
     }
     *scale_out = scale;
@@ -770,13 +801,18 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
     if (!a.do_chain) return;
     if (!a.do_sum) __syncthreads();
     if (L.mode == TGNH_MODE_TGNH) {
-        if (tid < NT) {
+        // real thermostats on lanes 0..NT-2 of wave 0, the Drude thermostat on lane 0 of wave 1: the two code
+        // paths then run side by side on two SIMDs instead of one after the other under one exec mask
+        int itg = -1;
+        if (tid < NT - 1) itg = tid;
+        else if (tid == 64) itg = NT - 1;
+        if (itg >= 0) {
             switch (L.C) {
-                case 1: run_tgnh<1>(a, tid, s_chain, s_ke[tid]); break;
-                case 2: run_tgnh<2>(a, tid, s_chain, s_ke[tid]); break;
-                case 3: run_tgnh<3>(a, tid, s_chain, s_ke[tid]); break;
-                case 4: run_tgnh<4>(a, tid, s_chain, s_ke[tid]); break;
-                default: run_tgnh<0>(a, tid, s_chain, s_ke[tid]); break;       // host checked NT*(4C+1) <= CHAIN_LDS_DOUBLES
+                case 1: run_tgnh<1>(a, itg, s_chain, s_ke[itg]); break;
+                case 2: run_tgnh<2>(a, itg, s_chain, s_ke[itg]); break;
+                case 3: run_tgnh<3>(a, itg, s_chain, s_ke[itg]); break;
+                case 4: run_tgnh<4>(a, itg, s_chain, s_ke[itg]); break;
+                default: run_tgnh<0>(a, itg, s_chain, s_ke[itg]); break;   // host checked NT*(4C+1) <= CHAIN_LDS_DOUBLES
             }
         }
         if (tid == 0) {                                              // Cu :493-497
@@ -807,31 +843,50 @@ __global__ __launch_bounds__(BLOCK) void force_kernel(const ForceArgs a) {
     const float4* __restrict__ pcorr = reinterpret_cast<const float4*>(a.posq_corr);
     const real4* __restrict__ x0 = reinterpret_cast<const real4*>(a.x0);      // (site x,y,z ; w = 1 if tethered)
     const mixed kd = (mixed)a.k_drude, kt = (mixed)a.k_tether;
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += gridDim.x * BLOCK) {
-        const uint32_t m = a.meta[i];
+    const int lane = threadIdx.x & 63;
+    // uniform trip count per wavefront so the shuffles below see all 64 lanes
+    const int nround = (a.n + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
+    for (int r = 0; r < nround; r++) {
+        const int i = (r * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x;
+        const bool in = i < a.n;
+        uint32_t m = 0;
+        mixed x = 0, y = 0, z = 0;
+        if (in) {
+            m = a.meta[i];
+            const real4 p = posq[i];
+            x = p.x; y = p.y; z = p.z;
+            if (PREC == TGNH_PREC_MIXED) { const float4 c = pcorr[i]; x += (mixed)c.x; y += (mixed)c.y; z += (mixed)c.z; }
+        }
         const uint32_t role = m & 3u;
-        const real4 p = posq[i];
-        mixed x = p.x, y = p.y, z = p.z;
-        if (PREC == TGNH_PREC_MIXED) { const float4 c = pcorr[i]; x += (mixed)c.x; y += (mixed)c.y; z += (mixed)c.z; }
+        const int off = (int)((m >> 10) & 2047u) - 1024;
+        // partner position: from the partner's lane when it is in this wavefront (the usual case: partners are
+        // neighbours), else one more global read
+        const int pl = lane + off;
+        const int src = (pl >= 0 && pl < 64) ? pl : lane;
+        mixed ox = __shfl(x, src, 64), oy = __shfl(y, src, 64), oz = __shfl(z, src, 64);
         mixed fx = 0, fy = 0, fz = 0;
-        if (role != ROLE_DRUDE) {                                   // tether of massive non-Drude sites
-            const real4 s = x0[i];
-            if (s.w != 0) { fx = -kt * (x - (mixed)s.x); fy = -kt * (y - (mixed)s.y); fz = -kt * (z - (mixed)s.z); }
+        if (in) {
+            if (role != ROLE_DRUDE) {                                   // tether of massive non-Drude sites
+                const real4 s = x0[i];
+                if (s.w != 0) { fx = -kt * (x - (mixed)s.x); fy = -kt * (y - (mixed)s.y); fz = -kt * (z - (mixed)s.z); }
+            }
+            if (role != ROLE_NORMAL) {                                  // Drude spring
+                if (src != pl) {
+                    const int j = i + off;
+                    const real4 q = posq[j];
+                    ox = q.x; oy = q.y; oz = q.z;
+                    if (PREC == TGNH_PREC_MIXED) { const float4 c = pcorr[j]; ox += (mixed)c.x; oy += (mixed)c.y; oz += (mixed)c.z; }
+                }
+                // separation Drude - parent; force -k sep on the Drude, +k sep on the parent
+                const bool is_d = role == ROLE_DRUDE;
+                const mixed sgn = is_d ? (mixed)-1 : (mixed)1;
+                const mixed sx = is_d ? x - ox : ox - x, sy = is_d ? y - oy : oy - y, sz = is_d ? z - oz : oz - z;
+                fx += sgn * kd * sx; fy += sgn * kd * sy; fz += sgn * kd * sz;
+            }
+            a.force[i] = (long long)(fx * (mixed)4294967296.0);
+            a.force[i + a.padded] = (long long)(fy * (mixed)4294967296.0);
+            a.force[i + 2 * a.padded] = (long long)(fz * (mixed)4294967296.0);
         }
-        if (role != ROLE_NORMAL) {                                  // Drude spring
-            const int j = i + (int)((m >> 10) & 2047u) - 1024;
-            const real4 q = posq[j];
-            mixed ox = q.x, oy = q.y, oz = q.z;
-            if (PREC == TGNH_PREC_MIXED) { const float4 c = pcorr[j]; ox += (mixed)c.x; oy += (mixed)c.y; oz += (mixed)c.z; }
-            // separation Drude - parent, force -k sep on the Drude, +k sep on the parent
-            const mixed sgn = role == ROLE_DRUDE ? (mixed)-1 : (mixed)1;
-            const mixed sx = role == ROLE_DRUDE ? x - ox : ox - x, sy = role == ROLE_DRUDE ? y - oy : oy - y,
-                        sz = role == ROLE_DRUDE ? z - oz : oz - z;
-            fx += sgn * kd * sx; fy += sgn * kd * sy; fz += sgn * kd * sz;
-        }
-        a.force[i] = (long long)(fx * (mixed)4294967296.0);
-        a.force[i + a.padded] = (long long)(fy * (mixed)4294967296.0);
-        a.force[i + 2 * a.padded] = (long long)(fz * (mixed)4294967296.0);
     }
 }
 
