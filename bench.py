@@ -41,6 +41,9 @@ def parse():
     p.add_argument("--drude-steps", type=int, default=20, help="drudeStepsPerRealStep (reference default 20)")
     p.add_argument("--hardwall", type=float, default=0.02, help="maxDrudeDistance nm (example/nacl_tg.py:22); 0 = off")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (rank 0, N=1)")
+    p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                   help="replay the step loop from a hipGraph (auto: on when sharded over >1 GPU, where launches are short)")
+    p.add_argument("--graph-steps", type=int, default=10, help="time steps per captured graph")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the extra single-precision / variant legs")
     return p.parse_args()
@@ -75,17 +78,36 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
     return HipContext(local, it, mode=args.mode, precision=precision, device=dev, flags=flags, **kw)
 
 
-def timed_run(ctx, steps, warmup, world):
+def timed_run(ctx, steps, warmup, world, graph_steps=0):
+    """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize pairs; max over ranks.
+    graph_steps > 0: the steps are replays of a hipGraph holding graph_steps steps (+ an eager remainder)."""
     import torch
     import torch.distributed as dist
     ctx.step(warmup)
     torch.cuda.synchronize()
-    ctx.timing(True)
+    replay = None
+    if graph_steps > 0:
+        try:
+            replay = ctx.capture_steps(graph_steps)
+            replay()                                   # first replay = the steps the capture recorded; untimed
+            torch.cuda.synchronize()
+        except Exception as e:                         # capture unsupported here: stay eager
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            replay = None
+            torch.cuda.synchronize()
+    ctx.graph_used = replay is not None
+    if replay is None:
+        ctx.timing(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ctx.step(steps)
+    if replay is None:
+        ctx.step(steps)
+    else:
+        for _ in range(steps // graph_steps):
+            replay()
+        ctx.step(steps % graph_steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -94,7 +116,13 @@ def timed_run(ctx, steps, warmup, world):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ctx.timing(False)
+    if replay is None:
+        ctx.timing(False)
+    else:                                              # per-kernel HIP-event timing needs eager launches: a short extra leg
+        ctx.timing(True)
+        ctx.step(min(steps, 50))
+        torch.cuda.synchronize()
+        ctx.timing(False)
     return dt
 
 
@@ -153,6 +181,12 @@ def cpu_baseline(args, system, group, ngroups):
 
 def main():
     args = parse()
+    # Exactly ONE line may reach stdout (the JSON).  Libraries print there too (RCCL writes its version banner to
+    # stdout at communicator creation), so fd 1 is pointed at stderr for the whole run and the JSON goes to a
+    # private duplicate of the original stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,7 +210,9 @@ def main():
     system, group, ngroups = synth.water_box(args.molecules)
 
     ctx = build_context(args, system, group, ngroups, rank, world, args.precision, args.variant)
-    dt = timed_run(ctx, args.steps, args.warmup, world)
+    use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
+    dt = timed_run(ctx, args.steps, args.warmup, world, args.graph_steps if use_graph else 0)
+    graph_used = ctx.graph_used
     rows = kernel_table(ctx)
     assert ctx.check() == 0
     # dominant kernel: the fused rescale + half kick + drift (+ hard wall) pass
@@ -216,7 +252,7 @@ def main():
                             f"{system.num_pairs} Drude pairs, 1 temperature group (+ molecular-COM and Drude thermostats), "
                             f"{args.mode} mode, {args.precision} precision, numNHChains={args.chains}, hard wall "
                             f"{args.hardwall} nm, harness force call-out inside the timed region",
-                "precision": args.precision, "variant": args.variant,
+                "precision": args.precision, "variant": args.variant, "hipgraph": graph_used,
                 "parallelism": f"particle-sharded x{world} (whole molecules), KE all-reduce per thermostat half step",
                 "slots_per_gpu": local_slots,
                 "model_bytes_per_step": b_step,
@@ -233,7 +269,7 @@ def main():
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, system, group, ngroups)
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -145,6 +145,9 @@ tgnh_status tgnh_step_end_thermo(tgnh_handle h, void* stream);
 /* Apply any rescale still pending (TGNH_FLAG_DEFER_SCALE) so velm is the
  * reference's end-of-step state; call before anything else reads velm. */
 tgnh_status tgnh_flush(tgnh_handle h, void* stream);
+/* A caller that captured `nsteps` steps into a hipGraph and replays it tells the handle here: the host-side
+ * clock and step count advance only when the step functions are called, not when a graph is replayed. */
+tgnh_status tgnh_note_replayed_steps(tgnh_handle h, int nsteps);
 /* Velocities were changed behind the integrator's back (setVelocities, CMMotionRemover,
  * barostat): cached kinetic energies are stale.  DrudeTGNHIntegrator.cpp:166-170 */
 tgnh_status tgnh_state_changed(tgnh_handle h);

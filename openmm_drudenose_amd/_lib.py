@@ -57,6 +57,7 @@ SIGNATURES = {
     "tgnh_step_end_thermo": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_flush": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_state_changed": (C.c_int, [C.c_void_p]),
+    "tgnh_note_replayed_steps": (C.c_int, [C.c_void_p, C.c_int]),
     "tgnh_get_kinetic_energy": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, c_f64p]),
     "tgnh_get_num_thermostats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "tgnh_get_last_kinetic_energies": (C.c_int, [C.c_void_p, C.c_void_p, c_f64p]),

@@ -659,6 +659,14 @@ extern "C" tgnh_status tgnh_flush(tgnh_handle h, void* stream) {
     return TGNH_OK;
 }
 
+extern "C" tgnh_status tgnh_note_replayed_steps(tgnh_handle h, int nsteps) {
+    CHECK_H(h);
+    if (nsteps < 0) return fail(TGNH_ERR_ARG, "negative step count");
+    h->time += h->d.step_size * nsteps;
+    h->step_count += nsteps;
+    return TGNH_OK;
+}
+
 extern "C" tgnh_status tgnh_state_changed(tgnh_handle h) {
     CHECK_H(h);
     tgnh_status rc = deferred_guard(h, "tgnh_state_changed"); if (rc) return rc;

@@ -437,6 +437,31 @@ class HipContext(_HandleQueries):
             self.compute_forces()
             self.step_end()
 
+    def capture_steps(self, steps):
+        """Captures `steps` time steps (harness force call-out included, and the KE all-reduce when sharded) into
+        a hipGraph on a side stream and returns a callable that replays it.  The step sequence must be in its
+        steady state (at least one step taken) and must not change afterwards (no setters)."""
+        torch = self.torch
+        if self.force_fn is not None:
+            raise TgnhError(_lib.ERR_STATE, "capture_steps supports the harness force call-out only")
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            _check(self.lib.tgnh_run_harness(self.h, self.x0.data_ptr(), self.k_drude, self.k_tether, int(steps), self._stream()))
+        # the capture itself advanced the host-side counters once without running anything: take that back
+        _check(self.lib.tgnh_note_replayed_steps(self.h, 0))
+        self._captured_not_run = int(steps)
+
+        def replay():
+            g.replay()
+            if self._captured_not_run:
+                self._captured_not_run = 0          # first replay is the run the capture already counted
+            else:
+                _check(self.lib.tgnh_note_replayed_steps(self.h, int(steps)))
+            self.ke_sum_valid = True
+        replay.graph = g
+        return replay
+
     def check(self):
         """Raises if the device flagged a Drude beyond 2x the hard wall (dualNH mode, Ref :311-312)."""
         flags = C.c_uint32()

@@ -302,6 +302,23 @@ def test_100_step_parity_deferred_rescale(mode, precision):
     ctx.close()
 
 
+@pytest.mark.parametrize("flags", [0, FLAG_DEFER_SCALE])
+def test_graph_replay_matches_eager(flags):
+    """hipGraph capture of the step loop (HipContext.capture_steps) replays the very same launches: bitwise equal."""
+    ref = make("mixed", "TGNH", "mixed", flags=flags, hardwall=0.02)
+    alt = make("mixed", "TGNH", "mixed", flags=flags, hardwall=0.02)
+    ref[4].step(3 + 4 * 5)
+    alt[4].step(3)
+    replay = alt[4].capture_steps(5)
+    for _ in range(4):
+        replay()
+    assert np.array_equal(alt[4].getPositions(), ref[4].getPositions())
+    assert np.array_equal(alt[4].getVelocities(), ref[4].getVelocities())
+    assert alt[4].time()[1] == ref[4].time()[1] == 23
+    assert np.array_equal(alt[4].thermostat_state(1), ref[4].thermostat_state(1))
+    ref[4].close(); alt[4].close()
+
+
 def test_split_constraint_path_matches_fused():
     """begin_kick / begin_move / end_kick / end_thermo (the posDelta path around OpenMM's constraint
     call-outs, Cu :356-369, :384-402) with no constraints applied equals the fused step."""
