@@ -191,7 +191,8 @@ tgnh_status tgnh_run_harness(tgnh_handle h, const void* x0, double k_drude, doub
 
 /* Per-kernel launch statistics gathered with HIP events on `stream` while
  * enabled (bench.py's live roofline).  kernel: 0 scale+kick+drift, 1 kick+KE,
- * 2 rescale(+KE), 3 KE, 4 chain, 5 harness force. */
+ * 2 rescale(+KE), 3 KE, 4 chain, 5 harness force.  on = 1: every kernel; on = 2 + k: kernel k only
+ * (two event records per step instead of eight, for timing inside a throughput measurement); 0: off. */
 tgnh_status tgnh_timing_enable(tgnh_handle h, int on);
 tgnh_status tgnh_timing_read(tgnh_handle h, int kernel, double* total_ms, int64_t* launches);
 /* Algorithmic HBM bytes of one launch of `kernel` (SURVEY.md 8d model: state arrays only). */

@@ -485,6 +485,7 @@ struct Timed {
     tgnh_context* c; hipStream_t s; int kid; tgnh_context::Ev* ev = nullptr;
     Timed(tgnh_context* c_, hipStream_t s_, int kid_) : c(c_), s(s_), kid(kid_) {
         if (!c->timing) return;
+        if (c->timing_only >= 0 && kid != c->timing_only) return;
         if (c->ev_used == c->ev_pool.size()) {
             tgnh_context::Ev e; e.kid = kid;
             if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
@@ -866,6 +867,7 @@ extern "C" tgnh_status tgnh_timing_enable(tgnh_handle h, int on) {
     if (!on) drain_events(h);
     else { for (int k = 0; k < KID_COUNT; k++) { h->t_total[k] = 0; h->t_count[k] = 0; } h->ev_used = 0; }
     h->timing = on != 0;
+    h->timing_only = on >= 2 ? on - 2 : -1;   // on = 2 + kernel id: time that kernel only (2 events per step, not 8)
     return TGNH_OK;
 }
 extern "C" tgnh_status tgnh_timing_read(tgnh_handle h, int kernel, double* total_ms, int64_t* launches) {

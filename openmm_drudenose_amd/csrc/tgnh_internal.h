@@ -170,6 +170,7 @@ struct tgnh_context {
     void* allreduce_user = nullptr;
     // timing
     bool timing = false;
+    int timing_only = -1;             // >= 0: only this kernel id is timed
     struct Ev { hipEvent_t a, b; int kid; };
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;

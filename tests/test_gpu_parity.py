@@ -383,6 +383,34 @@ def test_setters_take_effect_mid_run():
 
 
 # ---------------------------------------------------------------------------
+# BASELINE.json configs at their stated sizes (parity-test cases)
+# ---------------------------------------------------------------------------
+CONFIGS = {
+    # name: (builder, mode, hardwall, steps)   -- steps are fewer where the single-thread oracle is slow
+    "C2 SWM4 32k atoms, 1 group": (lambda: synth.water_box(6400), 0.0, 100),
+    "C3 ionic liquid 100k atoms, 2 groups": (lambda: synth.ionic_liquid(2222), 0.0, 100),
+    "C4 mixed 500k atoms, 4 groups, hard wall": (lambda: synth.mixed(60000, 4444), 0.02, 50),
+    "C5 SWM4 2M atoms": (lambda: synth.water_box(400000), 0.0, 20),
+}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_config_sizes_parity(name):
+    build, hardwall, nsteps = CONFIGS[name]
+    s, g, ng = build()
+    it = integ(chains=1, hardwall=hardwall)
+    bind_groups(it, g, ng)
+    ctx = HipContext(s, it, mode="TGNH", precision="mixed", flags=FLAG_DEFER_SCALE)
+    o = make_oracle(s, g, ng, "TGNH", it)
+    pos_o, vel_o = oracle_run(o, s, nsteps, x0=ctx.sites())
+    ctx.step(nsteps)
+    ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
+    print(f"{name}: N={s.num_particles} P={s.num_pairs} G={ng} steps={nsteps} pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= TOL and ev <= TOL and ctx.check() == 0
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------
 # full size (BASELINE.json metric: 1 M Drude pairs): size-independent properties
 # ---------------------------------------------------------------------------
 def test_full_size_properties():

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""GPU-side: steps/s of the BASELINE.json configs on ONE MI355X (C4/C5 are multi-GPU configs; their 1-GPU rate
+is what can be measured on a 1-GPU box).  Prints a markdown table for BASELINE.md section 5."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from openmm_drudenose_amd import synth, DrudeTGNHIntegrator, HipContext, _lib
+from openmm_drudenose_amd.drudetgnhplugin import FLAG_DEFER_SCALE
+CFG = [("C1 nacl", synth.nacl, 0.02), ("C2 SWM4 32k", lambda: synth.water_box(6400), 0.0),
+       ("C3 ionic liquid 100k", lambda: synth.ionic_liquid(2222), 0.0),
+       ("C4 mixed 500k + hard wall", lambda: synth.mixed(60000, 4444), 0.02),
+       ("C5 SWM4 2M", lambda: synth.water_box(400000), 0.0), ("metric SWM4 1M pairs", lambda: synth.water_box(1000000), 0.02)]
+print("| config | N slots | pairs | groups | precision | steps/s eager | steps/s hipGraph | B_step model | GB/s vs model |")
+print("|---|---|---|---|---|---|---|---|---|")
+for name, build, hw in CFG:
+    s, g, ng = build()
+    for prec in ("mixed", "single"):
+        it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, 1, True, True)
+        it.setMaxDrudeDistance(hw)
+        for _ in range(ng): it.addTempGroup()
+        it._particleTempGroup = [int(x) for x in g]
+        ctx = HipContext(s, it, mode="TGNH", precision=prec, flags=FLAG_DEFER_SCALE)
+        ctx.step(50); torch.cuda.synchronize()
+        n = 500
+        t0 = time.perf_counter(); ctx.step(n); torch.cuda.synchronize(); eager = n / (time.perf_counter() - t0)
+        rep = ctx.capture_steps(10); rep(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n // 10): rep()
+        torch.cuda.synchronize(); graph = n / (time.perf_counter() - t0)
+        V = 16 if prec == "single" else 32
+        b = s.num_particles * (7 * V + 48 + 2 * V)
+        print(f"| {name} | {s.num_particles} | {s.num_pairs} | {ng} | {prec} | {eager:.0f} | {graph:.0f} | {b/1e6:.1f} MB | {b*max(eager,graph)/1e9:.0f} |", flush=True)
+        ctx.close()
