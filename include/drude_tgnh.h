@@ -157,7 +157,7 @@ tgnh_status tgnh_get_kinetic_energy(tgnh_handle h, int ke_sum_valid, void* strea
 tgnh_status tgnh_get_num_thermostats(tgnh_handle h, int* count);               /* NT: TGNH G+2 = [groups.., COM, Drude]; DUALNH 3 = [real, unused, Drude] */
 tgnh_status tgnh_get_last_kinetic_energies(tgnh_handle h, void* stream, double* ke);   /* no 1/2; before the chain */
 tgnh_status tgnh_get_last_scale_factors(tgnh_handle h, void* stream, double* scale);
-tgnh_status tgnh_get_status_flags(tgnh_handle h, void* stream, uint32_t* flags);   /* bit0: Drude beyond 2x hard wall */
+tgnh_status tgnh_get_status_flags(tgnh_handle h, void* stream, uint32_t* flags);   /* bit0: Drude beyond 2x hard wall; bit1: harness SHAKE did not converge */
 tgnh_status tgnh_get_time(tgnh_handle h, double* time, int64_t* step_count);
 tgnh_status tgnh_get_dof(tgnh_handle h, double* dof, double* nkt);
 
@@ -188,6 +188,19 @@ tgnh_status tgnh_harness_force(tgnh_handle h, const void* x0, double k_drude, do
  * enqueued back to back with no host synchronisation. */
 tgnh_status tgnh_run_harness(tgnh_handle h, const void* x0, double k_drude, double k_tether,
                              int nsteps, void* stream);
+
+/* Harness call-outs of the constrained (split) path -- stand-ins for OpenMM's applyConstraints /
+ * applyVelocityConstraints / computeVirtualSites (CudaDrudeTGNHKernels.cpp:363, :391, :377), not part of the reference.
+ * Clusters: [n][4] slot indices (-1 = unused) and [n][6] distances for the pairs (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+ * of a cluster, 0 = unconstrained.  Virtual sites: [n][4] = (site, p1, p2, p3), [n][3] weights (three-particle average). */
+tgnh_status tgnh_harness_set_clusters(tgnh_handle h, int n, const int32_t* atoms, const double* dist);
+tgnh_status tgnh_harness_shake_positions(tgnh_handle h, double tol, void* stream);    /* SHAKE on posDelta */
+tgnh_status tgnh_harness_shake_velocities(tgnh_handle h, double tol, void* stream);   /* velocity stage on velm */
+tgnh_status tgnh_harness_set_virtual_sites(tgnh_handle h, int n, const int32_t* atoms, const double* weights);
+tgnh_status tgnh_harness_virtual_sites(tgnh_handle h, void* stream);
+/* nsteps x { begin_kick, SHAKE, begin_move, virtual sites, harness force, end_kick, [TGNH: velocity stage], end_thermo } */
+tgnh_status tgnh_run_harness_constrained(tgnh_handle h, const void* x0, double k_drude, double k_tether,
+                                         double tol, int nsteps, void* stream);
 
 /* Per-kernel launch statistics gathered with HIP events on `stream` while
  * enabled (bench.py's live roofline).  kernel: 0 scale+kick+drift, 1 kick+KE,

@@ -74,6 +74,12 @@ SIGNATURES = {
     "tgnh_half_kick": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_harness_force": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "tgnh_run_harness": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p]),
+    "tgnh_harness_set_clusters": (C.c_int, [C.c_void_p, C.c_int, c_i32p, c_f64p]),
+    "tgnh_harness_shake_positions": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
+    "tgnh_harness_shake_velocities": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
+    "tgnh_harness_set_virtual_sites": (C.c_int, [C.c_void_p, C.c_int, c_i32p, c_f64p]),
+    "tgnh_harness_virtual_sites": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tgnh_run_harness_constrained": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "tgnh_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "tgnh_timing_read": (C.c_int, [C.c_void_p, C.c_int, c_f64p, C.POINTER(C.c_int64)]),
     "tgnh_algorithmic_bytes": (C.c_int, [C.c_void_p, C.c_int, c_f64p]),
@@ -93,6 +99,8 @@ def load():
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the integrator path.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("TGNH_LIB") and not hasattr(lib, name):
+            continue                # older tuning build selected with TGNH_LIB: tolerate symbols it predates
         fn = getattr(lib, name)     # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdrudetgnh_hip.so")
-SOURCES = ["tgnh_host.cpp", "tgnh_kernels.hip"]
+SOURCES = ["tgnh_host.cpp", "tgnh_kernels.hip", "tgnh_harness.hip"]
 HEADERS = ["tgnh_internal.h", os.path.join("..", "..", "include", "drude_tgnh.h")]
 ARCH = "gfx950"
 

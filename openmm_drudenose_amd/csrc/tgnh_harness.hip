@@ -1,0 +1,275 @@
+// tgnh_harness.hip -- harness call-outs of the constrained path: SHAKE on posDelta, the velocity stage,
+// three-particle-average virtual sites.  NOT part of the reference's plugin: it delegates all three to OpenMM
+// (Cu :363 applyConstraints, :391 applyVelocityConstraints, :377 computeVirtualSites; Ref :268, :373).
+// They exist so that the split step path (tgnh_step_begin_kick / _move / _end_kick / _end_thermo) can be
+// exercised and measured with real constraint corrections, the way the harness force stands in for
+// calcForcesAndEnergy.  The oracle carries the same algorithms in fp64 (oracle/tgnh_oracle.c).
+//
+// Constraint cluster: up to 4 atoms and the 6 possible distances among them in the fixed order
+// (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); distance 0 = no constraint.  One lane per cluster, SHAKE sweeps in that
+// order until every |d^2 - r^2| <= 2 tol d^2 -- everything in registers, static indices.
+#include "tgnh_internal.h"
+
+namespace tgnh {
+
+template <int PREC> struct HPrec;
+template <> struct HPrec<TGNH_PREC_SINGLE> { typedef float real; typedef float mixed; typedef float4 real4; typedef float4 mixed4; };
+template <> struct HPrec<TGNH_PREC_MIXED>  { typedef float real; typedef double mixed; typedef float4 real4; typedef double4 mixed4; };
+template <> struct HPrec<TGNH_PREC_DOUBLE> { typedef double real; typedef double mixed; typedef double4 real4; typedef double4 mixed4; };
+
+struct ClusterArgs {
+    const int4* atoms;        // [n] slot indices, -1 = unused
+    const double* dist;       // [n][6]
+    int n;
+    const void* posq; const void* posq_corr;
+    void* velm; void* pos_delta;
+    double tol;
+    uint32_t* status;         // bit1: SHAKE did not converge
+};
+
+constexpr int SHAKE_MAX_ITER = 500;
+__device__ constexpr int PA[6] = {0, 0, 0, 1, 1, 2};
+__device__ constexpr int PB[6] = {1, 2, 3, 2, 3, 3};
+
+template <int PREC, bool VELOCITY>
+__global__ __launch_bounds__(BLOCK) void shake_kernel(const ClusterArgs a) {
+    typedef typename HPrec<PREC>::real4 real4;
+    typedef typename HPrec<PREC>::mixed mixed;
+    typedef typename HPrec<PREC>::mixed4 mixed4;
+    const real4* __restrict__ posq = reinterpret_cast<const real4*>(a.posq);
+    const float4* __restrict__ pcorr = reinterpret_cast<const float4*>(a.posq_corr);
+    mixed4* __restrict__ velm = reinterpret_cast<mixed4*>(a.velm);
+    mixed4* __restrict__ pdelta = reinterpret_cast<mixed4*>(a.pos_delta);
+    const mixed tol = (mixed)a.tol;
+    for (int c = blockIdx.x * BLOCK + threadIdx.x; c < a.n; c += gridDim.x * BLOCK) {
+        const int4 at4 = a.atoms[c];
+        const int at[4] = {at4.x, at4.y, at4.z, at4.w};
+        mixed x[4][3], q[4][3], w[4];         // positions, the corrected quantity (delta or velocity), inverse masses
+        mixed4 keep[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            w[k] = 0;
+#pragma unroll
+            for (int j = 0; j < 3; j++) { x[k][j] = 0; q[k][j] = 0; }
+            if (at[k] >= 0) {
+                const real4 p = posq[at[k]];
+                x[k][0] = p.x; x[k][1] = p.y; x[k][2] = p.z;
+                if (PREC == TGNH_PREC_MIXED) { const float4 cc = pcorr[at[k]]; x[k][0] += (mixed)cc.x; x[k][1] += (mixed)cc.y; x[k][2] += (mixed)cc.z; }
+                const mixed4 v = velm[at[k]];
+                w[k] = v.w;
+                if (VELOCITY) { keep[k] = v; q[k][0] = v.x; q[k][1] = v.y; q[k][2] = v.z; }
+                else { keep[k] = pdelta[at[k]]; q[k][0] = keep[k].x; q[k][1] = keep[k].y; q[k][2] = keep[k].z; }
+            }
+        }
+        mixed d2[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { const mixed d = (mixed)a.dist[(size_t)c * 6 + k]; d2[k] = d * d; }
+        bool converged = false;
+        int iter = 0;
+        while (!converged && iter++ < SHAKE_MAX_ITER) {
+            converged = true;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                if (d2[k] > 0) {
+                    const int i = PA[k], j = PB[k];
+                    const mixed rx = x[i][0] - x[j][0], ry = x[i][1] - x[j][1], rz = x[i][2] - x[j][2];
+                    if (VELOCITY) {
+                        const mixed vx = q[i][0] - q[j][0], vy = q[i][1] - q[j][1], vz = q[i][2] - q[j][2];
+                        const mixed r2 = rx * rx + ry * ry + rz * rz, rv = rx * vx + ry * vy + rz * vz;
+                        const mixed g = rv / (r2 * (w[i] + w[j]));
+                        if ((g < 0 ? -g : g) * (w[i] + w[j]) > tol) {
+                            converged = false;
+                            q[i][0] -= g * w[i] * rx; q[i][1] -= g * w[i] * ry; q[i][2] -= g * w[i] * rz;
+                            q[j][0] += g * w[j] * rx; q[j][1] += g * w[j] * ry; q[j][2] += g * w[j] * rz;
+                        }
+                    } else {
+                        const mixed sx = rx + (q[i][0] - q[j][0]), sy = ry + (q[i][1] - q[j][1]), sz = rz + (q[i][2] - q[j][2]);
+                        const mixed diff = d2[k] - (sx * sx + sy * sy + sz * sz);
+                        if ((diff < 0 ? -diff : diff) > 2 * tol * d2[k]) {
+                            converged = false;
+                            const mixed g = diff / (2 * (rx * sx + ry * sy + rz * sz) * (w[i] + w[j]));
+                            q[i][0] += g * w[i] * rx; q[i][1] += g * w[i] * ry; q[i][2] += g * w[i] * rz;
+                            q[j][0] -= g * w[j] * rx; q[j][1] -= g * w[j] * ry; q[j][2] -= g * w[j] * rz;
+                        }
+                    }
+                }
+            }
+        }
+        if (!converged) atomicOr(a.status, 2u);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (at[k] >= 0) {
+                mixed4 o = keep[k];
+                o.x = q[k][0]; o.y = q[k][1]; o.z = q[k][2];
+                if (VELOCITY) velm[at[k]] = o; else pdelta[at[k]] = o;
+            }
+        }
+    }
+}
+
+struct SiteArgs {
+    const int4* atoms;        // [n] (site, p1, p2, p3)
+    const double* w;          // [n][3]
+    int n;
+    void* posq; void* posq_corr;
+};
+
+template <int PREC>
+__global__ __launch_bounds__(BLOCK) void site_kernel(const SiteArgs a) {
+    typedef typename HPrec<PREC>::real real;
+    typedef typename HPrec<PREC>::real4 real4;
+    typedef typename HPrec<PREC>::mixed mixed;
+    real4* __restrict__ posq = reinterpret_cast<real4*>(a.posq);
+    float4* __restrict__ pcorr = reinterpret_cast<float4*>(a.posq_corr);
+    for (int k = blockIdx.x * BLOCK + threadIdx.x; k < a.n; k += gridDim.x * BLOCK) {
+        const int4 at = a.atoms[k];
+        const int src[3] = {at.y, at.z, at.w};
+        mixed s[3] = {0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            const real4 p = posq[src[m]];
+            mixed x = p.x, y = p.y, z = p.z;
+            if (PREC == TGNH_PREC_MIXED) { const float4 c = pcorr[src[m]]; x += (mixed)c.x; y += (mixed)c.y; z += (mixed)c.z; }
+            const mixed wm = (mixed)a.w[(size_t)k * 3 + m];
+            s[0] += wm * x; s[1] += wm * y; s[2] += wm * z;
+        }
+        real4 o = posq[at.x];
+        if (PREC == TGNH_PREC_MIXED) {
+            const float hx = (float)s[0], hy = (float)s[1], hz = (float)s[2];
+            o.x = hx; o.y = hy; o.z = hz;
+            pcorr[at.x] = make_float4((float)(s[0] - hx), (float)(s[1] - hy), (float)(s[2] - hz), 0.0f);
+        } else {
+            o.x = (real)s[0]; o.y = (real)s[1]; o.z = (real)s[2];
+        }
+        posq[at.x] = o;
+    }
+}
+
+static int grid_of(int n) { int g = (n + BLOCK - 1) / BLOCK; return g < 1 ? 1 : (g > 2048 ? 2048 : g); }
+
+template <bool VEL>
+static hipError_t launch_shake(int precision, const ClusterArgs& a, hipStream_t s) {
+    const int g = grid_of(a.n);
+    switch (precision) {
+        case TGNH_PREC_SINGLE: hipLaunchKernelGGL((shake_kernel<TGNH_PREC_SINGLE, VEL>), dim3(g), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_MIXED: hipLaunchKernelGGL((shake_kernel<TGNH_PREC_MIXED, VEL>), dim3(g), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_DOUBLE: hipLaunchKernelGGL((shake_kernel<TGNH_PREC_DOUBLE, VEL>), dim3(g), dim3(BLOCK), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+static hipError_t launch_sites(int precision, const SiteArgs& a, hipStream_t s) {
+    const int g = grid_of(a.n);
+    switch (precision) {
+        case TGNH_PREC_SINGLE: hipLaunchKernelGGL((site_kernel<TGNH_PREC_SINGLE>), dim3(g), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_MIXED: hipLaunchKernelGGL((site_kernel<TGNH_PREC_MIXED>), dim3(g), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_DOUBLE: hipLaunchKernelGGL((site_kernel<TGNH_PREC_DOUBLE>), dim3(g), dim3(BLOCK), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace tgnh
+
+using namespace tgnh;
+
+#define H_FAIL(code, msg) do { tgnh_set_error(msg); return code; } while (0)
+#define H_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { tgnh_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return TGNH_ERR_HIP; } } while (0)
+
+static tgnh_status harness_ready(tgnh_handle h) {
+    if (!h) H_FAIL(TGNH_ERR_ARG, "null handle");
+    if (h->host_only) H_FAIL(TGNH_ERR_STATE, "host-only handle (device -1): no GPU work can be launched on it");
+    if (!h->velm) H_FAIL(TGNH_ERR_STATE, "tgnh_bind_buffers has not been called");
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_harness_set_clusters(tgnh_handle h, int n, const int32_t* atoms, const double* dist) {
+    if (!h) H_FAIL(TGNH_ERR_ARG, "null handle");
+    if (h->host_only) H_FAIL(TGNH_ERR_STATE, "host-only handle");
+    if (n < 0 || (n > 0 && (!atoms || !dist))) H_FAIL(TGNH_ERR_ARG, "bad cluster arrays");
+    for (int i = 0; i < 4 * n; i++)
+        if (atoms[i] < -1 || atoms[i] >= h->d.num_particles) H_FAIL(TGNH_ERR_ARG, "cluster atom index out of range");
+    H_HIP(hipSetDevice(h->device));
+    if (h->d_cl_atoms) { (void)hipFree(h->d_cl_atoms); h->d_cl_atoms = nullptr; }
+    if (h->d_cl_dist) { (void)hipFree(h->d_cl_dist); h->d_cl_dist = nullptr; }
+    h->num_clusters = n;
+    if (n == 0) return TGNH_OK;
+    H_HIP(hipMalloc(&h->d_cl_atoms, sizeof(int4) * n));
+    H_HIP(hipMemcpy(h->d_cl_atoms, atoms, sizeof(int4) * n, hipMemcpyHostToDevice));
+    H_HIP(hipMalloc(&h->d_cl_dist, sizeof(double) * 6 * n));
+    H_HIP(hipMemcpy(h->d_cl_dist, dist, sizeof(double) * 6 * n, hipMemcpyHostToDevice));
+    return TGNH_OK;
+}
+
+static ClusterArgs cluster_args(tgnh_handle h, double tol) {
+    ClusterArgs a{};
+    a.atoms = h->d_cl_atoms; a.dist = h->d_cl_dist; a.n = h->num_clusters;
+    a.posq = h->posq; a.posq_corr = h->posq_corr; a.velm = h->velm; a.pos_delta = h->pos_delta;
+    a.tol = tol; a.status = h->d_status;
+    return a;
+}
+
+extern "C" tgnh_status tgnh_harness_shake_positions(tgnh_handle h, double tol, void* stream) {
+    tgnh_status rc = harness_ready(h); if (rc) return rc;
+    if (!h->pos_delta) H_FAIL(TGNH_ERR_STATE, "posDelta buffer not bound");
+    if (h->num_clusters == 0) return TGNH_OK;
+    H_HIP(hipSetDevice(h->device));
+    H_HIP(launch_shake<false>(h->d.precision, cluster_args(h, tol), (hipStream_t)stream));
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_harness_shake_velocities(tgnh_handle h, double tol, void* stream) {
+    tgnh_status rc = harness_ready(h); if (rc) return rc;
+    if (h->num_clusters == 0) return TGNH_OK;
+    H_HIP(hipSetDevice(h->device));
+    H_HIP(launch_shake<true>(h->d.precision, cluster_args(h, tol), (hipStream_t)stream));
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_harness_set_virtual_sites(tgnh_handle h, int n, const int32_t* atoms, const double* weights) {
+    if (!h) H_FAIL(TGNH_ERR_ARG, "null handle");
+    if (h->host_only) H_FAIL(TGNH_ERR_STATE, "host-only handle");
+    if (n < 0 || (n > 0 && (!atoms || !weights))) H_FAIL(TGNH_ERR_ARG, "bad virtual-site arrays");
+    for (int i = 0; i < 4 * n; i++)
+        if (atoms[i] < 0 || atoms[i] >= h->d.num_particles) H_FAIL(TGNH_ERR_ARG, "virtual-site atom index out of range");
+    H_HIP(hipSetDevice(h->device));
+    if (h->d_vs_atoms) { (void)hipFree(h->d_vs_atoms); h->d_vs_atoms = nullptr; }
+    if (h->d_vs_w) { (void)hipFree(h->d_vs_w); h->d_vs_w = nullptr; }
+    h->num_sites = n;
+    if (n == 0) return TGNH_OK;
+    H_HIP(hipMalloc(&h->d_vs_atoms, sizeof(int4) * n));
+    H_HIP(hipMemcpy(h->d_vs_atoms, atoms, sizeof(int4) * n, hipMemcpyHostToDevice));
+    H_HIP(hipMalloc(&h->d_vs_w, sizeof(double) * 3 * n));
+    H_HIP(hipMemcpy(h->d_vs_w, weights, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_harness_virtual_sites(tgnh_handle h, void* stream) {
+    tgnh_status rc = harness_ready(h); if (rc) return rc;
+    if (h->num_sites == 0) return TGNH_OK;
+    H_HIP(hipSetDevice(h->device));
+    SiteArgs a{};
+    a.atoms = h->d_vs_atoms; a.w = h->d_vs_w; a.n = h->num_sites; a.posq = h->posq; a.posq_corr = h->posq_corr;
+    H_HIP(launch_sites(h->d.precision, a, (hipStream_t)stream));
+    return TGNH_OK;
+}
+
+// nsteps x the constrained step (Cu :336-406) with the harness call-outs in OpenMM's places
+extern "C" tgnh_status tgnh_run_harness_constrained(tgnh_handle h, const void* x0, double k_drude, double k_tether,
+                                                    double tol, int nsteps, void* stream) {
+    tgnh_status rc = harness_ready(h); if (rc) return rc;
+    for (int i = 0; i < nsteps; i++) {
+        rc = tgnh_step_begin_kick(h, stream); if (rc) return rc;                         // Cu :336-360
+        rc = tgnh_harness_shake_positions(h, tol, stream); if (rc) return rc;            // Cu :363 call-out
+        rc = tgnh_step_begin_move(h, stream); if (rc) return rc;                         // Cu :366-376
+        rc = tgnh_harness_virtual_sites(h, stream); if (rc) return rc;                   // Cu :377 call-out
+        rc = tgnh_harness_force(h, x0, k_drude, k_tether, const_cast<void*>(h->force), stream); if (rc) return rc;   // Cu :380 call-out
+        rc = tgnh_step_end_kick(h, stream); if (rc) return rc;                           // Cu :384-388
+        if (h->d.mode == TGNH_MODE_TGNH) {                                               // Cu :391 call-out (the Reference platform has none)
+            rc = tgnh_harness_shake_velocities(h, tol, stream); if (rc) return rc;
+        }
+        rc = tgnh_step_end_thermo(h, stream); if (rc) return rc;                         // Cu :394-406
+    }
+    return TGNH_OK;
+}

@@ -20,6 +20,8 @@ static thread_local std::string g_err;
 extern "C" const char* tgnh_last_error(void) { return g_err.c_str(); }
 extern "C" int tgnh_abi_version(void) { return TGNH_ABI_VERSION; }
 
+void tgnh_set_error(const std::string& msg) { g_err = msg; }
+
 static tgnh_status fail(tgnh_status code, const std::string& msg) {
     g_err = msg;
     return code;
@@ -330,6 +332,10 @@ static void free_device(tgnh_context* c) {
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_scalar) (void)hipFree(c->d_scalar);
+    if (c->d_cl_atoms) (void)hipFree(c->d_cl_atoms);
+    if (c->d_cl_dist) (void)hipFree(c->d_cl_dist);
+    if (c->d_vs_atoms) (void)hipFree(c->d_vs_atoms);
+    if (c->d_vs_w) (void)hipFree(c->d_vs_w);
     for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     c->ev_pool.clear();
 }

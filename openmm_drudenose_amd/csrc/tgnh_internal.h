@@ -23,9 +23,13 @@ namespace tgnh {
 #ifndef TGNH_PREFETCH
 #define TGNH_PREFETCH 0   // software prefetch of the next tile: measured slower on MI355X (profiles/r01_tuning.md)
 #endif
-constexpr int BLOCK = 256;
+#ifndef TGNH_TBLOCK
+#define TGNH_TBLOCK 256
+#endif
+constexpr int BLOCK = 256;                  // chain / force / plain-KE kernels
+constexpr int TBLOCK = TGNH_TBLOCK;          // tile kernel work-group size
 constexpr int SPT = TGNH_SPT;                // slots per thread
-constexpr int TILE_SLOTS = BLOCK * SPT;      // 512 at SPT = 2
+constexpr int TILE_SLOTS = TBLOCK * SPT;      // 512 at SPT = 2
 constexpr int TILE_RES = TILE_SLOTS / 2;     // residues per tile the LDS COM table holds
 constexpr int GRID_CAP = 2048;               // upper bound of the persistent grid (256 CUs x 8 work-groups)
 constexpr int MAX_GROUPS = 8;                // per-thread KE bins are registers (GB template 1/4/8)
@@ -129,6 +133,8 @@ size_t tile_lds_bytes(int precision, int ops, bool hardwall, bool use_com);
 
 }  // namespace tgnh
 
+void tgnh_set_error(const std::string& msg);   // sets what tgnh_last_error() returns (tgnh_host.cpp)
+
 struct tgnh_context {
     tgnh_desc d;                      // scalars only; pointers are nulled after create
     int device = 0;
@@ -154,6 +160,9 @@ struct tgnh_context {
     double* d_state = nullptr;        // thermostat block
     uint32_t* d_status = nullptr;
     double* d_scalar = nullptr;       // plain KE result
+    // harness call-outs (tgnh_harness.hip)
+    int4* d_cl_atoms = nullptr; double* d_cl_dist = nullptr; int num_clusters = 0;
+    int4* d_vs_atoms = nullptr; double* d_vs_w = nullptr; int num_sites = 0;
     int grid = 0, num_tiles = 0, gb = 1;
     int num_cus = 256, grid_override = 0, ke_parts = 0;
     std::map<int, int> grid_cache;    // ops (+hard-wall bit) -> persistent grid size

@@ -33,6 +33,32 @@ __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
 __device__ __forceinline__ float abs_(float x) { return fabsf(x); }
 __device__ __forceinline__ double abs_(double x) { return fabs(x); }
 
+// Streaming accesses, optionally non-temporal (TGNH_NT bit 0: loads, bit 1: stores) -- a tuning knob, see
+// profiles/r01_tuning_sweep.log for what it measured.
+#ifndef TGNH_NT
+#define TGNH_NT 0
+#endif
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_s(const float4* p) {
+    if (TGNH_NT & 1) { const v4f_t t = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(p)); return make_float4(t.x, t.y, t.z, t.w); }
+    return *p;
+}
+__device__ __forceinline__ double4 ld_s(const double4* p) {
+    if (TGNH_NT & 1) { const v4d_t t = __builtin_nontemporal_load(reinterpret_cast<const v4d_t*>(p)); return make_double4(t.x, t.y, t.z, t.w); }
+    return *p;
+}
+__device__ __forceinline__ long long ld_s(const long long* p) { return (TGNH_NT & 1) ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ uint32_t ld_s(const uint32_t* p) { return (TGNH_NT & 1) ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void st_s(float4* p, const float4 v) {
+    if (TGNH_NT & 2) { v4f_t t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<v4f_t*>(p)); }
+    else *p = v;
+}
+__device__ __forceinline__ void st_s(double4* p, const double4 v) {
+    if (TGNH_NT & 2) { v4d_t t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<v4d_t*>(p)); }
+    else *p = v;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -43,7 +69,7 @@ size_t tile_lds_bytes(int precision, int ops, bool hardwall, bool use_com) {
     (void)use_com;
     const size_t m4 = (precision == TGNH_PREC_SINGLE) ? 16 : 32;
     const bool hw = hardwall && (ops & (OP_DRIFT | OP_MOVE));
-    size_t b = (size_t)(BLOCK / 64) * (MAX_GROUPS + 2) * 8;          // KE reduction scratch
+    size_t b = (size_t)(TBLOCK / 64) * (MAX_GROUPS + 2) * 8;          // KE reduction scratch
     if ((ops & (OP_SCALE | OP_KE)) || hw) b = m4 * (TILE_SLOTS + TILE_RES);   // sv + scom (fixed carve)
     if (hw) b += m4 * TILE_SLOTS;                                     // sx
     return b;
@@ -53,7 +79,7 @@ size_t tile_lds_bytes(int precision, int ops, bool hardwall, bool use_com) {
 // tile_kernel
 // ---------------------------------------------------------------------------
 template <int PREC, int OPS, int GB>
-__global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
+__global__ __launch_bounds__(TBLOCK) void tile_kernel(const TileArgs a) {
     typedef typename Prec<PREC>::real real;
     typedef typename Prec<PREC>::mixed mixed;
     typedef typename Prec<PREC>::real4 real4;
@@ -107,18 +133,18 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
         in.rs = a.tile_res[t]; in.nres = a.tile_res[t + 1] - in.rs;
 #pragma unroll
         for (int k = 0; k < SPT; k++) {
-            const int idx = in.ts + k * BLOCK + tid;
+            const int idx = in.ts + k * TBLOCK + tid;
             if (idx < in.te) {
-                in.v[k] = velm[idx];
-                in.meta[k] = a.meta[idx];
+                in.v[k] = ld_s(&velm[idx]);
+                in.meta[k] = ld_s(&a.meta[idx]);
                 if (DO_KICK) {
-                    in.fx[k] = a.force[idx];
-                    in.fy[k] = a.force[idx + a.padded];
-                    in.fz[k] = a.force[idx + 2 * a.padded];
+                    in.fx[k] = ld_s(&a.force[idx]);
+                    in.fy[k] = ld_s(&a.force[idx + a.padded]);
+                    in.fz[k] = ld_s(&a.force[idx + 2 * a.padded]);
                 }
                 if (POS) {
-                    in.p[k] = posq[idx];
-                    if (PREC == TGNH_PREC_MIXED) in.c[k] = pcorr[idx];       // K :443-445
+                    in.p[k] = ld_s(&posq[idx]);
+                    if (PREC == TGNH_PREC_MIXED) in.c[k] = ld_s(&pcorr[idx]);       // K :443-445
                 }
                 if (DO_MOVE) in.pd[k] = pdelta[idx];
             } else {
@@ -145,7 +171,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
         bool ok[SPT];
 #pragma unroll
         for (int k = 0; k < SPT; k++) {
-            ok[k] = ts + k * BLOCK + tid < te;
+            ok[k] = ts + k * TBLOCK + tid < te;
             v[k] = cur.v[k];
             meta[k] = cur.meta[k];
             if (DO_KICK) { fx[k] = cur.fx[k]; fy[k] = cur.fy[k]; fz[k] = cur.fz[k]; }
@@ -161,10 +187,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
         // ---------------- A6: rescale (K :249-301 ; Ref :516-541) ----------------
         if (DO_SCALE) {
 #pragma unroll
-            for (int k = 0; k < SPT; k++) sv[k * BLOCK + tid] = v[k];
+            for (int k = 0; k < SPT; k++) sv[k * TBLOCK + tid] = v[k];
             __syncthreads();
             if (use_com) {
-                for (int r = tid; r < nres; r += BLOCK) {            // K :86-111
+                for (int r = tid; r < nres; r += TBLOCK) {            // K :86-111
                     const int2 rt = a.res_table[rs + r];
                     const int first = rt.y - ts;
                     mixed cx = 0, cy = 0, cz = 0, cm = 0;
@@ -195,7 +221,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
                         v[k].z = s_g * rz + s_com * (v[k].z - rz);
                     }
                 } else {                                             // K :270-300
-                    const int pl = k * BLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
+                    const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
                     const mixed4 u = sv[pl];
                     const bool is_d = role == ROLE_DRUDE;
                     const mixed4 v1 = is_d ? v[k] : u;               // particles.x (Drude)
@@ -265,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
         if (DO_PD) {
 #pragma unroll
             for (int k = 0; k < SPT; k++) {
-                const int idx = ts + k * BLOCK + tid;
+                const int idx = ts + k * TBLOCK + tid;
                 if (ok[k]) {
                     const bool mv = v[k].w != 0;
                     pdelta[idx] = mk4(mv ? dt * v[k].x : (mixed)0, mv ? dt * v[k].y : (mixed)0, mv ? dt * v[k].z : (mixed)0, (mixed)0);
@@ -278,8 +304,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
             if (lds_read) __syncthreads();
 #pragma unroll
             for (int k = 0; k < SPT; k++) {
-                sv[k * BLOCK + tid] = v[k];
-                sx[k * BLOCK + tid] = mk4(px[k], py[k], pz[k], (mixed)0);
+                sv[k * TBLOCK + tid] = v[k];
+                sx[k * TBLOCK + tid] = mk4(px[k], py[k], pz[k], (mixed)0);
             }
             __syncthreads();
             const mixed maxd = (mixed)a.max_dist, hws = (mixed)a.hw_scale;
@@ -288,7 +314,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
                 const uint32_t m = meta[k];
                 const uint32_t role = m & 3u;
                 if (role != ROLE_NORMAL) {
-                    const int pl = k * BLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
+                    const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
                     const mixed4 uv = sv[pl], ux = sx[pl];
                     const bool is_d = role == ROLE_DRUDE;
                     const mixed4 vel1 = is_d ? v[k] : uv, vel2 = is_d ? uv : v[k];
@@ -347,16 +373,16 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
         // ---------------- stores ----------------
 #pragma unroll
         for (int k = 0; k < SPT; k++) {
-            const int idx = ts + k * BLOCK + tid;
+            const int idx = ts + k * TBLOCK + tid;
             if (ok[k]) {
-                if (VEL_W || (POS && hardwall)) velm[idx] = v[k];
+                if (VEL_W || (POS && hardwall)) st_s(&velm[idx], v[k]);
                 if (POS) {
                     if (PREC == TGNH_PREC_MIXED) {                   // K :457-458
                         const float hx = (float)px[k], hy = (float)py[k], hz = (float)pz[k];
-                        posq[idx] = mk4((real)hx, (real)hy, (real)hz, pq[k]);
-                        pcorr[idx] = make_float4((float)(px[k] - hx), (float)(py[k] - hy), (float)(pz[k] - hz), 0.0f);
+                        st_s(&posq[idx], mk4((real)hx, (real)hy, (real)hz, pq[k]));
+                        st_s(&pcorr[idx], make_float4((float)(px[k] - hx), (float)(py[k] - hy), (float)(pz[k] - hz), 0.0f));
                     } else {
-                        posq[idx] = mk4((real)px[k], (real)py[k], (real)pz[k], pq[k]);
+                        st_s(&posq[idx], mk4((real)px[k], (real)py[k], (real)pz[k], pq[k]));
                     }
                 }
             }
@@ -366,10 +392,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
         if (DO_KE) {
             if (lds_read) __syncthreads();
 #pragma unroll
-            for (int k = 0; k < SPT; k++) sv[k * BLOCK + tid] = v[k];
+            for (int k = 0; k < SPT; k++) sv[k * TBLOCK + tid] = v[k];
             __syncthreads();
             if (use_com) {
-                for (int r = tid; r < nres; r += BLOCK) {            // K :86-111, :152-158
+                for (int r = tid; r < nres; r += TBLOCK) {            // K :86-111, :152-158
                     const int2 rt = a.res_table[rs + r];
                     const int first = rt.y - ts;
                     mixed cx = 0, cy = 0, cz = 0, cm = 0;
@@ -400,7 +426,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
                         val = (rx * rx + ry * ry + rz * rz) / (double)v[k].w;
                     }
                 } else if (role == ROLE_DRUDE) {                     // K :171-186 (one lane per pair)
-                    const int pl = k * BLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
+                    const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
                     const mixed4 u = sv[pl];
                     const double w1 = v[k].w, w2 = u.w;
                     const double r1x = v[k].x - cx, r1y = v[k].y - cy, r1z = v[k].z - cz;
@@ -425,7 +451,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
 
     // ---- work-group reduction of the fp64 KE bins: 64-lane butterflies, then one LDS hop ----
     if (DO_KE) {
-        double* sred = reinterpret_cast<double*>(smem);              // [BLOCK/64][GB+2]
+        double* sred = reinterpret_cast<double*>(smem);              // [TBLOCK/64][GB+2]
         const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
         for (int b = 0; b < GB; b++) ke_g[b] = wave_sum(ke_g[b]);
@@ -441,7 +467,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(const TileArgs a) {
         if (tid < GB + 2) {
             double s = 0.0;
 #pragma unroll
-            for (int w = 0; w < BLOCK / 64; w++) s += sred[w * (GB + 2) + tid];   // fixed order
+            for (int w = 0; w < TBLOCK / 64; w++) s += sred[w * (GB + 2) + tid];   // fixed order
             const int NT = G + 2;
             if (tid < GB) { if (tid < G) a.partials[(size_t)blockIdx.x * NT + tid] = s; }
             else a.partials[(size_t)blockIdx.x * NT + G + (tid - GB)] = s;
@@ -966,14 +992,14 @@ static tile_fn_t tile_fn(int precision, int ops, int gb) {
 hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s) {
     tile_fn_t fn = tile_fn(precision, ops, gb);
     if (!fn) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(BLOCK), lds, s, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(TBLOCK), lds, s, a);
     return hipGetLastError();
 }
 
 int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds) {
     tile_fn_t fn = tile_fn(precision, ops, gb);
     int n = 0;
-    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(fn), BLOCK, lds) != hipSuccess) return 0;
+    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(fn), TBLOCK, lds) != hipSuccess) return 0;
     return n;
 }
 

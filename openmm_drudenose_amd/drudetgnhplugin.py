@@ -299,6 +299,17 @@ class HipContext(_HandleQueries):
         integrator._context = self
         self.force_fn = None
         self.ke_sum_valid = False
+        self.constrained = False
+        if system.cluster_atoms is not None and len(system.cluster_atoms):
+            _check(self.lib.tgnh_harness_set_clusters(self.h, len(system.cluster_atoms),
+                                                      system.cluster_atoms.ctypes.data_as(_lib.c_i32p),
+                                                      system.cluster_dist.ctypes.data_as(_lib.c_f64p)))
+            self.constrained = True
+        if system.site_atoms is not None and len(system.site_atoms):
+            _check(self.lib.tgnh_harness_set_virtual_sites(self.h, len(system.site_atoms),
+                                                           system.site_atoms.ctypes.data_as(_lib.c_i32p),
+                                                           system.site_weights.ctypes.data_as(_lib.c_f64p)))
+            self.constrained = True        # the split path is the one with the virtual-site call-out
         if system.positions is not None:
             self.setPositions(system.positions)
             self.set_sites(system.positions)
@@ -427,6 +438,12 @@ class HipContext(_HandleQueries):
         self.ke_sum_valid = True                             # DrudeTGNHIntegrator.cpp:192
 
     def step(self, steps):
+        if self.force_fn is None and self.constrained:
+            _check(self.lib.tgnh_run_harness_constrained(self.h, self.x0.data_ptr(), self.k_drude, self.k_tether,
+                                                         self.integrator.getConstraintTolerance(), int(steps), self._stream()))
+            if steps > 0:
+                self.ke_sum_valid = True
+            return
         if self.force_fn is None:
             _check(self.lib.tgnh_run_harness(self.h, self.x0.data_ptr(), self.k_drude, self.k_tether, int(steps), self._stream()))
             if steps > 0:

@@ -1,0 +1,72 @@
+"""XML round trip of DrudeTGNHIntegrator and a thermostat-state checkpoint.
+
+The XML carries the nine properties of the reference's proxy under the same names and version
+(serialization/src/DrudeTGNHIntegratorProxy.cpp:43-55), in the shape OpenMM's XmlSerializer gives a
+root node (`<Integrator type="DrudeTGNHIntegrator" version="1" .../>`), so files are interchangeable.
+What the reference's proxy drops (maxDrudeDistance, useCOMTempGroup, temperature groups)
+is written as extra attributes / children that an older reader ignores.  The thermostat variables
+(eta, etaDot, etaDotDot), which the reference cannot checkpoint at all, go into a plain dict.
+"""
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+from .drudetgnhplugin import DrudeTGNHIntegrator, TgnhError
+from . import _lib
+
+_DOUBLES = [("stepSize", "getStepSize"), ("constraintTolerance", "getConstraintTolerance"),
+            ("temperature", "getTemperature"), ("couplingTime", "getCouplingTime"),
+            ("drudeTemperature", "getDrudeTemperature"), ("drudeCouplingTime", "getDrudeCouplingTime")]
+_INTS = [("drudeStepsPerRealStep", "getDrudeStepsPerRealStep"), ("numNHChains", "getNumNHChains"),
+         ("useDrudeNHChains", "getUseDrudeNHChains")]
+
+
+def serialize(integrator, root_name="Integrator"):
+    node = ET.Element(root_name, {"type": "DrudeTGNHIntegrator", "version": "1"})
+    for name, getter in _DOUBLES:
+        node.set(name, repr(float(getattr(integrator, getter)())))
+    for name, getter in _INTS:
+        node.set(name, str(int(getattr(integrator, getter)())))
+    # extensions (ignored by the reference's version-1 reader)
+    node.set("maxDrudeDistance", repr(float(integrator.getMaxDrudeDistance())))
+    node.set("useCOMTempGroup", str(int(integrator.getUseCOMTempGroup())))
+    if integrator._particleTempGroup:
+        g = ET.SubElement(node, "TempGroups", {"count": str(integrator.getNumTempGroups())})
+        g.text = " ".join(str(x) for x in integrator._particleTempGroup)
+    return ET.tostring(node, encoding="unicode")
+
+
+def deserialize(text):
+    node = ET.fromstring(text)
+    if node.get("type") != "DrudeTGNHIntegrator":
+        raise TgnhError(_lib.ERR_ARG, "not a DrudeTGNHIntegrator node")
+    if int(node.get("version")) != 1:                            # DrudeTGNHIntegratorProxy.cpp:58-59
+        raise TgnhError(_lib.ERR_ARG, "Unsupported version number")
+    it = DrudeTGNHIntegrator(float(node.get("temperature")), float(node.get("couplingTime")),
+                             float(node.get("drudeTemperature")), float(node.get("drudeCouplingTime")),
+                             float(node.get("stepSize")), int(node.get("drudeStepsPerRealStep")),
+                             int(node.get("numNHChains")), bool(int(node.get("useDrudeNHChains"))))
+    it.setConstraintTolerance(float(node.get("constraintTolerance")))
+    if node.get("maxDrudeDistance") is not None:
+        it.setMaxDrudeDistance(float(node.get("maxDrudeDistance")))
+    if node.get("useCOMTempGroup") is not None:
+        it.setUseCOMTempGroup(int(node.get("useCOMTempGroup")))
+    g = node.find("TempGroups")
+    if g is not None:
+        for _ in range(int(g.get("count"))):
+            it.addTempGroup()
+        for x in (g.text or "").split():
+            it.addParticleTempGroup(int(x))
+    return it
+
+
+def save_thermostat(ctx):
+    """Thermostat variables + clock of a context: what a checkpoint must hold besides positions/velocities."""
+    t, k = ctx.time()
+    return {"eta": ctx.thermostat_state(0), "etaDot": ctx.thermostat_state(1), "etaDotDot": ctx.thermostat_state(2),
+            "time": t, "stepCount": k}
+
+
+def load_thermostat(ctx, state):
+    for which, key in enumerate(("eta", "etaDot", "etaDotDot")):
+        ctx.set_thermostat_state(which, np.asarray(state[key], np.float64))

@@ -63,13 +63,26 @@ def _molecules(n_mol, table, spacing, origin=0.0):
     return mass, base + table["drude"], base + table["parent"], np.repeat(np.arange(n_mol), k), pos
 
 
-def water_box(n_mol, order="test", temperature=300.0, drude_temperature=1.0, seed=SEED, spacing=0.31):
-    """SWM4-NDP water: 5 slots per molecule (one massless M site), one Drude pair per molecule."""
+def water_box(n_mol, order="test", temperature=300.0, drude_temperature=1.0, seed=SEED, spacing=0.31, rigid=False):
+    """SWM4-NDP water: 5 slots per molecule (one massless M site), one Drude pair per molecule.
+    rigid=True adds the reference test's three distance constraints per molecule and its M virtual site
+    (TestReferenceDrudeTGNHIntegrator.cpp:145-148): O-H 0.09572, H-H 0.15139 nm, ThreeParticleAverageSite weights."""
     rng = np.random.default_rng(seed)
     table = _W_TEST if order == "test" else _W_NACL
     mass, pd, pp, resid, pos = _molecules(n_mol, table, spacing)
-    return _finish(mass, pd, pp, resid, pos, np.zeros(mass.shape[0], np.int32), 1, rng, temperature, drude_temperature,
-                   f"swm4-{n_mol}")
+    out = _finish(mass, pd, pp, resid, pos, np.zeros(mass.shape[0], np.int32), 1, rng, temperature, drude_temperature,
+                  f"swm4-{n_mol}" + ("-rigid" if rigid else ""))
+    if rigid:
+        o, h1, h2, m = (0, 2, 3, 4) if order == "test" else (0, 1, 2, 3)
+        base = np.arange(n_mol) * 5
+        atoms = np.stack([base + o, base + h1, base + h2, -np.ones(n_mol, np.int64)], 1)
+        dist = np.tile(np.array([0.09572, 0.09572, 0.0, 0.15139, 0.0, 0.0]), (n_mol, 1))
+        out[0].set_clusters(atoms, dist)
+        out[0].set_virtual_sites(np.stack([base + m, base + o, base + h1, base + h2], 1),
+                                 np.tile(np.array([0.786646558, 0.106676721, 0.106676721]), (n_mol, 1)))
+        out[0].positions[base + m] = (0.786646558 * out[0].positions[base + o] + 0.106676721 * out[0].positions[base + h1]
+                                      + 0.106676721 * out[0].positions[base + h2])
+    return out
 
 
 def nacl(temperature=300.0, drude_temperature=1.0, seed=SEED):
@@ -119,12 +132,28 @@ def _ion_pairs(n_pairs, rng, origin, res0, slot0):
     return mass, pd, pp, resid, pos, kind
 
 
-def ionic_liquid(n_pairs, temperature=300.0, drude_temperature=1.0, seed=SEED):
+def ionic_liquid(n_pairs, temperature=300.0, drude_temperature=1.0, seed=SEED, constrained=False):
     """[BMIM][BF4]-like: cation 35 sites (10 heavy + 10 Drude + 15 H), anion 10 (5 heavy + 5 Drude).
-    Two temperature groups: cations 0, anions 1.  Every ion is its own molecule."""
+    Two temperature groups: cations 0, anions 1.  Every ion is its own molecule.
+    constrained=True: the 15 X-H bonds of every cation are distance constraints (H k bonded to heavy atom k mod 10),
+    i.e. BASELINE.json's "[BMIM][BF4] ... + SHAKE constraints"."""
     rng = np.random.default_rng(seed)
     mass, pd, pp, resid, pos, kind = _ion_pairs(n_pairs, rng, 0.0, 0, 0)
-    return _finish(mass, pd, pp, resid, pos, kind, 2, rng, temperature, drude_temperature, f"il-{n_pairs}")
+    out = _finish(mass, pd, pp, resid, pos, kind, 2, rng, temperature, drude_temperature,
+                  f"il-{n_pairs}" + ("-shake" if constrained else ""))
+    if constrained:
+        s = out[0]
+        base = np.arange(n_pairs) * 45
+        atoms, dist = [], []
+        for h in range(10):
+            hs = [20 + h] + ([30 + h] if h < 5 else [])
+            a = np.stack([base + 2 * h] + [base + x for x in hs] + [-np.ones(n_pairs, np.int64)] * (3 - len(hs)), 1)
+            d = np.zeros((n_pairs, 6))
+            for k, x in enumerate(hs):
+                d[:, k] = np.linalg.norm(s.positions[base + x] - s.positions[base + 2 * h], axis=1)
+            atoms.append(a); dist.append(d)
+        s.set_clusters(np.concatenate(atoms), np.concatenate(dist))
+    return out
 
 
 def mixed(n_water, n_pairs, temperature=300.0, drude_temperature=1.0, seed=SEED):

@@ -17,6 +17,11 @@ class DrudeSystem:
     positions: np.ndarray = None           # [N,3] nm
     velocities: np.ndarray = None          # [N,3] nm/ps
     name: str = ""
+    # harness call-out data (what OpenMM's constraint / virtual-site machinery would hold)
+    cluster_atoms: np.ndarray = None       # [K,4] slot indices, -1 = unused
+    cluster_dist: np.ndarray = None        # [K,6] distances for pairs (0,1)(0,2)(0,3)(1,2)(1,3)(2,3), 0 = none
+    site_atoms: np.ndarray = None          # [S,4] (site, p1, p2, p3)
+    site_weights: np.ndarray = None        # [S,3]
 
     def __post_init__(self):
         self.mass = np.ascontiguousarray(self.mass, np.float64)
@@ -24,6 +29,24 @@ class DrudeSystem:
         self.pair_parent = np.ascontiguousarray(self.pair_parent, np.int32)
         self.resid = np.ascontiguousarray(self.resid, np.int32)
         self.constraints = np.ascontiguousarray(self.constraints, np.int32).reshape(-1, 2)
+        if self.cluster_atoms is not None:
+            self.set_clusters(self.cluster_atoms, self.cluster_dist)
+
+    PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))
+
+    def set_clusters(self, atoms, dist):
+        """Constraint clusters; System::getConstraintParameters is derived from them (dof bookkeeping)."""
+        self.cluster_atoms = np.ascontiguousarray(atoms, np.int32).reshape(-1, 4)
+        self.cluster_dist = np.ascontiguousarray(dist, np.float64).reshape(-1, 6)
+        cons = []
+        for k, (a, b) in enumerate(self.PAIRS):
+            m = self.cluster_dist[:, k] > 0
+            cons.append(np.stack([self.cluster_atoms[m, a], self.cluster_atoms[m, b]], 1))
+        self.constraints = np.ascontiguousarray(np.concatenate(cons), np.int32).reshape(-1, 2)
+
+    def set_virtual_sites(self, atoms, weights):
+        self.site_atoms = np.ascontiguousarray(atoms, np.int32).reshape(-1, 4)
+        self.site_weights = np.ascontiguousarray(weights, np.float64).reshape(-1, 3)
 
     @property
     def num_particles(self):

@@ -67,6 +67,12 @@ def _load():
         L.tgo_kinetic_energy_query.restype = C.c_double
         L.tgo_harness_force.argtypes = [C.c_void_p, _f64p, _f64p, C.c_double, C.c_double, _f64p]
         L.tgo_run_harness.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_int]
+        L.tgo_set_clusters.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, _i32p, _f64p]
+        L.tgo_shake_positions.argtypes = [C.c_void_p, _f64p, _f64p, C.c_double]
+        L.tgo_shake_velocities.argtypes = [C.c_void_p, _f64p, _f64p, C.c_double]
+        L.tgo_set_virtual_sites.argtypes = [C.c_void_p, C.c_int, _i32p, _f64p]
+        L.tgo_virtual_sites.argtypes = [C.c_void_p, _f64p]
+        L.tgo_run_harness_constrained.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_double, C.c_int]
         L.tgo_time.argtypes = [C.c_void_p]
         L.tgo_time.restype = C.c_double
         L.tgo_step_count.argtypes = [C.c_void_p]
@@ -125,6 +131,12 @@ class Oracle:
         self.h = h
         self.n = d.num_particles
         self.mode = mode
+        ca = getattr(system, "cluster_atoms", None)
+        if ca is not None and len(ca):
+            self.set_clusters(ca, system.cluster_dist)
+        sa = getattr(system, "site_atoms", None)
+        if sa is not None and len(sa):
+            self.set_virtual_sites(sa, system.site_weights)
 
     @classmethod
     def from_integrator(cls, system, integ, group, num_groups, mode, **kw):
@@ -205,6 +217,40 @@ class Oracle:
 
     def run_harness(self, pos, vel, force, x0, k_drude, k_tether, nsteps):
         self._chk(self.L.tgo_run_harness(self.h, _p(pos), _p(vel), _p(force), _p(x0), k_drude, k_tether, nsteps))
+
+    PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))
+
+    def set_clusters(self, atoms, dist6):
+        """Clusters in the library's canonical form ([K,4] atoms, [K,6] distances, 0 = none) -> the oracle's
+        general (pairs, distances) lists, kept in the same sweep order."""
+        atoms = np.ascontiguousarray(atoms, np.int32).reshape(-1, 4)
+        dist6 = np.asarray(dist6, np.float64).reshape(-1, 6)
+        k = len(atoms)
+        ncons = np.zeros(k, np.int32)
+        pairs = np.zeros((k, 6, 2), np.int32)
+        dist = np.zeros((k, 6))
+        for c in range(k):
+            n = 0
+            for p, (a, b) in enumerate(self.PAIRS):
+                if dist6[c, p] > 0:
+                    pairs[c, n] = (a, b); dist[c, n] = dist6[c, p]; n += 1
+            ncons[c] = n
+        self._cl = (atoms, ncons, np.ascontiguousarray(pairs), np.ascontiguousarray(dist))
+        self.L.tgo_set_clusters(self.h, k, atoms.ctypes.data_as(_i32p), ncons.ctypes.data_as(_i32p),
+                                self._cl[2].ctypes.data_as(_i32p), _p(self._cl[3]))
+
+    def set_virtual_sites(self, atoms, w):
+        atoms = np.ascontiguousarray(atoms, np.int32).reshape(-1, 4)
+        w = np.ascontiguousarray(w, np.float64).reshape(-1, 3)
+        self._vs = (atoms, w)
+        self.L.tgo_set_virtual_sites(self.h, len(atoms), atoms.ctypes.data_as(_i32p), _p(w))
+
+    def shake_positions(self, pos, delta, tol): self._chk(self.L.tgo_shake_positions(self.h, _p(pos), _p(delta), tol))
+    def shake_velocities(self, pos, vel, tol): self._chk(self.L.tgo_shake_velocities(self.h, _p(pos), _p(vel), tol))
+    def virtual_sites(self, pos): self.L.tgo_virtual_sites(self.h, _p(pos))
+
+    def run_harness_constrained(self, pos, vel, force, x0, k_drude, k_tether, tol, nsteps):
+        self._chk(self.L.tgo_run_harness_constrained(self.h, _p(pos), _p(vel), _p(force), _p(x0), k_drude, k_tether, tol, nsteps))
 
     def time(self): return self.L.tgo_time(self.h)
     def step_count(self): return self.L.tgo_step_count(self.h)

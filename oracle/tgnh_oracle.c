@@ -53,6 +53,9 @@ struct tgo_state {
     /* scratch */
     double *comv;   /* [R][4] (vx,vy,vz,w=1/M) */
     double *normv;  /* [N][3] */
+    /* harness call-outs */
+    int ncl; int *cl_atoms, *cl_ncons, *cl_pairs; double *cl_dist;
+    int nvs; int *vs_atoms; double *vs_w;
 };
 
 static void* xcalloc(size_t n, size_t sz) {
@@ -271,6 +274,7 @@ void tgo_destroy(tgo_state* s) {
     free(s->tgDof); free(s->tgRed); free(s->tgNkbT);
     free(s->eta); free(s->etaDot); free(s->etaDotDot); free(s->etaMass);
     free(s->comv); free(s->normv);
+    free(s->cl_atoms); free(s->cl_ncons); free(s->cl_pairs); free(s->cl_dist); free(s->vs_atoms); free(s->vs_w);
     free(s);
 }
 
@@ -814,6 +818,132 @@ int tgo_run_harness(tgo_state* s, double* pos, double* vel, double* force, const
         tgo_step_end(s, vel, force);
     }
     return TGO_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* Harness call-outs of the constrained path (not from the reference)  */
+/* ------------------------------------------------------------------ */
+void tgo_set_clusters(tgo_state* s, int n, const int* atoms, const int* ncons, const int* pairs, const double* dist) {
+    free(s->cl_atoms); free(s->cl_ncons); free(s->cl_pairs); free(s->cl_dist);
+    s->ncl = n;
+    s->cl_atoms = xcalloc((size_t)n * 4, sizeof(int)); memcpy(s->cl_atoms, atoms, sizeof(int) * 4 * n);
+    s->cl_ncons = xcalloc(n, sizeof(int)); memcpy(s->cl_ncons, ncons, sizeof(int) * n);
+    s->cl_pairs = xcalloc((size_t)n * 12, sizeof(int)); memcpy(s->cl_pairs, pairs, sizeof(int) * 12 * n);
+    s->cl_dist = xcalloc((size_t)n * 6, sizeof(double)); memcpy(s->cl_dist, dist, sizeof(double) * 6 * n);
+}
+
+#define SHAKE_MAX_ITER 500
+
+int tgo_shake_positions(const tgo_state* s, const double* pos, double* delta, double tol) {
+    for (int c = 0; c < s->ncl; c++) {
+        const int* at = s->cl_atoms + 4 * c;
+        const int nc = s->cl_ncons[c];
+        int iter = 0, converged = 0;
+        while (!converged && iter++ < SHAKE_MAX_ITER) {
+            converged = 1;
+            for (int k = 0; k < nc; k++) {
+                const int i = at[s->cl_pairs[12 * c + 2 * k]], j = at[s->cl_pairs[12 * c + 2 * k + 1]];
+                const double d = s->cl_dist[6 * c + k], d2 = d * d;
+                double r[3], sv[3];
+                for (int a = 0; a < 3; a++) {
+                    r[a] = V(pos, i, a) - V(pos, j, a);
+                    sv[a] = r[a] + (V(delta, i, a) - V(delta, j, a));
+                }
+                const double diff = d2 - dot3(sv, sv);
+                if (fabs(diff) > 2.0 * tol * d2) {
+                    converged = 0;
+                    const double g = diff / (2.0 * dot3(r, sv) * (s->inv_mass[i] + s->inv_mass[j]));
+                    for (int a = 0; a < 3; a++) {
+                        V(delta, i, a) += g * s->inv_mass[i] * r[a];
+                        V(delta, j, a) -= g * s->inv_mass[j] * r[a];
+                    }
+                }
+            }
+        }
+        if (!converged) return fail(TGO_ERR_ARG, "SHAKE did not converge");
+    }
+    return TGO_OK;
+}
+
+int tgo_shake_velocities(const tgo_state* s, const double* pos, double* vel, double tol) {
+    for (int c = 0; c < s->ncl; c++) {
+        const int* at = s->cl_atoms + 4 * c;
+        const int nc = s->cl_ncons[c];
+        int iter = 0, converged = 0;
+        while (!converged && iter++ < SHAKE_MAX_ITER) {
+            converged = 1;
+            for (int k = 0; k < nc; k++) {
+                const int i = at[s->cl_pairs[12 * c + 2 * k]], j = at[s->cl_pairs[12 * c + 2 * k + 1]];
+                double r[3], vr[3];
+                for (int a = 0; a < 3; a++) { r[a] = V(pos, i, a) - V(pos, j, a); vr[a] = V(vel, i, a) - V(vel, j, a); }
+                const double r2 = dot3(r, r), rv = dot3(r, vr);
+                const double g = rv / (r2 * (s->inv_mass[i] + s->inv_mass[j]));
+                if (fabs(g) * (s->inv_mass[i] + s->inv_mass[j]) > tol) {      /* relative bond-velocity rate above tol (1/ps) */
+                    converged = 0;
+                    for (int a = 0; a < 3; a++) {
+                        V(vel, i, a) -= g * s->inv_mass[i] * r[a];
+                        V(vel, j, a) += g * s->inv_mass[j] * r[a];
+                    }
+                }
+            }
+        }
+        if (!converged) return fail(TGO_ERR_ARG, "velocity SHAKE did not converge");
+    }
+    return TGO_OK;
+}
+
+void tgo_set_virtual_sites(tgo_state* s, int n, const int* atoms, const double* w) {
+    free(s->vs_atoms); free(s->vs_w);
+    s->nvs = n;
+    s->vs_atoms = xcalloc((size_t)n * 4, sizeof(int)); memcpy(s->vs_atoms, atoms, sizeof(int) * 4 * n);
+    s->vs_w = xcalloc((size_t)n * 3, sizeof(double)); memcpy(s->vs_w, w, sizeof(double) * 3 * n);
+}
+
+void tgo_virtual_sites(const tgo_state* s, double* pos) {
+    for (int k = 0; k < s->nvs; k++) {
+        const int* a = s->vs_atoms + 4 * k;
+        const double* w = s->vs_w + 3 * k;
+        for (int j = 0; j < 3; j++)
+            V(pos, a[0], j) = w[0] * V(pos, a[1], j) + w[1] * V(pos, a[2], j) + w[2] * V(pos, a[3], j);
+    }
+}
+
+int tgo_run_harness_constrained(tgo_state* s, double* pos, double* vel, double* force, const double* x0,
+                                double k_drude, double k_tether, double tol, int nsteps) {
+    double* delta = xcalloc((size_t)s->n * 3, sizeof(double));
+    int rc = TGO_OK;
+    for (int it = 0; it < nsteps && rc == TGO_OK; it++) {
+        tgo_propagate_nhc(s, vel, NULL, NULL);              /* Ref :231 ; Cu :336-353 */
+        tgo_half_kick(s, vel, force);                       /* Ref :239 ; Cu :356-360 */
+        const double dt = s->dt;
+        for (int i = 0; i < s->n; i++)                      /* Ref :256-258 xPrime - pos ; K :323, :361-362 posDelta */
+            for (int j = 0; j < 3; j++) V(delta, i, j) = (s->inv_mass[i] != 0.0) ? V(vel, i, j) * dt : 0.0;
+        rc = tgo_shake_positions(s, pos, delta, tol);       /* Ref :268 ; Cu :363 */
+        if (rc != TGO_OK) break;
+        const double dtInv = 1.0 / dt;
+        for (int i = 0; i < s->n; i++) {                    /* Ref :278-284 ; K :440-455 */
+            if (s->inv_mass[i] != 0.0) {
+                for (int j = 0; j < 3; j++) {
+                    V(pos, i, j) += V(delta, i, j);
+                    V(vel, i, j) = dtInv * V(delta, i, j);
+                }
+            }
+        }
+        rc = tgo_hardwall(s, pos, vel);                     /* Ref :298-363 ; Cu :372-376 */
+        if (rc != TGO_OK) break;
+        tgo_virtual_sites(s, pos);                          /* Ref :373 ; Cu :377 */
+        tgo_harness_force(s, pos, x0, k_drude, k_tether, force);   /* Ref :384 ; Cu :380 */
+        tgo_half_kick(s, vel, force);                       /* Ref :394 ; Cu :384-388 */
+        if (s->mode == TGO_MODE_TGNH) {                     /* Cu :391 only: the Reference platform has no velocity stage */
+            rc = tgo_shake_velocities(s, pos, vel, tol);
+            if (rc != TGO_OK) break;
+        }
+        tgo_propagate_nhc(s, vel, NULL, NULL);              /* Ref :406 ; Cu :394-402 */
+        s->time += s->dt;
+        s->step_count++;
+    }
+    free(delta);
+    return rc;
 }
 
 double tgo_time(const tgo_state* s) { return s->time; }

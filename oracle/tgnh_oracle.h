@@ -123,6 +123,25 @@ void tgo_harness_force(const tgo_state* s, const double* pos, const double* x0,
 int  tgo_run_harness(tgo_state* s, double* pos, double* vel, double* force, const double* x0,
                      double k_drude, double k_tether, int nsteps);
 
+/* ---- harness call-outs for the constrained path (NOT from the reference, which delegates both to OpenMM:
+ * Ref :268 ReferenceConstraints::apply ; Cu :363 applyConstraints, :391 applyVelocityConstraints, Ref :373 /
+ * Cu :377 virtual sites).  Constraint clusters: up to 4 atoms with up to 6 distance constraints among them,
+ * solved by SHAKE sweeps in cluster order until every |d^2 - r^2| <= 2 tol d^2. ---- */
+void tgo_set_clusters(tgo_state* s, int nclusters, const int* atoms /*[n][4], -1 = unused*/,
+                      const int* ncons /*[n]*/, const int* pairs /*[n][6][2] local indices*/, const double* dist /*[n][6]*/);
+/* positions: old positions `pos`, proposed displacement `delta` (x' = pos + delta), corrected in place */
+int  tgo_shake_positions(const tgo_state* s, const double* pos, double* delta, double tol);
+/* velocities: remove the components along the constrained bonds (RATTLE velocity stage) */
+int  tgo_shake_velocities(const tgo_state* s, const double* pos, double* vel, double tol);
+/* three-particle-average virtual sites: pos[site] = w1 pos[p1] + w2 pos[p2] + w3 pos[p3] */
+void tgo_set_virtual_sites(tgo_state* s, int n, const int* atoms /*[n][4] site,p1,p2,p3*/, const double* w /*[n][3]*/);
+void tgo_virtual_sites(const tgo_state* s, double* pos);
+/* A11 with the call-outs in place.  DUALNH (Ref :253-284): x' = x + v dt, constrain, v = (x'-x)/dt, no velocity
+ * stage.  TGNH (Cu :356-391): posDelta = dt v, constrain, x += posDelta, v = posDelta/dt, velocity stage after
+ * the second kick. */
+int  tgo_run_harness_constrained(tgo_state* s, double* pos, double* vel, double* force, const double* x0,
+                                 double k_drude, double k_tether, double tol, int nsteps);
+
 double tgo_time(const tgo_state* s);
 long   tgo_step_count(const tgo_state* s);
 

@@ -91,3 +91,25 @@ def test_shard_bounds_cut_at_molecules():
         parts = [s.slice_molecules(lo, hi) for lo, hi in zip(b, b[1:])]
         assert sum(p.num_particles for p in parts) == s.num_particles
         assert sum(p.num_pairs for p in parts) == s.num_pairs
+
+
+def test_xml_serialization_round_trip():
+    """serialization/tests/TestSerializeDrudeTGNHIntegrator.cpp:45-69, same eight comparisons."""
+    from openmm_drudenose_amd import serialization
+    integ1 = DrudeTGNHIntegrator(301.1, 0.1, 10.5, 0.005, 0.001)
+    xml = serialization.serialize(integ1)
+    assert 'type="DrudeTGNHIntegrator"' in xml and 'version="1"' in xml
+    integ2 = serialization.deserialize(xml)
+    for getter in ("getTemperature", "getCouplingTime", "getDrudeTemperature", "getDrudeCouplingTime",
+                   "getDrudeStepsPerRealStep", "getNumNHChains", "getUseDrudeNHChains", "getConstraintTolerance"):
+        assert getattr(integ1, getter)() == getattr(integ2, getter)(), getter
+    # what the reference's proxy drops survives here
+    integ1.setMaxDrudeDistance(0.02); integ1.setUseCOMTempGroup(False)
+    integ1.addTempGroup(); integ1.addTempGroup()
+    for g in (0, 1, 1, 0):
+        integ1.addParticleTempGroup(g)
+    integ3 = serialization.deserialize(serialization.serialize(integ1))
+    assert integ3.getMaxDrudeDistance() == 0.02 and integ3.getUseCOMTempGroup() == 0
+    assert integ3.getNumTempGroups() == 2 and [integ3.getParticleTempGroup(i) for i in range(4)] == [0, 1, 1, 0]
+    with pytest.raises(TgnhError, match="Unsupported version"):
+        serialization.deserialize(xml.replace('version="1"', 'version="2"'))

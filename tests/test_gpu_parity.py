@@ -337,6 +337,81 @@ def test_split_constraint_path_matches_fused():
     ref.close(); alt.close()
 
 
+CONSTRAINED = {
+    "rigid SWM4 water (3 constraints + M virtual site per molecule)": lambda: synth.water_box(343, rigid=True),
+    "ionic liquid, X-H bonds constrained": lambda: synth.ionic_liquid(40, constrained=True),
+}
+
+
+@pytest.mark.parametrize("precision", ["mixed", "double"])
+@pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
+@pytest.mark.parametrize("name", list(CONSTRAINED))
+def test_constrained_path_parity(name, mode, precision):
+    """The split step (begin_kick / SHAKE on posDelta / begin_move / virtual sites / force / end_kick /
+    [TGNH: velocity stage] / end_thermo; Cu :336-406, Ref :253-284) against the oracle's constrained loop.
+    The constraint solver is a harness call-out on both sides; its tolerance is set to 1e-10 so that the two
+    converged solutions agree far inside the 1e-6 gate."""
+    s, g, ng = CONSTRAINED[name]()
+    it = integ(chains=2, hardwall=0.02)
+    it.setConstraintTolerance(1e-10)
+    if mode == "TGNH":
+        bind_groups(it, g, ng)
+    else:
+        g, ng = np.zeros_like(g), 1
+    ctx = HipContext(s, it, mode=mode, precision=precision)
+    assert ctx.constrained
+    o = make_oracle(s, g, ng, mode, it)
+    assert np.allclose(ctx.dof()[0], to_internal(o.dof()[0], mode), rtol=1e-14)      # constraints reduce the dof
+    pos, vel, x0 = s.positions.copy(), s.velocities.copy(), ctx.sites()
+    f = o.harness_force(pos, x0, synth.K_DRUDE, synth.K_TETHER)
+    o.run_harness_constrained(pos, vel, f, x0, synth.K_DRUDE, synth.K_TETHER, 1e-10, 50)
+    ctx.step(50)
+    assert ctx.check() == 0                                                          # bit1 = SHAKE not converged
+    gp, gv = ctx.getPositions(), ctx.getVelocities()
+    ep, ev = rel_err(gp, pos), rel_err(gv, vel)
+    print(f"constrained {name} {mode} {precision}: pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= TOL and ev <= TOL
+    a, d = s.cluster_atoms, s.cluster_dist
+    for k, (i, j) in enumerate(s.PAIRS):
+        m = d[:, k] > 0
+        if m.any():
+            r = np.linalg.norm(gp[a[m, i]] - gp[a[m, j]], axis=1)
+            assert np.abs(r - d[m, k]).max() <= 1e-7 * d[m, k].max()                 # fp32 posq + correction holds ~1e-9 nm
+    if s.site_atoms is not None:
+        sa, w = s.site_atoms, s.site_weights
+        expect = sum(w[:, [m]] * gp[sa[:, m + 1]] for m in range(3))
+        assert np.abs(gp[sa[:, 0]] - expect).max() <= 1e-7
+    ctx.close()
+
+
+def test_shake_call_outs_alone():
+    """The two constraint stages by themselves against the oracle's (same sweeps, same order)."""
+    s, g, ng = synth.ionic_liquid(25, constrained=True)
+    it = integ(chains=1)
+    bind_groups(it, g, ng)
+    ctx = HipContext(s, it, mode="TGNH", precision="double")
+    o = make_oracle(s, g, ng, "TGNH", it)
+    rng = np.random.default_rng(3)
+    delta = rng.normal(0, 2e-3, s.positions.shape)
+    ctx.pos_delta[:, :3] = ctx.torch.from_numpy(delta).to(ctx.dev)
+    assert ctx.lib.tgnh_harness_shake_positions(ctx.h, 1e-11, ctx._stream()) == 0
+    o.shake_positions(s.positions, delta, 1e-11)
+    assert rel_err(ctx.pos_delta[:, :3].cpu().numpy(), delta) < 1e-9
+    vel = s.velocities.copy()
+    assert ctx.lib.tgnh_harness_shake_velocities(ctx.h, 1e-11, ctx._stream()) == 0
+    o.shake_velocities(s.positions, vel, 1e-11)
+    assert rel_err(ctx.getVelocities(), vel) < 1e-9
+    # along every constrained bond the relative velocity is gone
+    a, d = s.cluster_atoms, s.cluster_dist
+    gv = ctx.getVelocities()
+    for k, (i, j) in enumerate(s.PAIRS):
+        m = d[:, k] > 0
+        if m.any():
+            r = s.positions[a[m, i]] - s.positions[a[m, j]]
+            assert np.abs(((gv[a[m, i]] - gv[a[m, j]]) * r).sum(1)).max() < 1e-9
+    ctx.close()
+
+
 def test_thermostat_state_checkpoint_roundtrip():
     s, g, ng, it, a = make("il40", "TGNH", "double")
     a.step(20)
