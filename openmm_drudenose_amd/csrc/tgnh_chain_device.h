@@ -1,0 +1,333 @@
+// tgnh_chain_device.h -- device code of the Nose-Hoover chain (A5), shared by chain_kernel and by the tile
+// kernel's in-kernel chain.  Included by tgnh_kernels.hip only.
+//
+// TGNH: one lane per thermostat (Cu :558-650).  dualNH: one lane runs the reference's coupled, interleaved
+// vectors (Ref :467-504), including its indexing quirk when useDrudeNHChains is false.
+// The chain variables are copied into registers (numNHChains <= 4, fully unrolled) or LDS (longer chains) for
+// the S-fold loop and written back once.
+#ifndef TGNH_CHAIN_DEVICE_H_
+#define TGNH_CHAIN_DEVICE_H_
+
+namespace tgnh {
+
+#pragma clang fp contract(off)
+
+// exp() for the chain.  The arguments are -dtc/8*etaDot and -dtc/2*etaDot: exactly 0 for the dummy link
+// (exp(-0) = 1 exactly, as libm returns) and tiny otherwise, so a short Taylor polynomial in explicit FMAs is
+// exact to double rounding: degree 6 for |x| < 2^-10 (truncation < 2^-62 relative), degree 11 for |x| < 2^-5
+// (< 2^-55); larger arguments take the library exp.  The chain is one serial fp64 dependency chain per
+// thermostat, so its latency is the number of dependent operations: this keeps an exp at 6-11 of them.
+template <bool LIBM = true>
+__device__ __forceinline__ double chain_exp(double x) {
+    const double ax = fabs(x);
+    if (__builtin_expect(ax < 0.0009765625, 1)) {                    // also x = +-0: returns exactly 1
+        double p = 1.0 / 720.0;
+        p = fma(p, x, 1.0 / 120.0);
+        p = fma(p, x, 1.0 / 24.0);
+        p = fma(p, x, 1.0 / 6.0);
+        p = fma(p, x, 0.5);
+        p = fma(p, x, 1.0);
+        return fma(p, x, 1.0);
+    }
+    if (ax < 0.03125) {
+        double p = 1.0 / 39916800.0;
+        p = fma(p, x, 1.0 / 3628800.0);
+        p = fma(p, x, 1.0 / 362880.0);
+        p = fma(p, x, 1.0 / 40320.0);
+        p = fma(p, x, 1.0 / 5040.0);
+        p = fma(p, x, 1.0 / 720.0);
+        p = fma(p, x, 1.0 / 120.0);
+        p = fma(p, x, 1.0 / 24.0);
+        p = fma(p, x, 1.0 / 6.0);
+        p = fma(p, x, 0.5);
+        p = fma(p, x, 1.0);
+        return fma(p, x, 1.0);
+    }
+    if (LIBM) return exp(x);
+    // no libm call (the tile kernel's in-kernel chain: ocml's exp would cost it ~30 VGPRs): halve the argument
+    // into the polynomial's range, then square back; k <= 11 squarings for |x| < 64, error <= 2^k ulp
+    int k = 0;
+    double y = x;
+    while (fabs(y) >= 0.03125 && k < 40) { y *= 0.5; k++; }
+    double p = 1.0 / 39916800.0;
+    p = fma(p, y, 1.0 / 3628800.0);
+    p = fma(p, y, 1.0 / 362880.0);
+    p = fma(p, y, 1.0 / 40320.0);
+    p = fma(p, y, 1.0 / 5040.0);
+    p = fma(p, y, 1.0 / 720.0);
+    p = fma(p, y, 1.0 / 120.0);
+    p = fma(p, y, 1.0 / 24.0);
+    p = fma(p, y, 1.0 / 6.0);
+    p = fma(p, y, 0.5);
+    p = fma(p, y, 1.0);
+    p = fma(p, y, 1.0);
+    for (int i = 0; i < k; i++) p *= p;
+    return p;
+}
+
+struct ChainConst {
+    double dtc2, dtc4, dtc8;
+    int S;
+};
+
+// One real (temperature-group or COM) thermostat.  Cu :560-595.  CC > 0: compile-time chain length.
+template <int CC, bool LIBM = true>
+__device__ __forceinline__ void chain_real_core(double* eta, double* etaDot, double* etaDotDot, const double* etaMass,
+                                                const int Cdyn, const ChainConst k, const double nkbt, const double kbT,
+                                                double ke, double* scale_out, double* ke_out) {
+    const int C = CC > 0 ? CC : Cdyn;
+    double scale = 1.0, expfac = 1.0;
+    const bool live = etaMass[0] > 0;
+    const double invQ0 = live ? 1.0 / etaMass[0] : 0.0;              // (KE - NkT)/Q as a multiply: <= 1 ulp from the division
+    if (live) etaDotDot[0] = (ke - nkbt) * invQ0;                    // Cu :561-563
+    if constexpr (CC == 1) {
+        // One link: link 1 is the reference's dummy that "will always have etaDot = 0" (Cu :252, Ref :215), so
+        // expfac = exp(-dtc8*0) = 1 exactly and each of Cu :568-570 / :583-585 collapses to one fused multiply-add.
+        // This is the serial critical path of a whole time step: 16 dependent fp64 operations per sub-step.
+        double ed = etaDot[0], edd = etaDotDot[0], et = eta[0];
+        for (int iter = 0; iter < k.S; iter++) {
+            ed = fma(edd, k.dtc4, ed);                               // Cu :568-570 with expfac = 1
+            const double e = chain_exp<LIBM>(-k.dtc2 * ed);
+            scale *= e; ke *= e * e;                                 // Cu :573-574
+            et = fma(k.dtc2, ed, et);                                // Cu :575-577
+            if (live) edd = (ke - nkbt) * invQ0;                     // Cu :579-581
+            ed = fma(edd, k.dtc4, ed);                               // Cu :583-585
+        }
+        etaDot[0] = ed; etaDotDot[0] = edd; eta[0] = et;
+        *scale_out = scale;
+        *ke_out = ke;
+        return;
+    }
+    for (int iter = 0; iter < k.S; iter++) {
+#pragma unroll
+        for (int i = C - 1; i >= 0; i--) {                           // Cu :566-571
+            expfac = chain_exp<LIBM>(-k.dtc8 * etaDot[i + 1]);
+            etaDot[i] *= expfac;
+            etaDot[i] += etaDotDot[i] * k.dtc4;
+            etaDot[i] *= expfac;
+        }
+        { const double e = chain_exp<LIBM>(-k.dtc2 * etaDot[0]); scale *= e; ke *= e * e; }   // Cu :573-574, exp(-dtc x) = e^2
+#pragma unroll
+        for (int i = 0; i < C; i++) eta[i] += k.dtc2 * etaDot[i];    // Cu :575-577
+        if (live) etaDotDot[0] = (ke - nkbt) * invQ0;                // Cu :579-581
+        etaDot[0] *= expfac;                                         // Cu :583-585 (expfac of link 0 reused)
+        etaDot[0] += etaDotDot[0] * k.dtc4;
+        etaDot[0] *= expfac;
+#pragma unroll
+        for (int i = 1; i < C; i++) {                                // Cu :586-592
+            expfac = chain_exp<LIBM>(-k.dtc8 * etaDot[i + 1]);
+            etaDot[i] *= expfac;
+            etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - kbT) / etaMass[i];
+            etaDot[i] += etaDotDot[i] * k.dtc4;
+            etaDot[i] *= expfac;
+        }
+    }
+    *scale_out = scale;
+    *ke_out = ke;
+}
+
+// The Drude thermostat.  Cu :597-642.
+template <int CC, bool LIBM = true>
+__device__ __forceinline__ void chain_drude_core(double* eta, double* etaDot, double* etaDotDot, const double* etaMass,
+                                                 const int Cdyn, const bool chains, const ChainConst k, const double nkbt,
+                                                 const double kbT, double ke, double* scale_out, double* ke_out) {
+    const int C = CC > 0 ? CC : Cdyn;
+    double scale = 1.0, expfac = 1.0;
+    const double invQ0 = 1.0 / etaMass[0];
+    etaDotDot[0] = (ke - nkbt) * invQ0;                              // Cu :605
+    if (CC == 1 || !chains) {
+        // Only link 0 moves (Cu :607-614, :624-628, :633-641 are skipped), so expfac = exp(-dtc8*etaDot[1]) is a
+        // constant of the whole call (1 exactly when etaDot[1] = 0, the usual case).
+        expfac = chain_exp<LIBM>(-k.dtc8 * etaDot[1]);                     // Cu :615
+        const double ef2 = expfac * expfac, efd = expfac * k.dtc4;
+        double ed = etaDot[0], edd = etaDotDot[0], et = eta[0];
+        const bool unit = expfac == 1.0;
+        for (int iter = 0; iter < k.S; iter++) {
+            ed = unit ? fma(edd, k.dtc4, ed) : fma(ed, ef2, edd * efd);      // Cu :616-618: (ed*ef + edd*dtc4)*ef
+            const double e = chain_exp<LIBM>(-k.dtc2 * ed);
+            scale *= e; ke *= e * e;                                 // Cu :620-621
+            et = fma(k.dtc2, ed, et);                                // Cu :623
+            edd = (ke - nkbt) * invQ0;                               // Cu :629
+            ed = unit ? fma(edd, k.dtc4, ed) : fma(ed, ef2, edd * efd);      // Cu :630-632
+        }
+        etaDot[0] = ed; etaDotDot[0] = edd; eta[0] = et;
+        *scale_out = scale;
+        *ke_out = ke;
+        return;
+    }
+    for (int iter = 0; iter < k.S; iter++) {                         // Cu :606-642
+#pragma unroll
+        for (int i = C - 1; i > 0; i--) {
+            expfac = chain_exp<LIBM>(-k.dtc8 * etaDot[i + 1]);
+            etaDot[i] *= expfac;
+            etaDot[i] += etaDotDot[i] * k.dtc4;
+            etaDot[i] *= expfac;
+        }
+        expfac = chain_exp<LIBM>(-k.dtc8 * etaDot[1]);
+        etaDot[0] *= expfac;
+        etaDot[0] += etaDotDot[0] * k.dtc4;
+        etaDot[0] *= expfac;
+        { const double e = chain_exp<LIBM>(-k.dtc2 * etaDot[0]); scale *= e; ke *= e * e; }   // Cu :620-621
+        eta[0] += k.dtc2 * etaDot[0];
+#pragma unroll
+        for (int i = 1; i < C; i++) eta[i] += k.dtc2 * etaDot[i];
+        etaDotDot[0] = (ke - nkbt) * invQ0;
+        etaDot[0] *= expfac;
+        etaDot[0] += etaDotDot[0] * k.dtc4;
+        etaDot[0] *= expfac;
+#pragma unroll
+        for (int i = 1; i < C; i++) {
+            expfac = chain_exp<LIBM>(-k.dtc8 * etaDot[i + 1]);
+            etaDot[i] *= expfac;
+            etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - kbT) / etaMass[i];
+            etaDot[i] += etaDotDot[i] * k.dtc4;
+            etaDot[i] *= expfac;
+        }
+    }
+    *scale_out = scale;
+    *ke_out = ke;
+}
+
+// One TGNH thermostat (lane itg), `reps` chain calls back to back on register / LDS copies.
+template <int CC, bool LIBM = true>
+// st_in -> st_out (may alias); `write`: this caller owns the write-back; s_scale (LDS, may be null) receives the factors.
+__device__ __forceinline__ void run_tgnh(const ChainArgs& a, const double* st_in, double* st_out, const bool write,
+                                         double* s_scale, const int itg, double* lds, const double ke_in) {
+    const ChainLayout& L = a.L;
+    const int C = L.C, NT = L.NT;
+    constexpr int CM = CC > 0 ? CC : 1;
+    double r_eta[CM], r_etaDot[CM + 1], r_etaDotDot[CM], r_etaMass[CM];
+    double *eta = r_eta, *etaDot = r_etaDot, *etaDotDot = r_etaDotDot, *etaMass = r_etaMass;
+    if (CC == 0) {                       // long chains: this lane's slice of the LDS scratch
+        eta = lds + itg * (4 * C + 1); etaDot = eta + C; etaDotDot = etaDot + C + 1; etaMass = etaDotDot + C;
+    }
+    const double* g_eta = st_in + L.off_eta + itg * C;
+    const double* g_etaDot = st_in + L.off_etaDot + itg * (C + 1);
+    const double* g_etaDotDot = st_in + L.off_etaDotDot + itg * C;
+    const double* g_etaMass = st_in + L.off_etaMass + itg * C;
+#pragma unroll
+    for (int i = 0; i < (CC > 0 ? CC : C); i++) { eta[i] = g_eta[i]; etaDotDot[i] = g_etaDotDot[i]; etaMass[i] = g_etaMass[i]; }
+#pragma unroll
+    for (int i = 0; i < (CC > 0 ? CC : C) + 1; i++) etaDot[i] = g_etaDot[i];
+    ChainConst k;
+    const double dtc = a.dt / a.S;                                   // Cu :440-443
+    k.dtc2 = dtc / 2.0; k.dtc4 = dtc / 4.0; k.dtc8 = dtc / 8.0; k.S = a.S;
+    const double nkbt = st_in[L.off_nkbt + itg];
+    double ke = ke_in;
+    if (write) st_out[L.off_ke + itg] = ke;                          // KE before the chain (Cu :490)
+    const int reps = a.chain_twice ? 2 : 1;
+    double total = 1.0;
+    for (int rep = 0; rep < reps; rep++) {
+        double sc, kep;
+        if (itg < NT - 1) chain_real_core<CC, LIBM>(eta, etaDot, etaDotDot, etaMass, C, k, nkbt, a.realkbT, ke, &sc, &kep);
+        else chain_drude_core<CC, LIBM>(eta, etaDot, etaDotDot, etaMass, C, L.use_drude_chains != 0, k, nkbt, a.drudekbT, ke, &sc, &kep);
+        if (write) {
+            if (rep == 0) { st_out[L.off_scale_a + itg] = sc; st_out[L.off_ke_post + itg] = kep; }
+            else st_out[L.off_scale_b + itg] = sc;
+        }
+        total *= sc;
+        ke = kep;
+    }
+    if (s_scale) s_scale[itg] = total;
+    if (!write) return;
+    if (reps == 1) st_out[L.off_scale_b + itg] = 1.0;
+    st_out[L.off_scale + itg] = total;
+    double* o_eta = st_out + L.off_eta + itg * C;
+    double* o_etaDot = st_out + L.off_etaDot + itg * (C + 1);
+    double* o_etaDotDot = st_out + L.off_etaDotDot + itg * C;
+#pragma unroll
+    for (int i = 0; i < (CC > 0 ? CC : C); i++) { o_eta[i] = eta[i]; o_etaDotDot[i] = etaDotDot[i]; }
+#pragma unroll
+    for (int i = 0; i < (CC > 0 ? CC : C) + 1; i++) o_etaDot[i] = etaDot[i];
+}
+
+// The Reference platform's coupled real/Drude chain on its interleaved vectors.  Ref :467-504.
+// LEN = compile-time bound of the vectors (2*CC+2), 0 = dynamic (LDS).
+template <int CC>
+__device__ __forceinline__ void run_dualnh(const ChainArgs& a, const double* st_in, double* st_out, const bool write,
+                                           double* s_scale, double* lds, const double ke0, const double ke1, const double ke2) {
+    const ChainLayout& L = a.L;
+    constexpr int LM = CC > 0 ? 2 * CC + 2 : 1;
+    double r_eta[LM], r_etaDot[LM], r_etaDotDot[LM], r_etaMass[LM];
+    double *eta = r_eta, *etaDot = r_etaDot, *etaDotDot = r_etaDotDot, *etaMass = r_etaMass;
+    const int n = L.len_eta, nd = L.len_etaDot;                      // n = 2C or C+1 ; nd = n+2
+    if (CC == 0) { eta = lds; etaDot = eta + nd; etaDotDot = etaDot + nd; etaMass = etaDotDot + nd; }
+    const int NB = CC > 0 ? LM : nd;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        eta[i] = i < n ? st_in[L.off_eta + i] : 0.0;
+        etaDotDot[i] = i < n ? st_in[L.off_etaDotDot + i] : 0.0;
+        etaMass[i] = i < n ? st_in[L.off_etaMass + i] : 1.0;
+        etaDot[i] = i < nd ? st_in[L.off_etaDot + i] : 0.0;
+    }
+    const double realNkbT = st_in[L.off_nkbt + 0], drudeNkbT = st_in[L.off_nkbt + 2];
+    const double dtc = a.dt / a.S;                                   // Ref :432-435
+    const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
+    const int ntg = L.numTempGroup, idxMax = L.idxMaxNHChains, iNum = L.iNumNHChains;
+    double realKE = ke0, drudeKE = ke2;
+    if (write) {
+        st_out[L.off_ke + 0] = realKE; st_out[L.off_ke + 1] = ke1; st_out[L.off_ke + 2] = drudeKE;
+        st_out[L.off_kesum] = 0.5 * (realKE + drudeKE);
+    }
+    const int reps = a.chain_twice ? 2 : 1;
+    double totR = 1.0, totD = 1.0;
+    for (int rep = 0; rep < reps; rep++) {
+        double scaleReal = 1.0, scaleDrude = 1.0, expfac = 1.0;
+        const double invQr = 1.0 / etaMass[0], invQd = 1.0 / etaMass[1];
+        etaDotDot[0] = (realKE - realNkbT) * invQr;                  // Ref :471-472
+        etaDotDot[1] = (drudeKE - drudeNkbT) * invQd;
+        for (int iter = 0; iter < a.S; iter++) {
+#pragma unroll
+            for (int i = NB - 3; i >= 0; i--) {                      // Ref :476-481 (i = idxMaxNHChains .. 0)
+                if (i <= idxMax) {
+                    expfac = chain_exp(-dtc8 * (ntg == 2 ? etaDot[i + 2] : etaDot[i + 1]));
+                    etaDot[i] *= expfac;
+                    etaDot[i] += etaDotDot[i] * dtc4;
+                    etaDot[i] *= expfac;
+                }
+            }
+            { const double e = chain_exp(-dtc2 * etaDot[0]); scaleReal *= e; realKE *= e * e; }    // Ref :483-486
+            { const double e = chain_exp(-dtc2 * etaDot[1]); scaleDrude *= e; drudeKE *= e * e; }
+#pragma unroll
+            for (int i = 0; i < NB - 2; i++) if (i < iNum) eta[i] += dtc2 * etaDot[i];             // Ref :487-489
+            etaDotDot[0] = (realKE - realNkbT) * invQr;              // Ref :491-492
+            etaDotDot[1] = (drudeKE - drudeNkbT) * invQd;
+#pragma unroll
+            for (int i = 0; i < NB - 2; i++) {                       // Ref :494-503
+                if (i < iNum) {
+                    expfac = chain_exp(-dtc8 * etaDot[i + 2]);
+                    etaDot[i] *= expfac;
+                    if (i > 1) {
+                        const double dofkbT = (i % 2 == 0 ? a.realkbT : a.drudekbT);
+                        etaDotDot[i] = (etaMass[i - 2] * etaDot[i - 2] * etaDot[i - 2] - dofkbT) / etaMass[i];
+                    }
+                    etaDot[i] += etaDotDot[i] * dtc4;
+                    etaDot[i] *= expfac;
+                }
+            }
+        }
+        if (write) {
+            if (rep == 0) {
+                st_out[L.off_scale_a + 0] = scaleReal; st_out[L.off_scale_a + 1] = 1.0; st_out[L.off_scale_a + 2] = scaleDrude;
+                st_out[L.off_ke_post + 0] = realKE; st_out[L.off_ke_post + 1] = 0.0; st_out[L.off_ke_post + 2] = drudeKE;
+            } else {
+                st_out[L.off_scale_b + 0] = scaleReal; st_out[L.off_scale_b + 1] = 1.0; st_out[L.off_scale_b + 2] = scaleDrude;
+            }
+        }
+        totR *= scaleReal; totD *= scaleDrude;
+    }
+    if (s_scale) { s_scale[0] = totR; s_scale[1] = 1.0; s_scale[2] = totD; }
+    if (!write) return;
+    if (reps == 1) { st_out[L.off_scale_b + 0] = 1.0; st_out[L.off_scale_b + 1] = 1.0; st_out[L.off_scale_b + 2] = 1.0; }
+    st_out[L.off_scale + 0] = totR; st_out[L.off_scale + 1] = 1.0; st_out[L.off_scale + 2] = totD;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        if (i < n) { st_out[L.off_eta + i] = eta[i]; st_out[L.off_etaDotDot + i] = etaDotDot[i]; }
+        if (i < nd) st_out[L.off_etaDot + i] = etaDot[i];
+    }
+}
+
+#pragma clang fp contract(fast)
+
+}  // namespace tgnh
+#endif

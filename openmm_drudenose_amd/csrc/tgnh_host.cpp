@@ -279,7 +279,11 @@ static tgnh_status finalize_thermostat(tgnh_context* c) {
         st[L.off_scale + i] = 1.0; st[L.off_scale_a + i] = 1.0; st[L.off_scale_b + i] = 1.0;
     }
     c->h_state = st;
-    if (!c->host_only) HIP_OK(hipMemcpy(c->d_state, st.data(), sizeof(double) * L.total, hipMemcpyHostToDevice));
+    if (!c->host_only) {
+        for (int b = 0; b < 2; b++)
+            HIP_OK(hipMemcpy(c->d_state_buf[b], st.data(), sizeof(double) * L.total, hipMemcpyHostToDevice));
+    }
+    c->chain_pending = false;
     c->ke_valid = false; c->scale_pending = false; c->first_half_done = false;
     return TGNH_OK;
 }
@@ -329,7 +333,7 @@ static void free_device(tgnh_context* c) {
     if (c->d_tile_res) (void)hipFree(c->d_tile_res);
     if (c->d_res_table) (void)hipFree(c->d_res_table);
     if (c->d_partials) (void)hipFree(c->d_partials);
-    if (c->d_state) (void)hipFree(c->d_state);
+    for (int b = 0; b < 2; b++) if (c->d_state_buf[b]) (void)hipFree(c->d_state_buf[b]);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_scalar) (void)hipFree(c->d_scalar);
     if (c->d_cl_atoms) (void)hipFree(c->d_cl_atoms);
@@ -402,13 +406,20 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     c->gb = c->L.G <= 1 ? 1 : (c->L.G <= 4 ? 4 : 8);
+    {   // one-link chains run inside the rescale launch (TGNH_INLINE_CHAIN=0 keeps the separate chain launch)
+        const char* e = getenv("TGNH_INLINE_CHAIN");
+        c->inline_chain = c->L.C == 1 && c->L.mode == TGNH_MODE_TGNH && !(e && e[0] == '0');
+    }
     auto alloc = [&]() -> tgnh_status {
         if (host_only) return TGNH_OK;
         HIP_OK(hipMalloc(&c->d_partials, sizeof(double) * (size_t)c->grid * c->L.NT));
         HIP_OK(hipMemset(c->d_partials, 0, sizeof(double) * (size_t)c->grid * c->L.NT));
-        HIP_OK(hipMalloc(&c->d_state, sizeof(double) * c->L.total));
+        for (int b = 0; b < 2; b++) HIP_OK(hipMalloc(&c->d_state_buf[b], sizeof(double) * c->L.total));
+        c->state_cur = 0;
+        c->d_state = c->d_state_buf[0];
         HIP_OK(hipMalloc(&c->d_status, sizeof(uint32_t)));
         HIP_OK(hipMemset(c->d_status, 0, sizeof(uint32_t)));
+
         HIP_OK(hipMalloc(&c->d_scalar, sizeof(double)));
         return TGNH_OK;
     };
@@ -540,14 +551,32 @@ static int grid_for(tgnh_handle h, int ops, bool hardwall, size_t lds) {
     return g;
 }
 
+static ChainArgs chain_args(tgnh_handle h);
+
 static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, const double* scale = nullptr) {
     TileArgs a = tile_args(h, scale);
+    bool flip = false;
+    if ((ops & OP_SCALE) && h->chain_pending && !scale) {           // this rescale launch runs the chain itself
+        a.chain_on = 1;
+        a.chain = chain_args(h);
+        a.chain.chain_twice = h->chain_pending_twice ? 1 : 0;
+        a.st_in = h->d_state_buf[h->state_cur];
+        a.st_out = h->d_state_buf[h->state_cur ^ 1];
+        flip = true;
+    }
     if ((ops & (OP_POSDELTA | OP_MOVE)) && !h->pos_delta) return fail(TGNH_ERR_STATE, "posDelta buffer not bound");
     const size_t lds = tile_lds_bytes(h->d.precision, ops, a.hardwall != 0, a.use_com != 0);
     const int grid = grid_for(h, ops, a.hardwall != 0, lds);
     if (ops & OP_KE) h->ke_parts = grid;
-    Timed t(h, s, kid);
-    HIP_OK(launch_tile(h->d.precision, ops, h->gb, a, grid, lds, s));
+    {
+        Timed t(h, s, kid);
+        HIP_OK(launch_tile(h->d.precision, ops, h->gb, a, grid, lds, s));
+    }
+    if (flip) {                                                      // the other copy now holds the advanced thermostat
+        h->state_cur ^= 1;
+        h->d_state = h->d_state_buf[h->state_cur];
+        h->chain_pending = false;
+    }
     return TGNH_OK;
 }
 
@@ -563,6 +592,14 @@ static ChainArgs chain_args(tgnh_handle h) {
 static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
     ChainArgs a = chain_args(h);
     a.chain_twice = twice ? 1 : 0;
+    if (h->inline_chain) {           // sum (and all-reduce) now, the chain itself inside the next rescale launch
+        a.do_sum = 1; a.do_chain = 0;
+        { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
+        if (h->allreduce && h->allreduce(h->d_state + h->L.off_ke_red, h->L.NT, (void*)s, h->allreduce_user) != 0)
+            return fail(TGNH_ERR_HIP, "all-reduce hook failed");
+        h->chain_pending = true; h->chain_pending_twice = twice;
+        return TGNH_OK;
+    }
     if (h->allreduce) {
         a.do_sum = 1; a.do_chain = 0;
         { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
@@ -575,6 +612,16 @@ static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
         Timed t(h, s, KID_CHAIN);
         HIP_OK(launch_chain(a, s));
     }
+    return TGNH_OK;
+}
+
+// a chain that is still waiting for its rescale launch is run now, in place, by the standalone kernel
+static tgnh_status materialize_chain(tgnh_handle h, hipStream_t s) {
+    if (!h->chain_pending) return TGNH_OK;
+    ChainArgs a = chain_args(h);
+    a.do_sum = 0; a.do_chain = 1; a.chain_twice = h->chain_pending_twice ? 1 : 0;
+    { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
+    h->chain_pending = false;
     return TGNH_OK;
 }
 
@@ -659,6 +706,7 @@ extern "C" tgnh_status tgnh_flush(tgnh_handle h, void* stream) {
     tgnh_status rc = need_buffers(h); if (rc) return rc;
     HIP_OK(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
+    rc = materialize_chain(h, s); if (rc) return rc;
     rc = run_tile(h, OP_SCALE, KID_SCALE, s, h->d_state + h->L.off_scale_a); if (rc) return rc;
     HIP_OK(hipMemcpyAsync(h->d_state + h->L.off_scale, h->d_state + h->L.off_scale_b, sizeof(double) * h->L.NT,
                           hipMemcpyDeviceToDevice, s));
@@ -687,6 +735,7 @@ extern "C" tgnh_status tgnh_state_changed(tgnh_handle h) {
 static tgnh_status read_state(tgnh_handle h, int off, int n, hipStream_t s, double* out) {
     if (h->host_only) { std::copy(h->h_state.begin() + off, h->h_state.begin() + off + n, out); return TGNH_OK; }
     HIP_OK(hipSetDevice(h->device));
+    { tgnh_status rc = materialize_chain(h, s); if (rc) return rc; }
     HIP_OK(hipMemcpyAsync(out, h->d_state + off, sizeof(double) * n, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     return TGNH_OK;
@@ -773,6 +822,7 @@ extern "C" tgnh_status tgnh_set_thermostat_state(tgnh_handle h, int which, void*
     tgnh_status rc = deferred_guard(h, "tgnh_set_thermostat_state"); if (rc) return rc;
     if (h->host_only) { std::copy(in, in + len, h->h_state.begin() + off); return TGNH_OK; }
     HIP_OK(hipSetDevice(h->device));
+    rc = materialize_chain(h, (hipStream_t)stream); if (rc) return rc;
     HIP_OK(hipMemcpyAsync(h->d_state + off, in, sizeof(double) * len, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));
     return TGNH_OK;
@@ -813,6 +863,7 @@ extern "C" tgnh_status tgnh_compute_kinetic_energies(tgnh_handle h, void* stream
     tgnh_status rc = need_buffers(h); if (rc) return rc;
     HIP_OK(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
+    rc = materialize_chain(h, s); if (rc) return rc;      // ke_red is about to be overwritten
     rc = run_tile(h, OP_KE, KID_KE, s); if (rc) return rc;
     ChainArgs a = chain_args(h);
     a.do_sum = 1; a.do_chain = 0;

@@ -58,29 +58,6 @@ enum : int {
 enum : int { KID_SKD = 0, KID_KICK_KE = 1, KID_SCALE = 2, KID_KE = 3, KID_CHAIN = 4, KID_FORCE = 5,
              KID_OTHER = 6, KID_COUNT = 7 };
 
-struct TileArgs {
-    void* posq;
-    void* posq_corr;
-    void* velm;
-    const long long* force;
-    void* pos_delta;
-    const uint32_t* meta;
-    const int* tile_start;     // [num_tiles+1]
-    const int* tile_res;       // [num_tiles+1] first residue of each tile
-    const int2* res_table;     // [R] (count, first slot)
-    const double* scale;       // [NT] velocity scale factors (device)
-    double* partials;          // [grid][NT] per-work-group KE partial sums
-    uint32_t* status;          // bit0: Drude beyond 2x hard wall
-    int num_tiles;
-    int padded;
-    int num_groups;            // G (internal layout: NT = G+2, [G]=COM, [G+1]=Drude)
-    int use_com;
-    int hardwall;
-    double dt;
-    double max_dist;
-    double hw_scale;           // sqrt(kB*T_drude)
-};
-
 // thermostat block in device memory (doubles), offsets in doubles
 struct ChainLayout {
     int mode, G, NT, C, use_drude_chains;
@@ -110,6 +87,35 @@ struct ChainArgs {
     double dt;
     int S;
     double realkbT, drudekbT;
+};
+
+struct TileArgs {
+    void* posq;
+    void* posq_corr;
+    void* velm;
+    const long long* force;
+    void* pos_delta;
+    const uint32_t* meta;
+    const int* tile_start;     // [num_tiles+1]
+    const int* tile_res;       // [num_tiles+1] first residue of each tile
+    const int2* res_table;     // [R] (count, first slot)
+    const double* scale;       // [NT] velocity scale factors (device)
+    double* partials;          // [grid][NT] per-work-group KE partial sums
+    uint32_t* status;          // bit0: Drude beyond 2x hard wall
+    int num_tiles;
+    int padded;
+    int num_groups;            // G (internal layout: NT = G+2, [G]=COM, [G+1]=Drude)
+    int use_com;
+    int hardwall;
+    double dt;
+    double max_dist;
+    double hw_scale;           // sqrt(kB*T_drude)
+    // in-kernel chain (numNHChains == 1): every work-group derives the scale factors from the summed kinetic
+    // energies itself, work-group 0 writes the advanced thermostat block to the OTHER copy (double buffer)
+    int chain_on;
+    const double* st_in;
+    double* st_out;
+    ChainArgs chain;
 };
 
 struct ForceArgs {
@@ -157,7 +163,11 @@ struct tgnh_context {
     int* d_tile_res = nullptr;
     int2* d_res_table = nullptr;
     double* d_partials = nullptr;
-    double* d_state = nullptr;        // thermostat block
+    double* d_state = nullptr;        // thermostat block (the current one of the two copies)
+    double* d_state_buf[2] = {nullptr, nullptr};
+    int state_cur = 0;
+    bool chain_pending = false, chain_pending_twice = false;   // summed KE waits for the next rescale launch to run the chain
+    bool inline_chain = false;        // numNHChains == 1: the chain runs inside the rescale launch
     uint32_t* d_status = nullptr;
     double* d_scalar = nullptr;       // plain KE result
     // harness call-outs (tgnh_harness.hip)
