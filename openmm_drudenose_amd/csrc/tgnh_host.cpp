@@ -103,7 +103,22 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
         }
     }
 
-    // allowed tile cuts: never through a pair, never through a residue when the COM is needed
+    // Molecules longer than a tile ("big": proteins, polymers) cannot have their COM formed in LDS; theirs comes
+    // from a table filled by big_com_kernel, and tiles may cut them anywhere (except through a Drude pair).
+    std::vector<char> is_big(R, 0);
+    c->big_first.clear(); c->big_count.clear();
+    std::vector<int> big_index(R, -1);
+    if (com) {
+        for (int r : res_order) {
+            if (c->res_count[r] > TILE_SLOTS) {
+                is_big[r] = 1;
+                big_index[r] = (int)c->big_first.size();
+                c->big_first.push_back(c->res_first[r]);
+                c->big_count.push_back(c->res_count[r]);
+            }
+        }
+    }
+    // allowed tile cuts: never through a pair, never through a small molecule when the COM is needed
     std::vector<int> forbid(N + 2, 0);
     for (int i = 0; i < P; i++) {
         const int lo = std::min(c->pair_drude[i], c->pair_parent[i]), hi = std::max(c->pair_drude[i], c->pair_parent[i]);
@@ -111,6 +126,7 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
     }
     if (com) {
         for (int r : res_order) {
+            if (is_big[r]) continue;
             const int lo = c->res_first[r], hi = lo + c->res_count[r] - 1;
             forbid[lo + 1] += 1; forbid[hi + 1] -= 1;
         }
@@ -125,46 +141,62 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
     int align = 1;
     if (const char* e = getenv("TGNH_TILE_ALIGN")) { align = atoi(e); if (align < 1) align = 1; }
     c->tile_start.clear(); c->tile_res.clear();
+    // residues overlapping [start, e): those starting inside, plus one that started before `start`
+    auto entries_in = [&](int start, int e) {
+        int n = res_starts_before[e] - res_starts_before[start];
+        if (start > 0 && start < N && c->resid[start] == c->resid[start - 1]) n += 1;
+        return n;
+    };
     int start = 0;
     while (start < N) {
         int end = std::min(start + TILE_SLOTS, N);
         auto ok = [&](int e) {
             if (e < N && forbid[e] > 0) return false;
-            if (com && res_starts_before[e] - res_starts_before[start] > TILE_RES) return false;
+            if (com && entries_in(start, e) > TILE_RES) return false;
             return true;
         };
         while (end > start && !ok(end)) end--;
         if (end == start)
-            return fail(TGNH_ERR_UNSUPPORTED, "a Drude pair or molecule spans more than one 512-slot tile");
+            return fail(TGNH_ERR_UNSUPPORTED, "a Drude pair spans more than one 512-slot tile");
         if (align > 1 && end < N) {           // prefer a cut on an `align`-slot boundary close by
             for (int e = end; e > start && e > end - 64; e--)
                 if (e % align == 0 && ok(e)) { end = e; break; }
         }
         c->tile_start.push_back(start);
-        c->tile_res.push_back(com ? res_starts_before[start] : 0);
         start = end;
     }
     c->tile_start.push_back(N);
-    c->tile_res.push_back(com ? res_starts_before[N] : 0);
     c->num_tiles = (int)c->tile_start.size() - 1;
 
-    // packed per-slot words
+    // per-tile residue entries (count, first slot) -- count < 0: big molecule, COM at table index -count-1 --
+    // and the packed per-slot words
+    std::vector<int2> entries;
+    c->tile_res.assign(c->num_tiles + 1, 0);
     c->meta.assign(N, 0);
-    {
-        int t = 0;
-        for (int i = 0; i < N; i++) {
-            while (i >= c->tile_start[t + 1]) t++;
-            int local_res = 0;
-            if (com) local_res = res_internal[c->resid[i]] - c->tile_res[t];
+    for (int t = 0; t < c->num_tiles; t++) {
+        c->tile_res[t] = (int)entries.size();
+        int prev_res = -1, local = -1;
+        for (int i = c->tile_start[t]; i < c->tile_start[t + 1]; i++) {
+            if (com && c->resid[i] != prev_res) {
+                prev_res = c->resid[i];
+                local++;
+                entries.push_back(is_big[prev_res] ? make_int2(-(big_index[prev_res] + 1), 0)
+                                                   : make_int2(c->res_count[prev_res], c->res_first[prev_res]));
+            }
             int off = 0;
             if (partner[i] >= 0) {
                 off = partner[i] - i;
                 if (partner[i] < c->tile_start[t] || partner[i] >= c->tile_start[t + 1] || off < -1024 || off > 1023)
                     return fail(TGNH_ERR_UNSUPPORTED, "internal: Drude partner outside its tile");
             }
-            c->meta[i] = pack_meta((uint32_t)role[i], (uint32_t)c->group[i], off, (uint32_t)local_res);
+            c->meta[i] = pack_meta((uint32_t)role[i], (uint32_t)c->group[i], off, (uint32_t)(com ? local : 0));
         }
+        if (com && local + 1 > TILE_RES) return fail(TGNH_ERR_UNSUPPORTED, "internal: too many molecules in a tile");
     }
+    c->tile_res[c->num_tiles] = (int)entries.size();
+    if (entries.empty()) entries.push_back(make_int2(0, 0));
+    c->res_entries = entries;
+    c->num_big = (int)c->big_first.size();
     if (c->host_only) return TGNH_OK;
     // device copies
     HIP_OK(hipMalloc(&c->d_meta, sizeof(uint32_t) * std::max(N, 1)));
@@ -173,10 +205,16 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
     HIP_OK(hipMemcpy(c->d_tile_start, c->tile_start.data(), sizeof(int) * c->tile_start.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMalloc(&c->d_tile_res, sizeof(int) * c->tile_res.size()));
     HIP_OK(hipMemcpy(c->d_tile_res, c->tile_res.data(), sizeof(int) * c->tile_res.size(), hipMemcpyHostToDevice));
-    std::vector<int2> rt(std::max<size_t>(res_order.size(), 1));
-    for (size_t k = 0; k < res_order.size(); k++) rt[k] = make_int2(c->res_count[res_order[k]], c->res_first[res_order[k]]);
-    HIP_OK(hipMalloc(&c->d_res_table, sizeof(int2) * rt.size()));
-    HIP_OK(hipMemcpy(c->d_res_table, rt.data(), sizeof(int2) * rt.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc(&c->d_res_table, sizeof(int2) * c->res_entries.size()));
+    HIP_OK(hipMemcpy(c->d_res_table, c->res_entries.data(), sizeof(int2) * c->res_entries.size(), hipMemcpyHostToDevice));
+    if (c->num_big) {
+        std::vector<int2> bt(c->num_big);
+        for (int k = 0; k < c->num_big; k++) bt[k] = make_int2(c->big_count[k], c->big_first[k]);
+        HIP_OK(hipMalloc(&c->d_big_table, sizeof(int2) * c->num_big));
+        HIP_OK(hipMemcpy(c->d_big_table, bt.data(), sizeof(int2) * c->num_big, hipMemcpyHostToDevice));
+        HIP_OK(hipMalloc(&c->d_big_com, 32 * (size_t)c->num_big));           // mixed4 per big molecule
+        HIP_OK(hipMemset(c->d_big_com, 0, 32 * (size_t)c->num_big));
+    }
     return TGNH_OK;
 }
 
@@ -332,6 +370,8 @@ static void free_device(tgnh_context* c) {
     if (c->d_tile_start) (void)hipFree(c->d_tile_start);
     if (c->d_tile_res) (void)hipFree(c->d_tile_res);
     if (c->d_res_table) (void)hipFree(c->d_res_table);
+    if (c->d_big_table) (void)hipFree(c->d_big_table);
+    if (c->d_big_com) (void)hipFree(c->d_big_com);
     if (c->d_partials) (void)hipFree(c->d_partials);
     for (int b = 0; b < 2; b++) if (c->d_state_buf[b]) (void)hipFree(c->d_state_buf[b]);
     if (c->d_status) (void)hipFree(c->d_status);
@@ -392,6 +432,8 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
             }
         }
     }
+    if (c->num_big && (c->d.flags & TGNH_FLAG_MERGE_SCALE_KE))
+        c->d.flags &= ~TGNH_FLAG_MERGE_SCALE_KE;   // a rescale+KE launch would need the big molecules' COM twice: plain passes instead
     local_dof_terms(c);
     c->global_terms = c->local_terms;
     // constraint arrays are only needed during create
@@ -412,8 +454,8 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     }
     auto alloc = [&]() -> tgnh_status {
         if (host_only) return TGNH_OK;
-        HIP_OK(hipMalloc(&c->d_partials, sizeof(double) * (size_t)c->grid * c->L.NT));
-        HIP_OK(hipMemset(c->d_partials, 0, sizeof(double) * (size_t)c->grid * c->L.NT));
+        HIP_OK(hipMalloc(&c->d_partials, sizeof(double) * (size_t)(c->grid + c->num_big) * c->L.NT));
+        HIP_OK(hipMemset(c->d_partials, 0, sizeof(double) * (size_t)(c->grid + c->num_big) * c->L.NT));
         for (int b = 0; b < 2; b++) HIP_OK(hipMalloc(&c->d_state_buf[b], sizeof(double) * c->L.total));
         c->state_cur = 0;
         c->d_state = c->d_state_buf[0];
@@ -526,6 +568,7 @@ static TileArgs tile_args(tgnh_handle h, const double* scale) {
     a.posq = h->posq; a.posq_corr = h->posq_corr; a.velm = h->velm;
     a.force = reinterpret_cast<const long long*>(h->force); a.pos_delta = h->pos_delta;
     a.meta = h->d_meta; a.tile_start = h->d_tile_start; a.tile_res = h->d_tile_res; a.res_table = h->d_res_table;
+    a.big_com = h->d_big_com;
     a.scale = scale ? scale : h->d_state + h->L.off_scale;
     a.partials = h->d_partials; a.status = h->d_status;
     a.num_tiles = h->num_tiles; a.padded = h->d.padded_num_particles; a.num_groups = h->L.G;
@@ -553,6 +596,18 @@ static int grid_for(tgnh_handle h, int ops, bool hardwall, size_t lds) {
 
 static ChainArgs chain_args(tgnh_handle h);
 
+static tgnh_status run_big_com(tgnh_handle h, bool kick, hipStream_t s) {
+    BigComArgs b{};
+    b.table = h->d_big_table; b.n = h->num_big; b.velm = h->velm;
+    b.force = reinterpret_cast<const long long*>(h->force); b.padded = h->d.padded_num_particles;
+    b.kick = kick ? 1 : 0; b.dt = h->d.step_size;
+    b.big_com = h->d_big_com;
+    b.partials = h->d_partials + (size_t)GRID_CAP * h->L.NT; b.NT = h->L.NT; b.G = h->L.G;
+    Timed t(h, s, KID_OTHER);
+    HIP_OK(launch_big_com(h->d.precision, b, s));
+    return TGNH_OK;
+}
+
 static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, const double* scale = nullptr) {
     TileArgs a = tile_args(h, scale);
     bool flip = false;
@@ -567,7 +622,15 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
     if ((ops & (OP_POSDELTA | OP_MOVE)) && !h->pos_delta) return fail(TGNH_ERR_STATE, "posDelta buffer not bound");
     const size_t lds = tile_lds_bytes(h->d.precision, ops, a.hardwall != 0, a.use_com != 0);
     const int grid = grid_for(h, ops, a.hardwall != 0, lds);
-    if (ops & OP_KE) h->ke_parts = grid;
+    if (ops & OP_KE) {
+        h->ke_parts = grid;
+        if (h->num_big && a.use_com) {
+            // COM velocity of every big molecule for the velocities this launch reduces: the current ones, or the
+            // kicked ones (the kick is linear, so sum m v' = sum (m v + dt/2 F) needs no second pass).  The rescale
+            // launches that follow reuse the table: velocities do not change between a KE pass and its rescale.
+            tgnh_status rc = run_big_com(h, (ops & OP_KICK) != 0, s); if (rc) return rc;
+        }
+    }
     {
         Timed t(h, s, kid);
         HIP_OK(launch_tile(h->d.precision, ops, h->gb, a, grid, lds, s));
@@ -583,6 +646,7 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
 static ChainArgs chain_args(tgnh_handle h) {
     ChainArgs a{};
     a.L = h->L; a.st = h->d_state; a.partials = h->d_partials; a.nparts = h->ke_parts;
+    a.nbig = h->num_big;
     a.dt = h->d.step_size; a.S = h->d.drude_steps_per_real_step;
     a.realkbT = h->realkbT; a.drudekbT = h->drudekbT;
     return a;
@@ -710,6 +774,9 @@ extern "C" tgnh_status tgnh_flush(tgnh_handle h, void* stream) {
     rc = run_tile(h, OP_SCALE, KID_SCALE, s, h->d_state + h->L.off_scale_a); if (rc) return rc;
     HIP_OK(hipMemcpyAsync(h->d_state + h->L.off_scale, h->d_state + h->L.off_scale_b, sizeof(double) * h->L.NT,
                           hipMemcpyDeviceToDevice, s));
+    if (h->num_big && h->d.mode == TGNH_MODE_TGNH && h->d.use_com_temp_group) {
+        rc = run_big_com(h, false, s); if (rc) return rc;             // the velocities just changed: refresh the COM table
+    }
     h->scale_pending = false;      // first_half_done stays: scale[] now holds only the pre-run half step
     return TGNH_OK;
 }

@@ -79,8 +79,9 @@ struct ChainLayout {
 struct ChainArgs {
     ChainLayout L;
     double* st;                // thermostat block
-    const double* partials;    // [nparts][NT] or nullptr when ke_red already holds the sums
+    const double* partials;    // [nparts][NT] rows of the tile work-groups, then [nbig][NT] rows at GRID_CAP
     int nparts;
+    int nbig;
     int do_sum;                // sum partials -> ke_red
     int do_chain;              // run the chain from ke_red
     int chain_twice;           // DEFER_SCALE: second half of step n and first half of step n+1 back to back
@@ -98,7 +99,8 @@ struct TileArgs {
     const uint32_t* meta;
     const int* tile_start;     // [num_tiles+1]
     const int* tile_res;       // [num_tiles+1] first residue of each tile
-    const int2* res_table;     // [R] (count, first slot)
+    const int2* res_table;     // per-tile molecule entries (count, first slot); count < 0: big molecule -count-1
+    const void* big_com;       // mixed4 [num_big] COM velocity (w = 1/M) of the molecules longer than a tile
     const double* scale;       // [NT] velocity scale factors (device)
     double* partials;          // [grid][NT] per-work-group KE partial sums
     uint32_t* status;          // bit0: Drude beyond 2x hard wall
@@ -118,6 +120,19 @@ struct TileArgs {
     ChainArgs chain;
 };
 
+struct BigComArgs {
+    const int2* table;         // [n] (count, first slot) of the molecules longer than a tile
+    int n;
+    const void* velm;
+    const long long* force;
+    int padded;
+    int kick;                  // 1: COM of the velocities after the half kick about to be applied
+    double dt;
+    void* big_com;             // mixed4 [n] out
+    double* partials;          // [n][NT] rows: M v_com^2 in bin G
+    int NT, G;
+};
+
 struct ForceArgs {
     const void* posq;
     const void* posq_corr;
@@ -132,6 +147,7 @@ struct ForceArgs {
 hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s);
 int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds);   // occupancy of that instantiation
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s);
+hipError_t launch_big_com(int precision, const BigComArgs& a, hipStream_t s);
 hipError_t launch_force(int precision, const ForceArgs& a, hipStream_t s);
 hipError_t launch_plain_ke(int precision, const void* velm, const long long* force, int n, int padded,
                            double time_shift, double* out /*[1] device, zeroed inside*/, hipStream_t s);
@@ -151,6 +167,11 @@ struct tgnh_context {
     std::vector<int> pair_drude, pair_parent, group, resid, normal;
     std::vector<int> res_count, res_first;
     std::vector<int> tile_start, tile_res;
+    std::vector<int2> res_entries;    // per-tile molecule entries
+    std::vector<int> big_first, big_count;   // molecules longer than a tile (COM from big_com_kernel)
+    int num_big = 0;
+    int2* d_big_table = nullptr;
+    void* d_big_com = nullptr;
     std::vector<uint32_t> meta;
     // dof bookkeeping (A2)
     std::vector<double> local_terms, global_terms;   // per thermostat, before CMM correction

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(TBLOCK) void tile_kernel(const TileArgs a) {
             if (use_com) {
                 for (int r = tid; r < nres; r += TBLOCK) {            // K :86-111
                     const int2 rt = a.res_table[rs + r];
+                    if (rt.x < 0) { scom[r] = reinterpret_cast<const mixed4*>(a.big_com)[-rt.x - 1]; continue; }   // molecule longer than a tile
                     const int first = rt.y - ts;
                     mixed cx = 0, cy = 0, cz = 0, cm = 0;
                     for (int j = 0; j < rt.x; j++) {
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(TBLOCK) void tile_kernel(const TileArgs a) {
             if (use_com) {
                 for (int r = tid; r < nres; r += TBLOCK) {            // K :86-111, :152-158
                     const int2 rt = a.res_table[rs + r];
+                    if (rt.x < 0) { scom[r] = reinterpret_cast<const mixed4*>(a.big_com)[-rt.x - 1]; continue; }   // its M v_com^2 comes from big_com_kernel
                     const int first = rt.y - ts;
                     mixed cx = 0, cy = 0, cz = 0, cm = 0;
                     for (int j = 0; j < rt.x; j++) {
@@ -556,6 +558,8 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
                 }
             }
         }
+        for (int p = tid; p < a.nbig; p += BLOCK)                    // rows of the molecules longer than a tile
+            for (int b = 0; b < NT; b++) acc[b] += a.partials[((size_t)GRID_CAP + p) * NT + b];
 #pragma unroll
         for (int b = 0; b < MAX_GROUPS + 2; b++) {
             if (b < NT) {
@@ -607,6 +611,63 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
     }
 }
 #pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------
+// big_com_kernel: COM velocity of the molecules longer than a tile (K :82-113 for those), one work-group each.
+// kick = 1 gives the COM after the half kick that the KE launch is about to apply: sum m v' = sum (m v + dt/2 F).
+// Also leaves the molecule's M v_com^2 (K :152-158) in its own partial row.
+// ---------------------------------------------------------------------------
+template <int PREC>
+__global__ __launch_bounds__(BLOCK) void big_com_kernel(const BigComArgs a) {
+    typedef typename Prec<PREC>::mixed mixed;
+    typedef typename Prec<PREC>::mixed4 mixed4;
+    __shared__ double sred[BLOCK / 64][4];
+    const mixed4* __restrict__ velm = reinterpret_cast<const mixed4*>(a.velm);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const mixed fscale = (mixed)(0.5 * a.dt / 4294967296.0);
+    for (int b = blockIdx.x; b < a.n; b += gridDim.x) {
+        const int2 rt = a.table[b];
+        double sx = 0, sy = 0, sz = 0, sm = 0;
+        for (int j = tid; j < rt.x; j += BLOCK) {
+            const int i = rt.y + j;
+            const mixed4 v = velm[i];
+            if (v.w != 0) {
+                mixed vx = v.x, vy = v.y, vz = v.z;
+                if (a.kick) {
+                    const mixed c = fscale * v.w;
+                    vx += c * (mixed)a.force[i]; vy += c * (mixed)a.force[i + a.padded]; vz += c * (mixed)a.force[i + 2 * a.padded];
+                }
+                const mixed m = rcp_(v.w);
+                sx += (double)(vx * m); sy += (double)(vy * m); sz += (double)(vz * m); sm += (double)m;
+            }
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); sm = wave_sum(sm);
+        if (lane == 0) { sred[wv][0] = sx; sred[wv][1] = sy; sred[wv][2] = sz; sred[wv][3] = sm; }
+        __syncthreads();
+        if (tid == 0) {
+            double x = 0, y = 0, z = 0, m = 0;
+            for (int w = 0; w < BLOCK / 64; w++) { x += sred[w][0]; y += sred[w][1]; z += sred[w][2]; m += sred[w][3]; }
+            const double wi = 1.0 / m;
+            x *= wi; y *= wi; z *= wi;
+            reinterpret_cast<mixed4*>(a.big_com)[b] = mk4((mixed)x, (mixed)y, (mixed)z, (mixed)wi);
+            for (int k = 0; k < a.NT; k++) a.partials[(size_t)b * a.NT + k] = 0.0;
+            const mixed cx = (mixed)x, cy = (mixed)y, cz = (mixed)z, cw = (mixed)wi;     // as the tiles will read it
+            a.partials[(size_t)b * a.NT + a.G] = ((double)cx * cx + (double)cy * cy + (double)cz * cz) / (double)cw;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_big_com(int precision, const BigComArgs& a, hipStream_t s) {
+    int grid = a.n < 1 ? 1 : (a.n > 1024 ? 1024 : a.n);
+    switch (precision) {
+        case TGNH_PREC_SINGLE: hipLaunchKernelGGL((big_com_kernel<TGNH_PREC_SINGLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_MIXED: hipLaunchKernelGGL((big_com_kernel<TGNH_PREC_MIXED>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_DOUBLE: hipLaunchKernelGGL((big_com_kernel<TGNH_PREC_DOUBLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------
 // harness force (bench/test workload; not part of the reference)

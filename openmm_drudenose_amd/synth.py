@@ -169,6 +169,24 @@ def mixed(n_water, n_pairs, temperature=300.0, drude_temperature=1.0, seed=SEED)
                    temperature, drude_temperature, f"mixed-{n_water}w-{n_pairs}ip")
 
 
+def polymer_in_water(n_units, n_water, temperature=300.0, drude_temperature=1.0, seed=SEED):
+    """One long polarizable chain molecule (n_units x [heavy, Drude, H] = 3 n_units slots in ONE molecule, the case of a
+    protein or polymer: longer than a 512-slot tile when n_units > 170) followed by SWM4 waters.
+    Temperature groups: polymer 1, water 0."""
+    rng = np.random.default_rng(seed)
+    pm = np.tile(np.array([12.011 - 0.4, 0.4, 1.008]), n_units)
+    pbase = np.arange(n_units, dtype=np.int64) * 3
+    ppos = np.repeat(np.stack([0.15 * np.arange(n_units), np.zeros(n_units), -1.0 * np.ones(n_units)], 1), 3, axis=0)
+    ppos += np.tile(np.array([[0, 0, 0], [0, 0, 0], [0.0, 0.1, 0.0]]), (n_units, 1))
+    wm, wpd, wpp, wres, wpos = _molecules(n_water, _W_TEST, 0.31)
+    n0 = pm.shape[0]
+    mass = np.r_[pm, wm]
+    group = np.r_[np.ones(n0, np.int32), np.zeros(wm.shape[0], np.int32)]
+    resid = np.r_[np.zeros(n0, np.int64), 1 + wres]
+    return _finish(mass, np.r_[pbase + 1, n0 + wpd], np.r_[pbase, n0 + wpp], resid, np.r_[ppos, wpos], group, 2, rng,
+                   temperature, drude_temperature, f"polymer{n_units}-water{n_water}")
+
+
 def single_pair():
     """platforms/reference/tests/TestReferenceDrudeTGNHIntegrator.cpp:54-83 (testSinglePair)."""
     s = DrudeSystem(mass=np.array([1.0, 0.1]), pair_drude=np.array([1]), pair_parent=np.array([0]),

@@ -35,6 +35,7 @@ def bind_groups(it, group, ngroups):
 
 
 SYSTEMS = {
+    "polymer": lambda: synth.polymer_in_water(700, 300),       # one 2100-slot molecule (longer than a tile) + waters
     "pair+normal+massless": lambda: synth.pair_normal_massless(),
     "water27": lambda: synth.water_box(27),
     "water1000": lambda: synth.water_box(1000),
@@ -160,6 +161,9 @@ CASES = [
     ("mixed", "TGNH", 3, True, True, 0.0),
     ("mixed", "TGNH", 2, True, False, 0.0),
     ("mixed", "dualNH", 2, True, True, 0.0),
+    ("polymer", "TGNH", 1, True, True, 0.0),              # molecule longer than a tile: COM from big_com_kernel
+    ("polymer", "TGNH", 3, True, True, 0.0),
+    ("polymer", "dualNH", 1, True, True, 0.0),
 ]
 
 
@@ -268,11 +272,12 @@ def test_single_precision_deviation():
 # ---------------------------------------------------------------------------
 # fused / split / lazy variants are the same integrator
 # ---------------------------------------------------------------------------
+@pytest.mark.parametrize("sysname", ["mixed", "polymer"])
 @pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
 @pytest.mark.parametrize("flags", [FLAG_MERGE_SCALE_KE, FLAG_DEFER_SCALE])
-def test_merged_and_deferred_rescale_match_plain(mode, flags):
-    ref = make("mixed", mode, "double")
-    alt = make("mixed", mode, "double", flags=flags)
+def test_merged_and_deferred_rescale_match_plain(mode, flags, sysname):
+    ref = make(sysname, mode, "double")
+    alt = make(sysname, mode, "double", flags=flags)
     ref[4].step(60)
     alt[4].step(60)
     assert rel_err(alt[4].getPositions(), ref[4].getPositions()) < 1e-11

@@ -104,10 +104,23 @@ def test_unsupported_topologies_fail_loudly():
     m = s.mass.copy(); m[0] = 0.0                               # massless parent: the reference divides by it
     with pytest.raises(TgnhError, match="massless"):
         HostTopology(type(s)(mass=m, pair_drude=s.pair_drude, pair_parent=s.pair_parent, resid=s.resid), integ())
-    big = synth.DrudeSystem(mass=np.ones(600), pair_drude=np.array([1]), pair_parent=np.array([0]), resid=np.zeros(600, np.int32))
-    with pytest.raises(TgnhError, match="spans more than one"):  # one 600-slot molecule
-        HostTopology(big, integ())
-    HostTopology(big, integ(), mode="dualNH").close()           # no COM needed: tiles may cut the molecule
+    far = synth.DrudeSystem(mass=np.ones(1300), pair_drude=np.array([1200]), pair_parent=np.array([0]), resid=np.zeros(1300, np.int32))
+    with pytest.raises(TgnhError, match="spans more than one"):  # Drude 1200 slots away from its parent
+        HostTopology(far, integ())
+
+
+def test_molecule_longer_than_a_tile_is_tiled_with_a_com_table():
+    s, g, ng = synth.polymer_in_water(400, 50)                  # one 1200-slot molecule + 50 waters
+    t = HostTopology(s, integ(group=g, ngroups=ng))
+    ts = t.topology(7)
+    assert np.all(np.diff(ts) <= 512) and ts[-1] == s.num_particles
+    tile_of = np.searchsorted(ts, np.arange(s.num_particles), side="right") - 1
+    assert np.all(tile_of[s.pair_drude] == tile_of[s.pair_parent])          # pairs are never cut
+    assert len(set(tile_of[:1200])) >= 3                                     # the long molecule spans tiles
+    for r in range(1, s.num_residues):                                        # the waters do not
+        assert len(set(tile_of[s.resid == r])) == 1
+    o = make_oracle(s, g, ng, "TGNH", integ(group=g, ngroups=ng))
+    assert np.allclose(t.dof()[0], o.dof()[0], rtol=1e-14)
 
 
 def test_host_only_handle_cannot_launch():
