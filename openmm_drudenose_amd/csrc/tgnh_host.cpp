@@ -70,7 +70,7 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
         for (int i = 0; i < N; i++)
             if (c->group[i] < 0 || c->group[i] >= d->num_groups) return fail(TGNH_ERR_ARG, "temperature group index out of range");
         if (d->num_groups > MAX_GROUPS)
-            return fail(TGNH_ERR_UNSUPPORTED, "more than 8 temperature groups are not supported by this build");
+            return fail(TGNH_ERR_UNSUPPORTED, "more than 32 temperature groups are not supported by this build");
         for (int i = 0; i < d->num_constraints; i++) {                        // Cu :186-193
             if (!d->constraint_i || !d->constraint_j) break;
             const int a = d->constraint_i[i], b = d->constraint_j[i];
@@ -396,6 +396,8 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     if (d->mode == TGNH_MODE_TGNH && (d->num_groups < 1 || d->num_residues < 1 || !d->group || !d->resid))
         return fail(TGNH_ERR_ARG, "TGNH mode needs temperature groups and residues");
     if (d->max_drude_distance < 0) return fail(TGNH_ERR_ARG, "setMaxDrudeDistance: Distance cannot be negative");   // API :98-99
+    if (d->mode == TGNH_MODE_DUALNH && d->num_pairs == 0)   // Ref :181 reads pairParticles[0]; its chain divides by the Drude thermostat mass 0
+        return fail(TGNH_ERR_UNSUPPORTED, "dualNH mode needs at least one Drude pair (the Reference platform does too)");
     if (d->step_size <= 0) return fail(TGNH_ERR_ARG, "step size must be positive");
     {   // the chain kernel keeps chains longer than 4 links in a 2048-double LDS scratch
         const long need = d->mode == TGNH_MODE_TGNH ? (long)(d->num_groups + 2) * (4L * d->num_nh_chains + 1)
@@ -447,7 +449,7 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         HIP_OK(hipGetDeviceProperties(&prop, d->device));
         c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    c->gb = c->L.G <= 1 ? 1 : (c->L.G <= 4 ? 4 : 8);
+    c->gb = c->L.G <= 1 ? 1 : (c->L.G <= 4 ? 4 : (c->L.G <= 8 ? 8 : 0));   // 0: KE bins in LDS
     {   // one-link chains run inside the rescale launch (TGNH_INLINE_CHAIN=0 keeps the separate chain launch)
         const char* e = getenv("TGNH_INLINE_CHAIN");
         c->inline_chain = c->L.C == 1 && c->L.mode == TGNH_MODE_TGNH && !(e && e[0] == '0');
@@ -620,7 +622,8 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
         flip = true;
     }
     if ((ops & (OP_POSDELTA | OP_MOVE)) && !h->pos_delta) return fail(TGNH_ERR_STATE, "posDelta buffer not bound");
-    const size_t lds = tile_lds_bytes(h->d.precision, ops, a.hardwall != 0, a.use_com != 0);
+    size_t lds = tile_lds_bytes(h->d.precision, ops, a.hardwall != 0, a.use_com != 0);
+    if ((ops & OP_KE) && h->gb == 0) lds += sizeof(double) * (TBLOCK / 64) * h->L.G;   // per-wave group bins
     const int grid = grid_for(h, ops, a.hardwall != 0, lds);
     if (ops & OP_KE) {
         h->ke_parts = grid;

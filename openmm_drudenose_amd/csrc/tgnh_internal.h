@@ -32,7 +32,7 @@ constexpr int SPT = TGNH_SPT;                // slots per thread
 constexpr int TILE_SLOTS = TBLOCK * SPT;      // 512 at SPT = 2
 constexpr int TILE_RES = TILE_SLOTS / 2;     // residues per tile the LDS COM table holds
 constexpr int GRID_CAP = 2048;               // upper bound of the persistent grid (256 CUs x 8 work-groups)
-constexpr int MAX_GROUPS = 8;                // per-thread KE bins are registers (GB template 1/4/8)
+constexpr int MAX_GROUPS = 32;               // temperature groups; <= 8: per-lane register KE bins (GB template 1/4/8), else per-wave LDS bins (GB 0)
 
 // ---- packed per-slot topology word ----------------------------------------
 //  bits  0..1  role: 0 normal, 1 Drude particle (pair.x), 2 parent (pair.y)

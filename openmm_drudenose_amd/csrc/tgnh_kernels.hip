@@ -111,9 +111,15 @@ __global__ __launch_bounds__(TBLOCK) void tile_kernel(const TileArgs a) {
     float4* __restrict__ pcorr = reinterpret_cast<float4*>(a.posq_corr);
     mixed4* __restrict__ pdelta = reinterpret_cast<mixed4*>(a.pos_delta);
 
-    double ke_g[GB];
+    constexpr int GBR = GB > 0 ? GB : 1;
+    double ke_g[GBR];
 #pragma unroll
-    for (int b = 0; b < GB; b++) ke_g[b] = 0.0;
+    for (int b = 0; b < GBR; b++) ke_g[b] = 0.0;
+    // more than 8 groups: one row of fp64 bins per wavefront in LDS, behind the images (GB == 0)
+    double* wbins = reinterpret_cast<double*>(sx + (hardwall ? TILE_SLOTS : 0)) + (tid >> 6) * G;
+    if (DO_KE && GB == 0) {
+        for (int g = tid & 63; g < G; g += 64) wbins[g] = 0.0;
+    }
     double ke_com = 0.0, ke_drude = 0.0;
 
     const mixed dt = (mixed)a.dt;
@@ -473,8 +479,23 @@ __global__ __launch_bounds__(TBLOCK) void tile_kernel(const TileArgs a) {
                     val = (cmx * cmx + cmy * cmy + cmz * cmz) * (mass1 + mass2);
                     ke_drude += (rlx * rlx + rly * rly + rlz * rlz) * (1.0 / invRed);
                 }
+                if constexpr (GB > 0) {
 #pragma unroll
-                for (int b = 0; b < GB; b++) ke_g[b] += (g == (uint32_t)b) ? val : 0.0;
+                    for (int b = 0; b < GB; b++) ke_g[b] += (g == (uint32_t)b) ? val : 0.0;
+                } else {
+                    // one pass per distinct group present in this wavefront (usually 1-3): butterfly-sum the lanes of
+                    // that group, lane 0 adds the sum to the wave's LDS bin.  The order depends on the data only.
+                    const bool has = role == ROLE_DRUDE || (role == ROLE_NORMAL && v[k].w != 0);
+                    unsigned long long rem = __ballot(has);
+                    while (rem) {
+                        const int src = __ffsll((long long)rem) - 1;
+                        const uint32_t g0 = __shfl(g, src, 64);
+                        const bool mine = has && g == g0;
+                        const double sg = wave_sum(mine ? val : 0.0);
+                        if ((tid & 63) == 0) wbins[g0] += sg;
+                        rem &= ~__ballot(mine);
+                    }
+                }
             }
             lds_read = true;
         }
@@ -488,6 +509,7 @@ __global__ __launch_bounds__(TBLOCK) void tile_kernel(const TileArgs a) {
         const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
         for (int b = 0; b < GB; b++) ke_g[b] = wave_sum(ke_g[b]);
+        if (GB == 0) __syncthreads();                                // every wave's LDS bins are final
         ke_com = wave_sum(ke_com);
         ke_drude = wave_sum(ke_drude);
         if (lane == 0) {
@@ -504,6 +526,15 @@ __global__ __launch_bounds__(TBLOCK) void tile_kernel(const TileArgs a) {
             const int NT = G + 2;
             if (tid < GB) { if (tid < G) a.partials[(size_t)blockIdx.x * NT + tid] = s; }
             else a.partials[(size_t)blockIdx.x * NT + G + (tid - GB)] = s;
+        }
+        if (GB == 0) {
+            const double* w0 = reinterpret_cast<const double*>(sx + (hardwall ? TILE_SLOTS : 0));
+            for (int g = tid; g < G; g += TBLOCK) {
+                double s = 0.0;
+#pragma unroll
+                for (int w = 0; w < TBLOCK / 64; w++) s += w0[w * G + g];     // fixed order
+                a.partials[(size_t)blockIdx.x * (G + 2) + g] = s;
+            }
         }
     }
 }
@@ -558,8 +589,11 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
                 }
             }
         }
-        for (int p = tid; p < a.nbig; p += BLOCK)                    // rows of the molecules longer than a tile
-            for (int b = 0; b < NT; b++) acc[b] += a.partials[((size_t)GRID_CAP + p) * NT + b];
+        for (int p = tid; p < a.nbig; p += BLOCK) {                  // rows of the molecules longer than a tile
+#pragma unroll
+            for (int b = 0; b < MAX_GROUPS + 2; b++)
+                if (b < NT) acc[b] += a.partials[((size_t)GRID_CAP + p) * NT + b];
+        }
 #pragma unroll
         for (int b = 0; b < MAX_GROUPS + 2; b++) {
             if (b < NT) {
@@ -768,6 +802,7 @@ typedef void (*tile_fn_t)(const TileArgs);
 template <int PREC, int OPS>
 static tile_fn_t tile_fn_gb(int gb) {
     if constexpr ((OPS & OP_KE) != 0) {
+        if (gb == 0) return tile_kernel<PREC, OPS, 0>;
         if (gb <= 1) return tile_kernel<PREC, OPS, 1>;
         if (gb <= 4) return tile_kernel<PREC, OPS, 4>;
         return tile_kernel<PREC, OPS, 8>;

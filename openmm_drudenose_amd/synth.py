@@ -187,6 +187,12 @@ def polymer_in_water(n_units, n_water, temperature=300.0, drude_temperature=1.0,
                    temperature, drude_temperature, f"polymer{n_units}-water{n_water}")
 
 
+def many_groups(n_water, n_pairs, num_groups, **kw):
+    """The mixed system with `num_groups` temperature groups dealt out per molecule (molecule index mod num_groups)."""
+    s, _, _ = mixed(n_water, n_pairs, **kw)
+    return s, np.ascontiguousarray(s.resid % num_groups, np.int32), int(num_groups)
+
+
 def single_pair():
     """platforms/reference/tests/TestReferenceDrudeTGNHIntegrator.cpp:54-83 (testSinglePair)."""
     s = DrudeSystem(mass=np.array([1.0, 0.1]), pair_drude=np.array([1]), pair_parent=np.array([0]),

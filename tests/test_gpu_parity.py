@@ -35,6 +35,8 @@ def bind_groups(it, group, ngroups):
 
 
 SYSTEMS = {
+    "groups12": lambda: synth.many_groups(300, 20, 12),         # > 8 groups: KE bins in LDS
+    "groups32": lambda: synth.many_groups(300, 20, 32),
     "polymer": lambda: synth.polymer_in_water(700, 300),       # one 2100-slot molecule (longer than a tile) + waters
     "pair+normal+massless": lambda: synth.pair_normal_massless(),
     "water27": lambda: synth.water_box(27),
@@ -117,7 +119,7 @@ def test_group_mismatch_is_an_error():
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
 @pytest.mark.parametrize("precision,tol", [("double", 1e-12), ("mixed", 1e-12), ("single", 1e-6)])
-@pytest.mark.parametrize("sysname", ["pair+normal+massless", "il40", "mixed"])
+@pytest.mark.parametrize("sysname", ["pair+normal+massless", "il40", "mixed", "groups12", "groups32", "polymer"])
 def test_kinetic_energies(sysname, mode, precision, tol):
     s, g, ng, it, ctx = make(sysname, mode, precision)
     o = make_oracle(s, g, ng, mode, it)
@@ -161,6 +163,8 @@ CASES = [
     ("mixed", "TGNH", 3, True, True, 0.0),
     ("mixed", "TGNH", 2, True, False, 0.0),
     ("mixed", "dualNH", 2, True, True, 0.0),
+    ("groups12", "TGNH", 1, True, True, 0.0),             # 12 and 32 temperature groups
+    ("groups32", "TGNH", 2, True, True, 0.02),
     ("polymer", "TGNH", 1, True, True, 0.0),              # molecule longer than a tile: COM from big_com_kernel
     ("polymer", "TGNH", 3, True, True, 0.0),
     ("polymer", "dualNH", 1, True, True, 0.0),
@@ -242,6 +246,32 @@ def test_100_step_parity_hardwall(mode, precision):
     ctx.close()
 
 
+def test_system_without_drude_pairs_and_single_particle():
+    """Edge cases: no pairs at all (the Drude thermostat has zero degrees of freedom, as in the reference its
+    variables go NaN but touch nothing), and a one-particle system."""
+    rng = np.random.default_rng(2)
+    n = 700
+    s = synth.DrudeSystem(mass=rng.uniform(1.0, 30.0, n), pair_drude=np.zeros(0, np.int32), pair_parent=np.zeros(0, np.int32),
+                          resid=np.repeat(np.arange(n // 7), 7), positions=rng.uniform(0, 3, (n, 3)),
+                          velocities=rng.normal(0, 1.0, (n, 3)))
+    it = integ(chains=1)
+    ctx = HipContext(s, it, mode="TGNH", precision="double")
+    o = make_oracle(s, np.zeros(n, np.int32), 1, "TGNH", it)
+    pos_o, vel_o = oracle_run(o, s, 30, x0=ctx.sites())
+    ctx.step(30)
+    assert rel_err(ctx.getPositions(), pos_o) < 1e-12 and rel_err(ctx.getVelocities(), vel_o) < 1e-10
+    ctx.close()
+    one = synth.DrudeSystem(mass=np.array([5.0]), pair_drude=np.zeros(0, np.int32), pair_parent=np.zeros(0, np.int32),
+                            resid=np.array([0]), positions=np.array([[0.1, 0.2, 0.3]]), velocities=np.array([[1.0, -2.0, 0.5]]))
+    it = integ(chains=1, com=False)
+    ctx = HipContext(one, it, mode="TGNH", precision="mixed")
+    o = make_oracle(one, np.zeros(1, np.int32), 1, "TGNH", it)
+    pos_o, vel_o = oracle_run(o, one, 10, x0=ctx.sites())
+    ctx.step(10)
+    assert rel_err(ctx.getPositions(), pos_o) < 1e-9 and rel_err(ctx.getVelocities(), vel_o) < 1e-9
+    ctx.close()
+
+
 def test_hardwall_too_far_flag():
     s, g, ng = synth.water_box(8)
     it = integ(chains=1, hardwall=0.01)
@@ -272,7 +302,7 @@ def test_single_precision_deviation():
 # ---------------------------------------------------------------------------
 # fused / split / lazy variants are the same integrator
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("sysname", ["mixed", "polymer"])
+@pytest.mark.parametrize("sysname", ["mixed", "polymer", "groups12"])
 @pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
 @pytest.mark.parametrize("flags", [FLAG_MERGE_SCALE_KE, FLAG_DEFER_SCALE])
 def test_merged_and_deferred_rescale_match_plain(mode, flags, sysname):

@@ -138,3 +138,23 @@ def test_deferred_rescale_needs_single_group_molecules():
     HostTopology(s, it).close()
     with pytest.raises(TgnhError, match="inside one temperature group"):
         HostTopology(s, integ(group=g, ngroups=2), flags=_lib.FLAG_DEFER_SCALE)
+
+
+def test_no_drude_pairs():
+    """TGNH mode runs without pairs (the Drude thermostat is then inert); dualNH cannot (Ref :181, :472)."""
+    s = synth.DrudeSystem(mass=np.array([12.0, 1.0, 1.0, 16.0]), pair_drude=np.zeros(0, np.int32),
+                          pair_parent=np.zeros(0, np.int32), resid=np.array([0, 0, 0, 1]))
+    t = HostTopology(s, integ())
+    assert np.array_equal(t.topology(0), np.arange(4)) and t.dof()[0][0] == 12 - 6 and t.dof()[0][2] == 0
+    with pytest.raises(TgnhError, match="at least one Drude pair"):
+        HostTopology(s, integ(), mode="dualNH")
+
+
+def test_up_to_32_temperature_groups():
+    s, g, ng = synth.many_groups(100, 8, 32)
+    t = HostTopology(s, integ(group=g, ngroups=ng))
+    o = make_oracle(s, g, ng, "TGNH", integ(group=g, ngroups=ng))
+    assert t.num_thermostats() == 34 and np.allclose(t.dof()[0], o.dof()[0], rtol=1e-14)
+    s, g, ng = synth.many_groups(100, 8, 33)
+    with pytest.raises(TgnhError, match="more than 32 temperature groups"):
+        HostTopology(s, integ(group=g, ngroups=ng))
