@@ -113,3 +113,17 @@ def test_xml_serialization_round_trip():
     assert integ3.getNumTempGroups() == 2 and [integ3.getParticleTempGroup(i) for i in range(4)] == [0, 1, 1, 0]
     with pytest.raises(TgnhError, match="Unsupported version"):
         serialization.deserialize(xml.replace('version="1"', 'version="2"'))
+
+
+def test_cpp_mirror_class(tmp_path):
+    """include/DrudeTGNHIntegratorHip.hpp (C++ host-side mirror of the API class) against the library, host-only."""
+    import subprocess
+    _lib.load()
+    exe = tmp_path / "test_mirror"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "test_mirror.cpp"), "-o", str(exe),
+                    "-L", libdir, "-ldrudetgnh_hip", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
