@@ -130,6 +130,25 @@ def timed_run(ctx, steps, warmup, world, graph_steps=0):
     return dt
 
 
+def device_copy_gbps():
+    """Achievable HBM bandwidth of THIS device: a 1 GiB float4-style device-to-device copy (read + write bytes / time).
+    MI355X boxes differ by ~10 % on streaming kernels; this puts the roofline fraction next to what a copy reaches."""
+    import torch
+    n = 256 * 1024 * 1024
+    a = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * 4 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def kernel_table(ctx):
     from openmm_drudenose_amd import _lib
     rows = {}
@@ -230,6 +249,7 @@ def main():
     local_slots = ctx.n
     ctx.close()
 
+    copy_gbps = device_copy_gbps() if rank == 0 else None
     extra = {}
     if world == 1 and not args.no_extra:
         for prec, var in ((args.precision, "plain"), ("single", "defer")):
@@ -271,7 +291,9 @@ def main():
                          "traffic": pmc_traffic(args.precision, local_slots) if world == 1 else None,
                          "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes, bytes per launch)",
                          "algorithmic_bytes_per_launch": bytes_dom, "avg_launch_us": dom["avg_us"],
-                         "launches_timed": dom["launches"], "timing": dom["where"]},
+                         "launches_timed": dom["launches"], "timing": dom["where"],
+                         "device_copy_GBps": round(copy_gbps, 1),
+                         "frac_of_device_copy": round(achieved / copy_gbps, 4)},
             "kernels": rows,
         }
         if extra:

@@ -318,10 +318,10 @@ static tgnh_status finalize_thermostat(tgnh_context* c) {
     }
     c->h_state = st;
     if (!c->host_only) {
-        for (int b = 0; b < 2; b++)
-            HIP_OK(hipMemcpy(c->d_state_buf[b], st.data(), sizeof(double) * L.total, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(c->d_state, st.data(), sizeof(double) * L.total, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(c->d_stage, st.data(), sizeof(double) * L.total, hipMemcpyHostToDevice));
     }
-    c->chain_pending = false;
+    c->chain_pending = false; c->stage_pending = false;
     c->ke_valid = false; c->scale_pending = false; c->first_half_done = false;
     return TGNH_OK;
 }
@@ -373,7 +373,8 @@ static void free_device(tgnh_context* c) {
     if (c->d_big_table) (void)hipFree(c->d_big_table);
     if (c->d_big_com) (void)hipFree(c->d_big_com);
     if (c->d_partials) (void)hipFree(c->d_partials);
-    for (int b = 0; b < 2; b++) if (c->d_state_buf[b]) (void)hipFree(c->d_state_buf[b]);
+    if (c->d_state) (void)hipFree(c->d_state);
+    if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_scalar) (void)hipFree(c->d_scalar);
     if (c->d_cl_atoms) (void)hipFree(c->d_cl_atoms);
@@ -458,9 +459,8 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         if (host_only) return TGNH_OK;
         HIP_OK(hipMalloc(&c->d_partials, sizeof(double) * (size_t)(c->grid + c->num_big) * c->L.NT));
         HIP_OK(hipMemset(c->d_partials, 0, sizeof(double) * (size_t)(c->grid + c->num_big) * c->L.NT));
-        for (int b = 0; b < 2; b++) HIP_OK(hipMalloc(&c->d_state_buf[b], sizeof(double) * c->L.total));
-        c->state_cur = 0;
-        c->d_state = c->d_state_buf[0];
+        HIP_OK(hipMalloc(&c->d_state, sizeof(double) * c->L.total));
+        HIP_OK(hipMalloc(&c->d_stage, sizeof(double) * c->L.total));
         HIP_OK(hipMalloc(&c->d_status, sizeof(uint32_t)));
         HIP_OK(hipMemset(c->d_status, 0, sizeof(uint32_t)));
 
@@ -597,6 +597,7 @@ static int grid_for(tgnh_handle h, int ops, bool hardwall, size_t lds) {
 }
 
 static ChainArgs chain_args(tgnh_handle h);
+static tgnh_status commit_stage(tgnh_handle h, hipStream_t s);
 
 static tgnh_status run_big_com(tgnh_handle h, bool kick, hipStream_t s) {
     BigComArgs b{};
@@ -612,14 +613,15 @@ static tgnh_status run_big_com(tgnh_handle h, bool kick, hipStream_t s) {
 
 static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, const double* scale = nullptr) {
     TileArgs a = tile_args(h, scale);
-    bool flip = false;
+    bool inline_chain = false;
     if ((ops & OP_SCALE) && h->chain_pending && !scale) {           // this rescale launch runs the chain itself
+        if (h->stage_pending) { tgnh_status rc = commit_stage(h, s); if (rc) return rc; }
         a.chain_on = 1;
         a.chain = chain_args(h);
         a.chain.chain_twice = h->chain_pending_twice ? 1 : 0;
-        a.st_in = h->d_state_buf[h->state_cur];
-        a.st_out = h->d_state_buf[h->state_cur ^ 1];
-        flip = true;
+        a.st_in = h->d_state;
+        a.st_out = h->d_stage;
+        inline_chain = true;
     }
     if ((ops & (OP_POSDELTA | OP_MOVE)) && !h->pos_delta) return fail(TGNH_ERR_STATE, "posDelta buffer not bound");
     size_t lds = tile_lds_bytes(h->d.precision, ops, a.hardwall != 0, a.use_com != 0);
@@ -638,11 +640,7 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
         Timed t(h, s, kid);
         HIP_OK(launch_tile(h->d.precision, ops, h->gb, a, grid, lds, s));
     }
-    if (flip) {                                                      // the other copy now holds the advanced thermostat
-        h->state_cur ^= 1;
-        h->d_state = h->d_state_buf[h->state_cur];
-        h->chain_pending = false;
-    }
+    if (inline_chain) { h->chain_pending = false; h->stage_pending = true; }   // d_stage now holds the advanced thermostat
     return TGNH_OK;
 }
 
@@ -652,7 +650,19 @@ static ChainArgs chain_args(tgnh_handle h) {
     a.nbig = h->num_big;
     a.dt = h->d.step_size; a.S = h->d.drude_steps_per_real_step;
     a.realkbT = h->realkbT; a.drudekbT = h->drudekbT;
+    a.stage = h->d_stage;
+    a.commit = h->stage_pending ? 1 : 0;     // every chain_kernel launch takes over a staged block first
+    h->stage_pending = false;
     return a;
+}
+
+// a staged block with no chain_kernel launch coming up: commit it by a launch that does nothing else
+static tgnh_status commit_stage(tgnh_handle h, hipStream_t s) {
+    if (!h->stage_pending) return TGNH_OK;
+    ChainArgs a = chain_args(h);
+    a.do_sum = 0; a.do_chain = 0;
+    HIP_OK(launch_chain(a, s));
+    return TGNH_OK;
 }
 
 // sum the work-group partials, all-reduce across ranks when sharded, run the chain
@@ -672,7 +682,7 @@ static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
         { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
         if (h->allreduce(h->d_state + h->L.off_ke_red, h->L.NT, (void*)s, h->allreduce_user) != 0)
             return fail(TGNH_ERR_HIP, "all-reduce hook failed");
-        a.do_sum = 0; a.do_chain = 1;
+        a.do_sum = 0; a.do_chain = 1; a.commit = 0;
         { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
     } else {
         a.do_sum = 1; a.do_chain = 1;
@@ -684,7 +694,7 @@ static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
 
 // a chain that is still waiting for its rescale launch is run now, in place, by the standalone kernel
 static tgnh_status materialize_chain(tgnh_handle h, hipStream_t s) {
-    if (!h->chain_pending) return TGNH_OK;
+    if (!h->chain_pending) return commit_stage(h, s);
     ChainArgs a = chain_args(h);
     a.do_sum = 0; a.do_chain = 1; a.chain_twice = h->chain_pending_twice ? 1 : 0;
     { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }

@@ -82,6 +82,8 @@ struct ChainArgs {
     const double* partials;    // [nparts][NT] rows of the tile work-groups, then [nbig][NT] rows at GRID_CAP
     int nparts;
     int nbig;
+    const double* stage;       // commit != 0: copy this block over st first (an in-kernel chain left it there)
+    int commit;
     int do_sum;                // sum partials -> ke_red
     int do_chain;              // run the chain from ke_red
     int chain_twice;           // DEFER_SCALE: second half of step n and first half of step n+1 back to back
@@ -113,7 +115,8 @@ struct TileArgs {
     double max_dist;
     double hw_scale;           // sqrt(kB*T_drude)
     // in-kernel chain (numNHChains == 1): every work-group derives the scale factors from the summed kinetic
-    // energies itself, work-group 0 writes the advanced thermostat block to the OTHER copy (double buffer)
+    // energies itself; work-group 0 writes the advanced thermostat block to a staging copy (work-groups of this
+    // launch may start after work-group 0 has finished, so st_in must stay untouched); the next chain_kernel commits it
     int chain_on;
     const double* st_in;
     double* st_out;
@@ -184,9 +187,9 @@ struct tgnh_context {
     int* d_tile_res = nullptr;
     int2* d_res_table = nullptr;
     double* d_partials = nullptr;
-    double* d_state = nullptr;        // thermostat block (the current one of the two copies)
-    double* d_state_buf[2] = {nullptr, nullptr};
-    int state_cur = 0;
+    double* d_state = nullptr;        // thermostat block
+    double* d_stage = nullptr;        // same layout: where an in-kernel chain leaves the advanced block
+    bool stage_pending = false;       // d_stage is newer than d_state; the next chain_kernel launch commits it
     bool chain_pending = false, chain_pending_twice = false;   // summed KE waits for the next rescale launch to run the chain
     bool inline_chain = false;        // numNHChains == 1: the chain runs inside the rescale launch
     uint32_t* d_status = nullptr;

@@ -83,8 +83,11 @@ size_t tile_lds_bytes(int precision, int ops, bool hardwall, bool use_com) {
 // ---------------------------------------------------------------------------
 // tile_kernel
 // ---------------------------------------------------------------------------
+#ifndef TGNH_MINWAVES
+#define TGNH_MINWAVES 1
+#endif
 template <int PREC, int OPS, int GB>
-__global__ __launch_bounds__(TBLOCK) void tile_kernel(const TileArgs a) {
+__global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileArgs a) {
     typedef typename Prec<PREC>::real real;
     typedef typename Prec<PREC>::mixed mixed;
     typedef typename Prec<PREC>::real4 real4;
@@ -181,9 +184,9 @@ __global__ __launch_bounds__(TBLOCK) void tile_kernel(const TileArgs a) {
                 if (tid < NT - 1) itg = tid;
                 else if (tid == 64) itg = NT - 1;
                 if (itg >= 0) run_tgnh<1, false>(a.chain, a.st_in, a.st_out, write, s_scale, itg, nullptr, a.st_in[L.off_ke_red + itg]);
-                if (write && tid == 128) {                           // Cu :493-497 + carry the sums over
+                if (write && tid == 128) {                           // Cu :493-497
                     double s = 0.0;
-                    for (int i = 0; i < NT; i++) { const double k = a.st_in[L.off_ke_red + i]; s += k; a.st_out[L.off_ke_red + i] = k; }
+                    for (int i = 0; i < NT; i++) s += a.st_in[L.off_ke_red + i];
                     a.st_out[L.off_kesum] = 0.5 * s;
                 }
             }   // (dualNH keeps the separate chain launch: its coupled vectors would cost this kernel ~50 VGPRs)
@@ -557,6 +560,11 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
     const ChainLayout& L = a.L;
     const int NT = L.NT, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double* st = a.st;
+    if (a.commit) {                  // take over the block an in-kernel chain staged (everything but the KE sums)
+        for (int i = tid; i < L.total; i += BLOCK)
+            if (i < L.off_ke_red || i >= L.off_ke_red + NT) st[i] = a.stage[i];
+        __syncthreads();
+    }
     if (a.do_sum) {
         // Fixed-order sum of the work-group partials: lane `tid` owns partials tid, tid+256, ...; every load of a
         // lane is issued before the first add (one memory latency, not one per partial), then a 64-lane butterfly

@@ -337,11 +337,13 @@ def test_100_step_parity_deferred_rescale(mode, precision):
     ctx.close()
 
 
+@pytest.mark.parametrize("chains", [1, 3])          # 1: the chain runs inside the rescale launch (staged block + commit)
 @pytest.mark.parametrize("flags", [0, FLAG_DEFER_SCALE])
-def test_graph_replay_matches_eager(flags):
-    """hipGraph capture of the step loop (HipContext.capture_steps) replays the very same launches: bitwise equal."""
-    ref = make("mixed", "TGNH", "mixed", flags=flags, hardwall=0.02)
-    alt = make("mixed", "TGNH", "mixed", flags=flags, hardwall=0.02)
+def test_graph_replay_matches_eager(flags, chains):
+    """hipGraph capture of the step loop (HipContext.capture_steps) replays the very same launches: bitwise equal.
+    Five steps per graph on purpose: nothing in the captured launch arguments may alternate between replays."""
+    ref = make("mixed", "TGNH", "mixed", flags=flags, hardwall=0.02, chains=chains)
+    alt = make("mixed", "TGNH", "mixed", flags=flags, hardwall=0.02, chains=chains)
     ref[4].step(3 + 4 * 5)
     alt[4].step(3)
     replay = alt[4].capture_steps(5)
