@@ -298,6 +298,7 @@ class HipContext(_HandleQueries):
                                           self.velm.data_ptr(), self.force.data_ptr(), self.pos_delta.data_ptr()))
         integrator._context = self
         self.force_fn = None
+        self.state_hook = None
         self.ke_sum_valid = False
         self.constrained = False
         if system.cluster_atoms is not None and len(system.cluster_atoms):
@@ -449,10 +450,27 @@ class HipContext(_HandleQueries):
             if steps > 0:
                 self.ke_sum_valid = True
             return
+        # caller-supplied force call-out (and, optionally, a state hook: Context::updateContextState, e.g. CMMotionRemover)
+        lib, h = self.lib, self.h
         for _ in range(steps):
-            self.step_begin()
-            self.compute_forces()
-            self.step_end()
+            if self.state_hook is not None:
+                self.state_hook(self)                                   # DrudeTGNHIntegrator.cpp:186
+            if not self.constrained:
+                self.step_begin()
+                self.compute_forces()
+                self.step_end()
+                continue
+            tol = self.integrator.getConstraintTolerance()
+            _check(lib.tgnh_step_begin_kick(h, self._stream()))          # Cu :336-360
+            _check(lib.tgnh_harness_shake_positions(h, tol, self._stream()))   # Cu :363
+            _check(lib.tgnh_step_begin_move(h, self._stream()))          # Cu :366-376
+            _check(lib.tgnh_harness_virtual_sites(h, self._stream()))    # Cu :377
+            self.compute_forces()                                        # Cu :380
+            _check(lib.tgnh_step_end_kick(h, self._stream()))            # Cu :384-388
+            if self.mode == MODE_TGNH:
+                _check(lib.tgnh_harness_shake_velocities(h, tol, self._stream()))   # Cu :391
+            _check(lib.tgnh_step_end_thermo(h, self._stream()))          # Cu :394-406
+            self.ke_sum_valid = True
 
     def capture_steps(self, steps):
         """Captures `steps` time steps (harness force call-out included, and the KE all-reduce when sharded) into

@@ -26,7 +26,7 @@ class _Desc(C.Structure):
 
 
 def build_oracle(force=False):
-    src = [os.path.join(HERE, f) for f in ("tgnh_oracle.c", "tgnh_oracle.h", "Makefile")]
+    src = [os.path.join(HERE, f) for f in ("tgnh_oracle.c", "tgnh_oracle.h", "water_ff.c", "Makefile")]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
         subprocess.run(["make", "-C", HERE, "-B" if force else "-s", "libtgnh_oracle.so"], check=True,
                        stdout=subprocess.DEVNULL)
@@ -73,6 +73,8 @@ def _load():
         L.tgo_set_virtual_sites.argtypes = [C.c_void_p, C.c_int, _i32p, _f64p]
         L.tgo_virtual_sites.argtypes = [C.c_void_p, _f64p]
         L.tgo_run_harness_constrained.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_double, C.c_int]
+        L.tgo_water_forces.argtypes = [C.c_int, _f64p, C.c_double, C.c_double, _f64p]
+        L.tgo_water_forces.restype = C.c_double
         L.tgo_time.argtypes = [C.c_void_p]
         L.tgo_time.restype = C.c_double
         L.tgo_step_count.argtypes = [C.c_void_p]
@@ -254,3 +256,12 @@ class Oracle:
 
     def time(self): return self.L.tgo_time(self.h)
     def step_count(self): return self.L.tgo_step_count(self.h)
+
+
+def water_forces(pos, box, cutoff=1.0):
+    """Forces (and energy) of the reference's testWater force field (oracle/water_ff.c) for N/5 SWM4 molecules."""
+    L = _load()
+    pos = np.ascontiguousarray(pos, np.float64)
+    f = np.zeros_like(pos)
+    e = L.tgo_water_forces(pos.shape[0] // 5, _p(pos), box, cutoff, _p(f))
+    return f, e

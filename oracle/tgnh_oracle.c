@@ -1,7 +1,7 @@
 /*
  * tgnh_oracle.c -- CPU oracle for the DrudeTGNHIntegrator per-timestep path.
  *
- * TEST INFRASTRUCTURE ONLY (see tgnh_oracle.h).  PARITY UNPINNED (ibid.).
+ * TEST INFRASTRUCTURE ONLY (see tgnh_oracle.h).  Pin status: statistical only (ibid.).
  *
  * Citations: "Ref" = platforms/reference/src/ReferenceDrudeTGNHKernels.cpp,
  *            "Cu"  = platforms/cuda/src/CudaDrudeTGNHKernels.cpp,
