@@ -152,7 +152,12 @@ tgnh_status tgnh_note_replayed_steps(tgnh_handle h, int nsteps);
  * barostat): cached kinetic energies are stale.  DrudeTGNHIntegrator.cpp:166-170 */
 tgnh_status tgnh_state_changed(tgnh_handle h);
 
-/* Host-visible results (synchronise `stream`). */
+/* Host-visible results (synchronise `stream`).
+ * tgnh_get_kinetic_energy: TGNH mode = the cached 1/2 sum of the last thermostat half step's bins when ke_sum_valid,
+ * else 1/2 sum m v^2 (CudaDrudeTGNHKernels.cpp:654-658).  DUALNH mode = 1/2 sum m (v + F dt/2m)^2, the Reference
+ * platform's half-step-shifted energy (ReferenceDrudeTGNHKernels.cpp:70-98) WITHOUT its constraint projection, which is
+ * a call-out to the host's constraint solver: with constraints present project the shifted velocities first
+ * (tests/test_reference_water_gpu.py::reference_platform_kinetic_energy shows the sequence). */
 tgnh_status tgnh_get_kinetic_energy(tgnh_handle h, int ke_sum_valid, void* stream, double* out);
 tgnh_status tgnh_get_num_thermostats(tgnh_handle h, int* count);               /* NT: TGNH G+2 = [groups.., COM, Drude]; DUALNH 3 = [real, unused, Drude] */
 tgnh_status tgnh_get_last_kinetic_energies(tgnh_handle h, void* stream, double* ke);   /* no 1/2; before the chain */
