@@ -451,9 +451,12 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     c->gb = c->L.G <= 1 ? 1 : (c->L.G <= 4 ? 4 : (c->L.G <= 8 ? 8 : 0));   // 0: KE bins in LDS
-    {   // one-link chains run inside the rescale launch (TGNH_INLINE_CHAIN=0 keeps the separate chain launch)
+    {   // One-link chains can run inside the rescale launch.  That trades a ~10 us launch for ~5 us of every
+        // work-group's start: a gain when launches are short (a shard of a sharded run), a wash at millions of slots,
+        // where it only makes the streaming launch look slower.  Default: below 1.5 M slots.  TGNH_INLINE_CHAIN=0/1 forces.
         const char* e = getenv("TGNH_INLINE_CHAIN");
-        c->inline_chain = c->L.C == 1 && c->L.mode == TGNH_MODE_TGNH && !(e && e[0] == '0');
+        const bool want = e ? e[0] != '0' : d->num_particles < 1500000;
+        c->inline_chain = c->L.C == 1 && c->L.mode == TGNH_MODE_TGNH && want;
     }
     auto alloc = [&]() -> tgnh_status {
         if (host_only) return TGNH_OK;

@@ -103,6 +103,20 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
     mixed4* sv = reinterpret_cast<mixed4*>(smem);        // [TILE_SLOTS] velocity image
     mixed4* scom = sv + TILE_SLOTS;                      // [TILE_RES]   molecular COM velocity, w = 1/M
     mixed4* sx = scom + TILE_RES;                        // [TILE_SLOTS] position image (hard wall only)
+    // fp64 images are kept component-wise (x[], y[], z[], w[]): a 32-byte double4 per lane is a 2-way bank conflict on
+    // every ds_read/ds_write_b128 and on the per-molecule walk (SQ_LDS_BANK_CONFLICT was 48 % of the LDS cycles);
+    // 8-byte components at lane stride 8 (or 8 x molecule size) are conflict-free.  float4 images stay packed.
+    constexpr bool SOA = sizeof(mixed) == 8;
+    mixed* svc = reinterpret_cast<mixed*>(sv);
+    mixed* sxc = reinterpret_cast<mixed*>(sx);
+    auto st_img = [&](mixed4* img, mixed* imgc, int i, const mixed4& u) {
+        if (SOA) { imgc[i] = u.x; imgc[TILE_SLOTS + i] = u.y; imgc[2 * TILE_SLOTS + i] = u.z; imgc[3 * TILE_SLOTS + i] = u.w; }
+        else img[i] = u;
+    };
+    auto ld_img = [&](const mixed4* img, const mixed* imgc, int i) -> mixed4 {
+        if (SOA) return mk4(imgc[i], imgc[TILE_SLOTS + i], imgc[2 * TILE_SLOTS + i], imgc[3 * TILE_SLOTS + i]);
+        return img[i];
+    };
 
     const int tid = threadIdx.x;
     const bool use_com = a.use_com != 0;
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
         // ---------------- A6: rescale (K :249-301 ; Ref :516-541) ----------------
         if (DO_SCALE) {
 #pragma unroll
-            for (int k = 0; k < SPT; k++) sv[k * TBLOCK + tid] = v[k];
+            for (int k = 0; k < SPT; k++) st_img(sv, svc, k * TBLOCK + tid, v[k]);
             __syncthreads();
             if (use_com) {
                 for (int r = tid; r < nres; r += TBLOCK) {            // K :86-111
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     const int first = rt.y - ts;
                     mixed cx = 0, cy = 0, cz = 0, cm = 0;
                     for (int j = 0; j < rt.x; j++) {
-                        const mixed4 u = sv[first + j];
+                        const mixed4 u = ld_img(sv, svc, first + j);
                         if (u.w != 0) {
                             const mixed m = rcp_(u.w);
                             cx += u.x * m; cy += u.y * m; cz += u.z * m; cm += m;
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     }
                 } else {                                             // K :270-300
                     const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
-                    const mixed4 u = sv[pl];
+                    const mixed4 u = ld_img(sv, svc, pl);
                     const bool is_d = role == ROLE_DRUDE;
                     const mixed4 v1 = is_d ? v[k] : u;               // particles.x (Drude)
                     const mixed4 v2 = is_d ? u : v[k];               // particles.y (parent)
@@ -345,8 +359,8 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
             if (lds_read) __syncthreads();
 #pragma unroll
             for (int k = 0; k < SPT; k++) {
-                sv[k * TBLOCK + tid] = v[k];
-                sx[k * TBLOCK + tid] = mk4(px[k], py[k], pz[k], (mixed)0);
+                st_img(sv, svc, k * TBLOCK + tid, v[k]);
+                st_img(sx, sxc, k * TBLOCK + tid, mk4(px[k], py[k], pz[k], (mixed)0));
             }
             __syncthreads();
             const mixed maxd = (mixed)a.max_dist, hws = (mixed)a.hw_scale;
@@ -356,7 +370,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                 const uint32_t role = m & 3u;
                 if (role != ROLE_NORMAL) {
                     const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
-                    const mixed4 uv = sv[pl], ux = sx[pl];
+                    const mixed4 uv = ld_img(sv, svc, pl), ux = ld_img(sx, sxc, pl);
                     const bool is_d = role == ROLE_DRUDE;
                     const mixed4 vel1 = is_d ? v[k] : uv, vel2 = is_d ? uv : v[k];
                     const mixed p1x = is_d ? px[k] : ux.x, p1y = is_d ? py[k] : ux.y, p1z = is_d ? pz[k] : ux.z;
@@ -433,7 +447,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
         if (DO_KE) {
             if (lds_read) __syncthreads();
 #pragma unroll
-            for (int k = 0; k < SPT; k++) sv[k * TBLOCK + tid] = v[k];
+            for (int k = 0; k < SPT; k++) st_img(sv, svc, k * TBLOCK + tid, v[k]);
             __syncthreads();
             if (use_com) {
                 for (int r = tid; r < nres; r += TBLOCK) {            // K :86-111, :152-158
@@ -442,7 +456,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     const int first = rt.y - ts;
                     mixed cx = 0, cy = 0, cz = 0, cm = 0;
                     for (int j = 0; j < rt.x; j++) {
-                        const mixed4 u = sv[first + j];
+                        const mixed4 u = ld_img(sv, svc, first + j);
                         if (u.w != 0) {
                             const mixed m = rcp_(u.w);
                             cx += u.x * m; cy += u.y * m; cz += u.z * m; cm += m;
@@ -469,7 +483,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     }
                 } else if (role == ROLE_DRUDE) {                     // K :171-186 (one lane per pair)
                     const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
-                    const mixed4 u = sv[pl];
+                    const mixed4 u = ld_img(sv, svc, pl);
                     const double w1 = v[k].w, w2 = u.w;
                     const double r1x = v[k].x - cx, r1y = v[k].y - cy, r1z = v[k].z - cz;
                     const double r2x = u.x - cx, r2y = u.y - cy, r2z = u.z - cz;
