@@ -456,6 +456,8 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         // where it only makes the streaming launch look slower.  Default: below 1.5 M slots.  TGNH_INLINE_CHAIN=0/1 forces.
         const char* e = getenv("TGNH_INLINE_CHAIN");
         const bool want = e ? e[0] != '0' : d->num_particles < 1500000;
+        const char* e3 = getenv("TGNH_ALTERNATE_SWEEPS");
+        c->alternate_sweeps = !(e3 && e3[0] == '0');
         c->inline_chain = c->L.C == 1 && c->L.mode == TGNH_MODE_TGNH && want;
     }
     auto alloc = [&]() -> tgnh_status {
@@ -577,6 +579,7 @@ static TileArgs tile_args(tgnh_handle h, const double* scale) {
     a.scale = scale ? scale : h->d_state + h->L.off_scale;
     a.partials = h->d_partials; a.status = h->d_status;
     a.num_tiles = h->num_tiles; a.padded = h->d.padded_num_particles; a.num_groups = h->L.G;
+    a.reverse = h->sweep_reverse;
     a.use_com = (h->d.mode == TGNH_MODE_TGNH && h->d.use_com_temp_group) ? 1 : 0;
     a.hardwall = h->d.max_drude_distance > 0 ? 1 : 0;                         // Ref :299, Cu :372
     a.dt = h->d.step_size; a.max_dist = h->d.max_drude_distance;
@@ -644,6 +647,7 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
         HIP_OK(launch_tile(h->d.precision, ops, h->gb, a, grid, lds, s));
     }
     if (inline_chain) { h->chain_pending = false; h->stage_pending = true; }   // d_stage now holds the advanced thermostat
+    if (h->alternate_sweeps) h->sweep_reverse ^= 1;      // the next streaming launch starts where this one ends
     return TGNH_OK;
 }
 
@@ -972,6 +976,8 @@ extern "C" tgnh_status tgnh_harness_force(tgnh_handle h, const void* x0, double 
     a.force = reinterpret_cast<long long*>(force_out);
     a.n = h->d.num_particles; a.padded = h->d.padded_num_particles;
     a.k_drude = k_drude; a.k_tether = k_tether;
+    a.reverse = h->sweep_reverse;
+    if (h->alternate_sweeps) h->sweep_reverse ^= 1;
     Timed t(h, (hipStream_t)stream, KID_FORCE);
     HIP_OK(launch_force(h->d.precision, a, (hipStream_t)stream));
     return TGNH_OK;

@@ -107,6 +107,7 @@ struct TileArgs {
     double* partials;          // [grid][NT] per-work-group KE partial sums
     uint32_t* status;          // bit0: Drude beyond 2x hard wall
     int num_tiles;
+    int reverse;               // walk the tiles last-to-first: start where the previous launch ended (its lines are still in the Infinity Cache)
     int padded;
     int num_groups;            // G (internal layout: NT = G+2, [G]=COM, [G+1]=Drude)
     int use_com;
@@ -143,6 +144,7 @@ struct ForceArgs {
     const uint32_t* meta;
     long long* force;
     int n, padded;
+    int reverse;
     double k_drude, k_tether;
 };
 
@@ -190,6 +192,8 @@ struct tgnh_context {
     double* d_state = nullptr;        // thermostat block
     double* d_stage = nullptr;        // same layout: where an in-kernel chain leaves the advanced block
     bool stage_pending = false;       // d_stage is newer than d_state; the next chain_kernel launch commits it
+    int sweep_reverse = 0;            // direction of the next streaming launch (alternates)
+    bool alternate_sweeps = true;
     bool chain_pending = false, chain_pending_twice = false;   // summed KE waits for the next rescale launch to run the chain
     bool inline_chain = false;        // numNHChains == 1: the chain runs inside the rescale launch
     uint32_t* d_status = nullptr;

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
         float4 c[SPT];
         mixed4 pd[SPT];
     };
-    auto load_tile = [&](int t, TileIn& in) {
+    auto load_tile = [&](int tt, TileIn& in) {
+        const int t = a.reverse ? a.num_tiles - 1 - tt : tt;
         in.ts = a.tile_start[t]; in.te = a.tile_start[t + 1];
         in.rs = a.tile_res[t]; in.nres = a.tile_res[t + 1] - in.rs;
 #pragma unroll
@@ -739,8 +740,11 @@ __global__ __launch_bounds__(BLOCK) void force_kernel(const ForceArgs a) {
     const int lane = threadIdx.x & 63;
     // uniform trip count per wavefront so the shuffles below see all 64 lanes
     const int nround = (a.n + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
-    for (int r = 0; r < nround; r++) {
-        const int i = (r * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x;
+    for (int rr = 0; rr < nround; rr++) {
+        // optionally last chunk first (lane order inside a chunk unchanged): start where the previous launch ended
+        const int r = a.reverse ? nround - 1 - rr : rr;
+        const int blk = a.reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+        const int i = (r * gridDim.x + blk) * BLOCK + threadIdx.x;
         const bool in = i < a.n;
         uint32_t m = 0;
         mixed x = 0, y = 0, z = 0;
