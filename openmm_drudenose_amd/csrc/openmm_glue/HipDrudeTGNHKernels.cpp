@@ -5,6 +5,8 @@
 #include "openmm/OpenMMException.h"
 #include "openmm/internal/ContextImpl.h"
 #include "SimTKOpenMMRealType.h"
+#include "openmm/KernelFactory.h"
+#include "openmm/hip/HipPlatform.h"
 #include <typeinfo>
 #include <vector>
 
@@ -130,4 +132,44 @@ double HipIntegrateDrudeTGNHStepKernel::computeKineticEnergy(ContextImpl& contex
     double ke;
     check(tgnh_get_kinetic_energy(handle, 1, (void*) cu.getCurrentStream(), &ke));
     return ke;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Plugin entry points for the OpenMM "HIP" platform.  OpenMM dlopen()s every library in lib/plugins and looks these
+// C symbols up; they are the ones the reference's CUDA plugin exports for its platform
+// (platforms/cuda/src/CudaDrudeTGNHKernelFactory.cpp:37-59).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+class HipDrudeTGNHKernelFactory : public KernelFactory {
+public:
+    KernelImpl* createKernelImpl(std::string name, const Platform& platform, ContextImpl& context) const {
+        HipContext& cu = *static_cast<HipPlatform::PlatformData*>(context.getPlatformData())->contexts[0];
+        if (name == IntegrateDrudeTGNHStepKernel::Name())
+            return new HipIntegrateDrudeTGNHStepKernel(name, platform, cu);
+        throw OpenMMException((std::string("Tried to create kernel with illegal kernel name '")+name+"'").c_str());
+    }
+};
+}
+
+extern "C" OPENMM_EXPORT void registerPlatforms() {
+}
+
+extern "C" OPENMM_EXPORT void registerKernelFactories() {
+    try {
+        Platform& platform = Platform::getPlatformByName("HIP");
+        platform.registerKernelFactory(IntegrateDrudeTGNHStepKernel::Name(), new HipDrudeTGNHKernelFactory());
+    }
+    catch (std::exception& ex) {
+        // no HIP platform in this OpenMM: nothing to register (as the reference does for CUDA)
+    }
+}
+
+extern "C" OPENMM_EXPORT void registerDrudeTGNHHipKernelFactories() {
+    try {
+        Platform::getPlatformByName("HIP");
+    }
+    catch (...) {
+        Platform::registerPlatform(new HipPlatform());
+    }
+    registerKernelFactories();
 }

@@ -184,3 +184,20 @@ def test_reference_testSinglePair_statistics():
     assert ke_int / nsamp == pytest.approx(1.5 * KB * 10.0, rel=0.01)              # (b)
     ratio_c = ke_cm / nsamp / (1.5 * KB * 300.0)                                   # (c) recorded
     assert 0.5 < ratio_c < 1.5
+
+
+def test_oracle_regression_vectors():
+    """tests/golden/oracle_regression.npz: frozen outputs of THIS oracle (not reference outputs -- the reference cannot
+    run here); any edit that changes what the oracle, the synthetic builders or the harness force compute shows up."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_regression_vectors", os.path.join(path, "make_regression_vectors.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    frozen = np.load(os.path.join(path, "oracle_regression.npz"))
+    for name in gen.CASES:
+        now = gen.run(name)
+        for k, v in now.items():
+            ref = frozen[f"{name}/{k}"]
+            assert ref.shape == v.shape and np.allclose(v, ref, rtol=1e-12, atol=1e-14 * max(1.0, np.abs(ref).max())), (name, k)
