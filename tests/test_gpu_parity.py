@@ -449,6 +449,40 @@ def test_shake_call_outs_alone():
     ctx.close()
 
 
+def test_against_committed_regression_vectors():
+    """The HIP path against tests/golden/oracle_regression.npz (the oracle's frozen outputs; data only, so this check
+    does not need the oracle at run time)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_regression_vectors", os.path.join(path, "make_regression_vectors.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    frozen = np.load(os.path.join(path, "oracle_regression.npz"))
+    for name, (build, omode, chains, drude_chains, com, hw, steps) in gen.CASES.items():
+        mode = "TGNH" if omode == 1 else "dualNH"
+        s, g, ng = build()
+        it = integ(chains=chains, drude_chains=drude_chains, com=com, hardwall=hw)
+        if mode == "TGNH":
+            bind_groups(it, g, ng)
+        ctx = HipContext(s, it, mode=mode, precision="double")     # double: tether sites stored exactly, as the oracle had them
+        kes, scs = to_internal(frozen[f"{name}/ke"], mode), to_internal(frozen[f"{name}/scale"], mode)
+        for i in range(steps):
+            ctx.step_begin()
+            assert np.allclose(ctx.last_kinetic_energies(), kes[2 * i], rtol=TOL_KE, atol=TOL_KE * np.abs(kes[2 * i]).max())
+            ctx.compute_forces()
+            ctx.step_end()
+            assert np.allclose(ctx.last_kinetic_energies(), kes[2 * i + 1], rtol=TOL_KE, atol=TOL_KE * np.abs(kes[2 * i + 1]).max())
+            m = np.ones(kes.shape[1], bool)
+            if mode == "dualNH":
+                m[1] = False
+            assert np.abs(ctx.last_scale_factors()[m] - scs[2 * i + 1][m]).max() <= TOL_KE
+        assert rel_err(ctx.getPositions()[:64], frozen[f"{name}/pos64"]) <= TOL
+        assert rel_err(ctx.getVelocities()[:64], frozen[f"{name}/vel64"]) <= TOL
+        assert np.allclose(ctx.thermostat_state(1), frozen[f"{name}/etaDot"], rtol=1e-6, atol=1e-9)
+        ctx.close()
+
+
 def test_thermostat_state_checkpoint_roundtrip():
     s, g, ng, it, a = make("il40", "TGNH", "double")
     a.step(20)
