@@ -449,6 +449,62 @@ def test_shake_call_outs_alone():
     ctx.close()
 
 
+def test_particle_sharded_hip_path_on_one_gpu():
+    """The sharded schedule on the real kernels: two handles on this one GPU own the two halves of the molecules
+    (system.shard_bounds), degrees of freedom are summed over the 'ranks', and the all-reduce hook of each handle
+    adds the other handle's kinetic-energy sums (what RCCL does across GPUs).  The trajectory must be the
+    unsharded one.  (Real multi-GPU runs need the driver's 8-GPU node; the collective itself is torch.distributed's.)"""
+    from openmm_drudenose_amd.system import shard_bounds
+    s, g, ng = synth.mixed(400, 30)
+    it = integ(chains=1, hardwall=0.02)
+    bind_groups(it, g, ng)
+    ref = HipContext(s, it, mode="TGNH", precision="double")
+    b = shard_bounds(s, 2)
+    parts, terms = [], []
+    for r in range(2):
+        loc, lg = s.slice_molecules(b[r], b[r + 1]), g[b[r]:b[r + 1]]
+        itr = integ(chains=1, hardwall=0.02)
+        bind_groups(itr, lg, ng)
+        ctx = HipContext(loc, itr, mode="TGNH", precision="double")
+        parts.append(ctx)
+        terms.append(ctx.local_dof_terms())
+    total = terms[0] + terms[1]
+    assert np.allclose(total, ref.local_dof_terms(), rtol=1e-13)
+    peer = [None, None]                      # peer[r]: the other shard's KE sums for the phase in flight (device tensor)
+    for r, ctx in enumerate(parts):
+        ctx.set_global_dof_terms(total)
+        ctx.set_allreduce(lambda t, r=r: t.add_(peer[r]) if peer[r] is not None else None)
+    assert np.allclose(parts[0].dof()[0], ref.dof()[0], rtol=1e-13)
+    torch = ref.torch
+
+    def exchange():
+        """both shards reduce their own rows at the current phase; each then knows what the other would contribute"""
+        peer[0] = peer[1] = None
+        ke = [torch.from_numpy(c.compute_kinetic_energies()).to(c.dev) for c in parts]
+        peer[0], peer[1] = ke[1], ke[0]
+
+    lib = ref.lib
+    for _ in range(40):
+        ref.step_begin(); ref.compute_forces(); ref.step_end()
+        exchange()
+        for c in parts:
+            c.step_begin()                   # KE (own rows) -> hook adds the peer's -> chain -> rescale, kick, drift, wall
+        for c in parts:
+            c.compute_forces()
+        for c in parts:
+            assert lib.tgnh_step_end_kick(c.h, c._stream()) == 0
+        exchange()
+        for c in parts:
+            assert lib.tgnh_step_end_thermo(c.h, c._stream()) == 0
+    pos = np.concatenate([c.getPositions() for c in parts])
+    vel = np.concatenate([c.getVelocities() for c in parts])
+    assert rel_err(pos, ref.getPositions()) < 1e-12 and rel_err(vel, ref.getVelocities()) < 1e-10
+    assert np.allclose(parts[0].thermostat_state(1), parts[1].thermostat_state(1), rtol=0, atol=0)   # replicated chain: bitwise
+    assert np.allclose(parts[0].thermostat_state(1), ref.thermostat_state(1), rtol=1e-9, atol=1e-13)
+    for c in parts + [ref]:
+        c.close()
+
+
 def test_against_committed_regression_vectors():
     """The HIP path against tests/golden/oracle_regression.npz (the oracle's frozen outputs; data only, so this check
     does not need the oracle at run time)."""
