@@ -236,13 +236,20 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
             }
             if (DO_MOVE) pd[k] = cur.pd[k];
         }
+        // One fp64 division per slot: the mass.  The LDS images carry it in .w (0 = massless), so the per-molecule walk
+        // and the pair arithmetic multiply by masses instead of dividing by inverse masses again (K forms RECIP(w) in
+        // every kernel; an fp64 reciprocal is ~15 VALU instructions and these launches are VALU-heavy at small sizes).
+        mixed mass[SPT];
+#pragma unroll
+        for (int k = 0; k < SPT; k++) mass[k] = v[k].w != 0 ? rcp_(v[k].w) : (mixed)0;
+        auto img = [&](int k) { return mk4(v[k].x, v[k].y, v[k].z, mass[k]); };
 
         bool lds_read = false;   // some lane may still be reading sv/scom of this tile
 
         // ---------------- A6: rescale (K :249-301 ; Ref :516-541) ----------------
         if (DO_SCALE) {
 #pragma unroll
-            for (int k = 0; k < SPT; k++) st_img(sv, svc, k * TBLOCK + tid, v[k]);
+            for (int k = 0; k < SPT; k++) st_img(sv, svc, k * TBLOCK + tid, img(k));
             __syncthreads();
             if (use_com) {
                 for (int r = tid; r < nres; r += TBLOCK) {            // K :86-111
@@ -252,10 +259,8 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     mixed cx = 0, cy = 0, cz = 0, cm = 0;
                     for (int j = 0; j < rt.x; j++) {
                         const mixed4 u = ld_img(sv, svc, first + j);
-                        if (u.w != 0) {
-                            const mixed m = rcp_(u.w);
-                            cx += u.x * m; cy += u.y * m; cz += u.z * m; cm += m;
-                        }
+                        const mixed m = u.w;                       // mass (0 for massless sites)
+                        cx += u.x * m; cy += u.y * m; cz += u.z * m; cm += m;
                     }
                     const mixed w = rcp_(cm);
                     scom[r] = mk4(cx * w, cy * w, cz * w, w);
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     const mixed4 v2 = is_d ? u : v[k];               // particles.y (parent)
                     const mixed r1x = v1.x - cx, r1y = v1.y - cy, r1z = v1.z - cz;
                     const mixed r2x = v2.x - cx, r2y = v2.y - cy, r2z = v2.z - cz;
-                    const mixed mass1 = rcp_(v1.w), mass2 = rcp_(v2.w);
+                    const mixed mass1 = is_d ? mass[k] : u.w, mass2 = is_d ? u.w : mass[k];
                     const mixed invTot = rcp_(mass1 + mass2);
                     const mixed m1f = invTot * mass1, m2f = invTot * mass2;
                     const mixed cmx = s_g * (r1x * m1f + r2x * m2f);
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
             if (lds_read) __syncthreads();
 #pragma unroll
             for (int k = 0; k < SPT; k++) {
-                st_img(sv, svc, k * TBLOCK + tid, v[k]);
+                st_img(sv, svc, k * TBLOCK + tid, img(k));
                 st_img(sx, sxc, k * TBLOCK + tid, mk4(px[k], py[k], pz[k], (mixed)0));
             }
             __syncthreads();
@@ -377,17 +382,18 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     const mixed p1x = is_d ? px[k] : ux.x, p1y = is_d ? py[k] : ux.y, p1z = is_d ? pz[k] : ux.z;
                     const mixed p2x = is_d ? ux.x : px[k], p2y = is_d ? ux.y : py[k], p2z = is_d ? ux.z : pz[k];
                     const mixed dx = p1x - p2x, dy = p1y - p2y, dz = p1z - p2z;
-                    const mixed r = sqrt_(dx * dx + dy * dy + dz * dz);
-                    const mixed rInv = rcp_(r);
-                    if (rInv * maxd < 1) {
+                    const mixed d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 > maxd * maxd) {                           // r > max  <=>  rInv*max < 1 (K :490): sqrt and 1/r only for violators
+                        const mixed r = sqrt_(d2);
+                        const mixed rInv = rcp_(r);
                         if (rInv * maxd < (mixed)0.5) atomicOr(a.status, 1u);     // Ref :311-312
                         const mixed bx = dx * rInv, by = dy * rInv, bz = dz * rInv;
-                        const mixed mass1 = rcp_(vel1.w), mass2 = rcp_(vel2.w);
+                        const mixed mass1 = is_d ? mass[k] : uv.w, mass2 = is_d ? uv.w : mass[k];   // image .w = mass
                         const mixed deltaR = r - maxd;
                         mixed deltaT = dt;
                         mixed dotvr1 = vel1.x * bx + vel1.y * by + vel1.z * bz;
                         const mixed vp1x = vel1.x - bx * dotvr1, vp1y = vel1.y - by * dotvr1, vp1z = vel1.z - bz * dotvr1;
-                        if (vel2.w == 0) {                            // K :504-526 massless parent
+                        if (mass2 == 0) {                             // K :504-526 massless parent
                             if (dotvr1 != 0) deltaT = deltaR / abs_(dotvr1);
                             if (deltaT > dt) deltaT = dt;
                             dotvr1 = -dotvr1 * hws / (abs_(dotvr1) * sqrt_(mass1));
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
         if (DO_KE) {
             if (lds_read) __syncthreads();
 #pragma unroll
-            for (int k = 0; k < SPT; k++) st_img(sv, svc, k * TBLOCK + tid, v[k]);
+            for (int k = 0; k < SPT; k++) st_img(sv, svc, k * TBLOCK + tid, img(k));
             __syncthreads();
             if (use_com) {
                 for (int r = tid; r < nres; r += TBLOCK) {            // K :86-111, :152-158
@@ -458,15 +464,13 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     mixed cx = 0, cy = 0, cz = 0, cm = 0;
                     for (int j = 0; j < rt.x; j++) {
                         const mixed4 u = ld_img(sv, svc, first + j);
-                        if (u.w != 0) {
-                            const mixed m = rcp_(u.w);
-                            cx += u.x * m; cy += u.y * m; cz += u.z * m; cm += m;
-                        }
+                        const mixed m = u.w;                       // mass (0 for massless sites)
+                        cx += u.x * m; cy += u.y * m; cz += u.z * m; cm += m;
                     }
                     const mixed w = rcp_(cm);
                     cx *= w; cy *= w; cz *= w;
                     scom[r] = mk4(cx, cy, cz, w);
-                    ke_com += ((double)cx * cx + (double)cy * cy + (double)cz * cz) / (double)w;
+                    ke_com += ((double)cx * cx + (double)cy * cy + (double)cz * cz) * (double)cm;     // M v_com^2 (K :154)
                 }
                 __syncthreads();
             }
@@ -480,22 +484,20 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                 if (role == ROLE_NORMAL) {
                     if (v[k].w != 0) {                               // K :161-168
                         const double rx = v[k].x - cx, ry = v[k].y - cy, rz = v[k].z - cz;
-                        val = (rx * rx + ry * ry + rz * rz) / (double)v[k].w;
+                        val = (rx * rx + ry * ry + rz * rz) * (double)mass[k];
                     }
                 } else if (role == ROLE_DRUDE) {                     // K :171-186 (one lane per pair)
                     const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
                     const mixed4 u = ld_img(sv, svc, pl);
-                    const double w1 = v[k].w, w2 = u.w;
                     const double r1x = v[k].x - cx, r1y = v[k].y - cy, r1z = v[k].z - cz;
                     const double r2x = u.x - cx, r2y = u.y - cy, r2z = u.z - cz;
-                    const double mass1 = 1.0 / w1, mass2 = 1.0 / w2;
+                    const double mass1 = mass[k], mass2 = u.w;               // image .w = mass
                     const double invTot = 1.0 / (mass1 + mass2);
-                    const double invRed = (mass1 + mass2) * w1 * w2;
                     const double m1f = invTot * mass1, m2f = invTot * mass2;
                     const double cmx = r1x * m1f + r2x * m2f, cmy = r1y * m1f + r2y * m2f, cmz = r1z * m1f + r2z * m2f;
                     const double rlx = r2x - r1x, rly = r2y - r1y, rlz = r2z - r1z;
                     val = (cmx * cmx + cmy * cmy + cmz * cmz) * (mass1 + mass2);
-                    ke_drude += (rlx * rlx + rly * rly + rlz * rlz) * (1.0 / invRed);
+                    ke_drude += (rlx * rlx + rly * rly + rlz * rlz) * (mass1 * mass2 * invTot);   // reduced mass = 1/invReducedMass (K :178, :185)
                 }
                 if constexpr (GB > 0) {
 #pragma unroll
