@@ -282,29 +282,21 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                         v[k].z = s_g * rz + s_com * (v[k].z - rz);
                     }
                 } else {                                             // K :270-300
+                    // Written from the lane's own point of view (self s, partner p), which needs no role selects:
+                    // with cm = (r_s m_s + r_p m_p)/M and K's rel = r_parent - r_drude, both
+                    //   v_drude'  = s_g cm - s_D rel m_parent/M + s_COM v_com      (K :292-294)
+                    //   v_parent' = s_g cm + s_D rel m_drude/M  + s_COM v_com      (K :295-297)
+                    // read  v_s' = s_g cm + s_D (r_s - r_p) m_p/M + s_COM (v_s - r_s).
                     const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
-                    const mixed4 u = ld_img(sv, svc, pl);
-                    const bool is_d = role == ROLE_DRUDE;
-                    const mixed4 v1 = is_d ? v[k] : u;               // particles.x (Drude)
-                    const mixed4 v2 = is_d ? u : v[k];               // particles.y (parent)
-                    const mixed r1x = v1.x - cx, r1y = v1.y - cy, r1z = v1.z - cz;
-                    const mixed r2x = v2.x - cx, r2y = v2.y - cy, r2z = v2.z - cz;
-                    const mixed mass1 = is_d ? mass[k] : u.w, mass2 = is_d ? u.w : mass[k];
-                    const mixed invTot = rcp_(mass1 + mass2);
-                    const mixed m1f = invTot * mass1, m2f = invTot * mass2;
-                    const mixed cmx = s_g * (r1x * m1f + r2x * m2f);
-                    const mixed cmy = s_g * (r1y * m1f + r2y * m2f);
-                    const mixed cmz = s_g * (r1z * m1f + r2z * m2f);
-                    const mixed rlx = s_drude * (r2x - r1x), rly = s_drude * (r2y - r1y), rlz = s_drude * (r2z - r1z);
-                    if (is_d) {
-                        v[k].x = cmx - rlx * m2f + s_com * (v1.x - r1x);
-                        v[k].y = cmy - rly * m2f + s_com * (v1.y - r1y);
-                        v[k].z = cmz - rlz * m2f + s_com * (v1.z - r1z);
-                    } else {
-                        v[k].x = cmx + rlx * m1f + s_com * (v2.x - r2x);
-                        v[k].y = cmy + rly * m1f + s_com * (v2.y - r2y);
-                        v[k].z = cmz + rlz * m1f + s_com * (v2.z - r2z);
-                    }
+                    const mixed4 u = ld_img(sv, svc, pl);           // partner velocity, .w = partner mass
+                    const mixed rsx = v[k].x - cx, rsy = v[k].y - cy, rsz = v[k].z - cz;
+                    const mixed rpx = u.x - cx, rpy = u.y - cy, rpz = u.z - cz;
+                    const mixed invTot = rcp_(mass[k] + u.w);
+                    const mixed msf = invTot * mass[k], mpf = invTot * u.w;
+                    const mixed sdp = s_drude * mpf;
+                    v[k].x = s_g * (rsx * msf + rpx * mpf) + sdp * (rsx - rpx) + s_com * (v[k].x - rsx);
+                    v[k].y = s_g * (rsy * msf + rpy * mpf) + sdp * (rsy - rpy) + s_com * (v[k].y - rsy);
+                    v[k].z = s_g * (rsz * msf + rpz * mpf) + sdp * (rsz - rpz) + s_com * (v[k].z - rsz);
                 }
             }
             lds_read = true;
