@@ -368,14 +368,14 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                 const uint32_t role = m & 3u;
                 if (role != ROLE_NORMAL) {
                     const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
-                    const mixed4 uv = ld_img(sv, svc, pl), ux = ld_img(sx, sxc, pl);
-                    const bool is_d = role == ROLE_DRUDE;
-                    const mixed4 vel1 = is_d ? v[k] : uv, vel2 = is_d ? uv : v[k];
-                    const mixed p1x = is_d ? px[k] : ux.x, p1y = is_d ? py[k] : ux.y, p1z = is_d ? pz[k] : ux.z;
-                    const mixed p2x = is_d ? ux.x : px[k], p2y = is_d ? ux.y : py[k], p2z = is_d ? ux.z : pz[k];
-                    const mixed dx = p1x - p2x, dy = p1y - p2y, dz = p1z - p2z;
-                    const mixed d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 > maxd * maxd) {                           // r > max  <=>  rInv*max < 1 (K :490): sqrt and 1/r only for violators
+                    const mixed4 ux = ld_img(sx, sxc, pl);
+                    const mixed sxd = px[k] - ux.x, syd = py[k] - ux.y, szd = pz[k] - ux.z;     // self - partner
+                    const mixed d2 = sxd * sxd + syd * syd + szd * szd;
+                    if (d2 > maxd * maxd) {                           // r > max  <=>  rInv*max < 1 (K :490): the rest only for violators
+                        const mixed4 uv = ld_img(sv, svc, pl);
+                        const bool is_d = role == ROLE_DRUDE;
+                        const mixed4 vel1 = is_d ? v[k] : uv, vel2 = is_d ? uv : v[k];
+                        const mixed dx = is_d ? sxd : -sxd, dy = is_d ? syd : -syd, dz = is_d ? szd : -szd;   // Drude - parent (K :487)
                         const mixed r = sqrt_(d2);
                         const mixed rInv = rcp_(r);
                         if (rInv * maxd < (mixed)0.5) atomicOr(a.status, 1u);     // Ref :311-312
