@@ -48,3 +48,34 @@ def to_internal(x, mode):
     if mode == "dualNH":
         return np.array([x[0], 0.0, x[1]]) if x.ndim == 1 else np.stack([x[:, 0], 0 * x[:, 0], x[:, 1]], 1)
     return x
+
+
+def extended_energy(system, normal, pos, vel, x0, nkt, eta, eta_dot, eta_mass, chains, kT, kT_drude, mode,
+                    k_drude=synth.K_DRUDE, k_tether=synth.K_TETHER):
+    """The quantity Nose-Hoover-chain dynamics conserves, for the harness force field:
+        H = 1/2 sum m v^2 + U + sum_t [ sum_i 1/2 Q_ti etaDot_ti^2 + NkT_t eta_t0 + kT_t sum_{i>=1} eta_ti ].
+    The reference never evaluates it (it is the invariant SURVEY 8c(3) asks the build to add); a restatement whose
+    chain, KE partition or rescale were wrong in sign, factor or coupling would drift linearly instead of
+    fluctuating at O(dt^2).  Thermostat arrays: TGNH [thermostat][link] (etaDot rows of C+1); dualNH the reference's
+    interleaved [real0, drude0, real1, drude1, ...] (Ref :186-217), valid with useDrudeNHChains only."""
+    m = system.mass
+    ke = 0.5 * float((m[:, None] * vel ** 2).sum())
+    tether = np.zeros(len(m), bool)
+    tether[normal] = True
+    tether[system.pair_parent] = True
+    tether &= m > 0
+    sep = pos[system.pair_drude] - pos[system.pair_parent]
+    pe = 0.5 * k_tether * float(((pos - x0)[tether] ** 2).sum()) + 0.5 * k_drude * float((sep ** 2).sum())
+    C = chains
+    if mode == "dualNH":
+        eta, eta_dot, eta_mass = (np.asarray(a)[:2 * C].reshape(C, 2).T for a in (eta, eta_dot, eta_mass))
+    else:
+        nt = len(nkt)
+        eta, eta_dot, eta_mass = (np.asarray(a).reshape(nt, -1)[:, :C] for a in (eta, eta_dot, eta_mass))
+    th = 0.0
+    for t in range(len(nkt)):
+        if eta_mass[t, 0] <= 0:                       # inert thermostat (Cu :561 etaMass > 0 guard)
+            continue
+        kt = kT_drude if t == len(nkt) - 1 else kT
+        th += 0.5 * float((eta_mass[t] * eta_dot[t] ** 2).sum()) + nkt[t] * eta[t, 0] + kt * float(eta[t, 1:].sum())
+    return ke + pe + th, ke, th

@@ -322,6 +322,39 @@ def test_merged_and_deferred_rescale_match_plain(mode, flags, sysname):
     ref[4].close(); alt[4].close()
 
 
+@pytest.mark.parametrize("mode,flags,chains,sysname", [
+    ("TGNH", 0, 3, "mixed"), ("TGNH", 0, 1, "mixed"), ("TGNH", FLAG_MERGE_SCALE_KE, 3, "il40"),
+    ("TGNH", 0, 3, "polymer"), ("dualNH", 0, 3, "water1000"), ("dualNH", FLAG_MERGE_SCALE_KE, 1, "mixed")])
+def test_extended_energy_is_conserved(mode, flags, chains, sysname):
+    """SURVEY 8c(3), on the HIP path: the Nose-Hoover-chain invariant H (tests/helpers.py) computed from what the
+    C ABI hands back (positions, velocities, thermostat state, dof).  The thermostats move > 10 % of the initial
+    energy while H holds to O(dt^2); chains = 1 in TGNH mode is the in-kernel chain."""
+    from helpers import extended_energy
+    worst = []
+    for dt in (0.0005, 0.00025):
+        s, g, ng, it, ctx = make(sysname, mode, "double", flags=flags, chains=chains, dt=dt)
+        x0, normal = ctx.sites(), ctx.topology(0)
+        nkt = ctx.dof()[1]
+        nkt = nkt[[0, 2]] if mode == "dualNH" else nkt
+
+        def energy():
+            return extended_energy(s, normal, ctx.getPositions(), ctx.getVelocities(), x0, nkt,
+                                   ctx.thermostat_state(0), ctx.thermostat_state(1), ctx.thermostat_state(3), chains,
+                                   synth.KB * 300.0, synth.KB * 1.0, mode)
+        h0, ke0, _ = energy()
+        dev, th_min = 0.0, 0.0
+        for _ in range(10):
+            ctx.step(int(round(0.02 / dt)))
+            h, _, th = energy()
+            dev, th_min = max(dev, abs(h - h0)), min(th_min, th)
+        assert th_min < -0.1 * ke0
+        worst.append(dev / h0)
+        ctx.close()
+    print(f"extended energy {mode} flags={flags} C={chains} {sysname}: max |dH|/H0 = {worst[0]:.2e} (dt 0.5 fs), {worst[1]:.2e} (0.25 fs)")
+    assert worst[0] < 2e-4 and worst[1] < 5e-5
+    assert 2.5 < worst[0] / worst[1] < 7.0
+
+
 @pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
 @pytest.mark.parametrize("precision", ["mixed", "double"])
 def test_100_step_parity_deferred_rescale(mode, precision):

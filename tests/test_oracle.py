@@ -201,3 +201,34 @@ def test_oracle_regression_vectors():
         for k, v in now.items():
             ref = frozen[f"{name}/{k}"]
             assert ref.shape == v.shape and np.allclose(v, ref, rtol=1e-12, atol=1e-14 * max(1.0, np.abs(ref).max())), (name, k)
+
+
+@pytest.mark.parametrize("mode,system", [("TGNH", "ionic"), ("TGNH", "water"), ("dualNH", "water")])
+def test_extended_energy_is_conserved(mode, system):
+    """the Nose-Hoover-chain invariant.  While the thermostats take > 25 % of the initial energy out of
+    the particles, H stays put, and its fluctuation falls ~4x when dt is halved (second-order splitting)."""
+    from helpers import extended_energy
+    s, g, ng = synth.ionic_liquid(4) if system == "ionic" else synth.water_box(27)
+    C, T, TD = 3, 300.0, 1.0
+    worst = []
+    for dt in (0.0005, 0.00025):
+        it = _integ(stepSize=dt, numNHChains=C)
+        o = _oracle(s, g, ng, MODE_TGNH if mode == "TGNH" else MODE_DUALNH, it)
+        pos, vel, x0 = s.positions.copy(), s.velocities.copy(), s.positions.copy()
+        f = o.harness_force(pos, x0, synth.K_DRUDE, synth.K_TETHER)
+        normal = o.normal_particles()
+
+        def energy():
+            return extended_energy(s, normal, pos, vel, x0, o.dof()[1], o.chain(0), o.chain(1), o.chain(3), C,
+                                   KB * T, KB * TD, mode)
+        h0, ke0, _ = energy()
+        dev, th_min = 0.0, 0.0
+        for _ in range(10):
+            o.run_harness(pos, vel, f, x0, synth.K_DRUDE, synth.K_TETHER, int(round(0.02 / dt)))
+            h, _, th = energy()
+            dev, th_min = max(dev, abs(h - h0)), min(th_min, th)
+        assert th_min < -0.25 * ke0, "the thermostats must have done real work for this test to mean anything"
+        worst.append(dev / h0)
+    print("dH/H0:", worst)
+    assert worst[0] < 2e-4 and worst[1] < 5e-5
+    assert 2.5 < worst[0] / worst[1] < 7.0
