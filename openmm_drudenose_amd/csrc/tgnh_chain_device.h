@@ -16,13 +16,16 @@ namespace tgnh {
 
 // exp() for the chain.  The arguments are -dtc/8*etaDot and -dtc/2*etaDot: exactly 0 for the dummy link
 // (exp(-0) = 1 exactly, as libm returns) and tiny otherwise, so a short Taylor polynomial in explicit FMAs is
-// exact to double rounding: degree 6 for |x| < 2^-10 (truncation < 2^-62 relative), degree 11 for |x| < 2^-5
-// (< 2^-55); larger arguments take the library exp.  The chain is one serial fp64 dependency chain per
-// thermostat, so its latency is the number of dependent operations: this keeps an exp at 6-11 of them.
+// exact to double rounding: degree 6 for |x| < 2^-7 (truncation |x|^7/7! < 2^-61 relative), degree 11 for
+// |x| < 2^-5 (< 2^-55); larger arguments take the library exp.  The chain is one serial fp64 chain per thermostat
+// on the critical path of every time step, and a wavefront issues one fp64 instruction per 4 cycles however few
+// lanes are live, so what counts is the *number of instructions*: Horner (an Estrin form, 14 operations at depth 5,
+// measured 40 % slower), and the degree is chosen for the whole wavefront so that thermostats on different sides of
+// the switch do not execute both polynomials.
 template <bool LIBM = true>
 __device__ __forceinline__ double chain_exp(double x) {
     const double ax = fabs(x);
-    if (__builtin_expect(ax < 0.0009765625, 1)) {                    // also x = +-0: returns exactly 1
+    if (__builtin_expect(!__any(ax >= 0.0078125), 1)) {              // also x = +-0: returns exactly 1
         double p = 1.0 / 720.0;
         p = fma(p, x, 1.0 / 120.0);
         p = fma(p, x, 1.0 / 24.0);
@@ -246,6 +249,147 @@ __device__ __forceinline__ void run_tgnh(const ChainArgs& a, const double* st_in
     for (int i = 0; i < (CC > 0 ? CC : C); i++) { o_eta[i] = eta[i]; o_etaDotDot[i] = etaDotDot[i]; }
 #pragma unroll
     for (int i = 0; i < (CC > 0 ? CC : C) + 1; i++) o_etaDot[i] = etaDot[i];
+}
+
+// One-link TGNH thermostat in two halves, for the in-kernel chain of the rescale launches: the state loads are issued
+// at kernel entry, *ahead of* the tile loads (behind them they would queue for microseconds while every work-group
+// waits on its scale factors), the arithmetic runs while the tile loads are in flight.  Same arithmetic as
+// run_tgnh<1, false>.
+struct Chain1Regs { double eta, etaDot0, etaDot1, etaDotDot, etaMass, nkbt, ke; };
+
+__device__ __forceinline__ Chain1Regs chain1_load(const ChainArgs& a, const double* st_in, const int itg) {
+    const ChainLayout& L = a.L;
+    Chain1Regs r;
+    r.eta = st_in[L.off_eta + itg];
+    r.etaDot0 = st_in[L.off_etaDot + itg * 2];
+    r.etaDot1 = st_in[L.off_etaDot + itg * 2 + 1];
+    r.etaDotDot = st_in[L.off_etaDotDot + itg];
+    r.etaMass = st_in[L.off_etaMass + itg];
+    r.nkbt = st_in[L.off_nkbt + itg];
+    r.ke = st_in[L.off_ke_red + itg];
+    return r;
+}
+
+// exp(y) for the one-link fast path: Taylor polynomials in Estrin form -- the serial chain there is bound by the
+// latency of dependent fp64 operations (~17 cycles each, measured), so depth counts: degree 7 at depth 3 for
+// |y| < 2^-6 (truncation y^8/8! < 2^-63), degree 12 at depth 4 for |y| < 2^-2 (y^13/13! < 2^-58).
+__device__ __forceinline__ double chain_exp7(const double y) {
+    const double y2 = y * y;
+    const double p0 = 1.0 + y;
+    const double p1 = fma(y, 1.0 / 6.0, 0.5);
+    const double p2 = fma(y, 1.0 / 120.0, 1.0 / 24.0);
+    const double p3 = fma(y, 1.0 / 5040.0, 1.0 / 720.0);
+    const double y4 = y2 * y2;
+    const double q0 = fma(p1, y2, p0);
+    const double q1 = fma(p3, y2, p2);
+    return fma(q1, y4, q0);
+}
+__device__ __forceinline__ double chain_exp12(const double y) {
+    const double y2 = y * y;
+    const double p0 = 1.0 + y;
+    const double p1 = fma(y, 1.0 / 6.0, 0.5);
+    const double p2 = fma(y, 1.0 / 120.0, 1.0 / 24.0);
+    const double p3 = fma(y, 1.0 / 5040.0, 1.0 / 720.0);
+    const double p4 = fma(y, 1.0 / 362880.0, 1.0 / 40320.0);
+    const double p5 = fma(y, 1.0 / 39916800.0, 1.0 / 3628800.0);
+    const double y4 = y2 * y2;
+    const double q0 = fma(p1, y2, p0);
+    const double q1 = fma(p3, y2, p2);
+    const double q2 = fma(p5, y2, p4);
+    const double y8 = y4 * y4;
+    const double r0 = fma(q1, y4, q0);
+    const double r1 = fma(y4, 1.0 / 479001600.0, q2);
+    return fma(r1, y8, r0);
+}
+
+// All NT thermostats in the lanes of ONE wavefront, one instruction stream: with one link the real thermostats
+// (chain_real_core<1>) and the Drude thermostat (chain_drude_core<1>) differ only in expfac = exp(-dtc8*etaDot[1]),
+// which is exactly 1 for the real ones (their link 1 is the dummy with etaDot = 0), and in the etaMass > 0 guard
+// (Cu :561, :579; the Drude branch has none, Cu :605, :629).
+//
+// Fast path (expfac = 1 everywhere, i.e. always unless a caller has set etaDot[1] by hand).  One sub-step is
+//     ed1 = ed + edd dtc/4 ;  s = exp(-dtc/2 ed1) ;  scale *= s ;  KE *= s^2 ;  eta += dtc/2 ed1 ;
+//     edd = (KE - NkT)/Q ;    ed = ed1 + edd dtc/4                                   (Cu :566-585, :616-632)
+// and every work-group of a rescale launch waits for S (or 2S) of them in a row, so the loop carries only what it
+// must: with y = -dtc ed1 (the exponent of the KE factor) the next sub-step's y is y - (dtc^2/2) edd, so
+//     KE *= exp(y) ;  edd = (KE - NkT)/Q ;  y -= (dtc^2/2) edd
+// is the whole dependent chain (7 operations with the depth-3 polynomial; the direct transcription has 16), while
+// ed1 (advanced by two quarter-kicks at a time) and sum(y) are carried beside it: scale = exp(sum(y)/2),
+// eta -= sum(y)/2 and ed = ed1 - edd dtc/4 are formed once at the end.
+// Same mathematics; the roundings differ from the transcription by a few ulp (parity unchanged at 1e-11).
+__device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs& r, double* st_out, const bool write,
+                                           double* s_scale, const int itg) {
+    const ChainLayout& L = a.L;
+    const bool drude = itg == L.NT - 1;
+    const double dtc = a.dt / a.S;                                   // Cu :440-443
+    const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
+    double ke = r.ke;
+    if (write) st_out[L.off_ke + itg] = ke;                          // KE before the chain (Cu :490)
+    const bool live = drude || r.etaMass > 0;
+    const double invQ0 = live ? 1.0 / r.etaMass : 0.0;
+    const double expfac = chain_exp<false>(-dtc8 * r.etaDot1);       // Cu :615 ; real: exp(-0) = 1
+    const bool all_unit = !__any(expfac != 1.0);
+    double ed = r.etaDot0, edd = r.etaDotDot, et = r.eta;
+    const int reps = a.chain_twice ? 2 : 1;
+    double total = 1.0;
+    // etaMass > 0 guard without selects: edd = (KE - NkT) * invQ0 + hold, with (invQ0, hold) = (1/Q, 0) for a live
+    // thermostat (the fma then rounds exactly like the product) and (0, etaDotDot) for an inert one
+    const double hold = live ? 0.0 : r.etaDotDot;
+    for (int rep = 0; rep < reps; rep++) {
+        double scale = 1.0;
+        if (live) edd = (ke - r.nkbt) * invQ0;                       // Cu :561-563, :605
+        if (all_unit) {
+            const double ky = -0.5 * dtc * dtc;                      // y' = y - dtc * 2 * dtc/4 * edd
+            const double ed1_0 = fma(edd, dtc4, ed), ke_0 = ke, edd_0 = edd;
+            double ed1 = ed1_0, y = -dtc * ed1, sy = 0.0, ymax = 0.0;
+            // a single wavefront issues an instruction every 4+ cycles at best, so the loop is as short as it gets:
+            // the degree-7 polynomial without a range test; the largest |y| seen is checked once after the loop
+            for (int iter = 0; iter < a.S; iter++) {
+                ymax = fmax(ymax, fabs(y));
+                ke *= chain_exp7(y);                                 // Cu :574, :621
+                sy += y;
+                edd = fma(ke - r.nkbt, invQ0, hold);                 // Cu :579-581, :629
+                y = fma(edd, ky, y);
+                ed1 = fma(edd, 2.0 * dtc4, ed1);                     // Cu :583-585 / :630-632 and the next :568-570
+            }
+            if (__builtin_expect(__any(ymax >= 0.015625), 0)) {      // out of the short polynomial's range: again, carefully
+                ke = ke_0; edd = edd_0; ed1 = ed1_0; y = -dtc * ed1; sy = 0.0;
+                for (int iter = 0; iter < a.S; iter++) {
+                    ke *= fabs(y) < 0.25 ? chain_exp12(y) : chain_exp<false>(y);
+                    sy += y;
+                    edd = fma(ke - r.nkbt, invQ0, hold);
+                    y = fma(edd, ky, y);
+                    ed1 = fma(edd, 2.0 * dtc4, ed1);
+                }
+            }
+            ed = fma(edd, -dtc4, ed1);                               // ed1 is one quarter-kick ahead
+            scale = chain_exp<false>(0.5 * sy);                      // prod exp(-dtc/2 ed1)      (Cu :573, :620)
+            et = fma(-0.5, sy, et);                                  // sum dtc/2 ed1            (Cu :575-577, :623)
+        } else {
+            const double ef2 = expfac * expfac, efd = expfac * dtc4;
+            for (int iter = 0; iter < a.S; iter++) {
+                ed = expfac == 1.0 ? fma(edd, dtc4, ed) : fma(ed, ef2, edd * efd);      // (ed*ef + edd*dtc4)*ef
+                const double e = chain_exp<false>(-dtc2 * ed);
+                scale *= e; ke *= e * e;
+                et = fma(dtc2, ed, et);
+                if (live) edd = (ke - r.nkbt) * invQ0;
+                ed = expfac == 1.0 ? fma(edd, dtc4, ed) : fma(ed, ef2, edd * efd);
+            }
+        }
+        if (write) {
+            if (rep == 0) { st_out[L.off_scale_a + itg] = scale; st_out[L.off_ke_post + itg] = ke; }
+            else st_out[L.off_scale_b + itg] = scale;
+        }
+        total *= scale;
+    }
+    if (s_scale) s_scale[itg] = total;
+    if (!write) return;
+    if (reps == 1) st_out[L.off_scale_b + itg] = 1.0;
+    st_out[L.off_scale + itg] = total;
+    st_out[L.off_eta + itg] = et;
+    st_out[L.off_etaDotDot + itg] = edd;
+    st_out[L.off_etaDot + itg * 2] = ed;
+    st_out[L.off_etaDot + itg * 2 + 1] = r.etaDot1;
 }
 
 // The Reference platform's coupled real/Drude chain on its interleaved vectors.  Ref :467-504.

@@ -147,9 +147,11 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
         if (start > 0 && start < N && c->resid[start] == c->resid[start - 1]) n += 1;
         return n;
     };
+    int cap = TILE_SLOTS;
+    if (const char* e = getenv("TGNH_TILE_CAP")) { int v = atoi(e); if (v >= 64 && v <= TILE_SLOTS) cap = v; }
     int start = 0;
     while (start < N) {
-        int end = std::min(start + TILE_SLOTS, N);
+        int end = std::min(start + cap, N);
         auto ok = [&](int e) {
             if (e < N && forbid[e] > 0) return false;
             if (com && entries_in(start, e) > TILE_RES) return false;

@@ -86,6 +86,25 @@ size_t tile_lds_bytes(int precision, int ops, bool hardwall, bool use_com) {
 #ifndef TGNH_MINWAVES
 #define TGNH_MINWAVES 1
 #endif
+#ifdef TGNH_TRACE
+// Phase timestamps of the tile kernel (tuning builds only: tools/trace_probe.py).  16 slots per work-group,
+// constant 100 MHz clock, written by thread 0.
+__device__ unsigned long long g_trace[GRID_CAP * 16];
+#define TRACE(slot) do { if (threadIdx.x == 0 && (slot) < 16) g_trace[blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+#define TRACE_WAIT() __builtin_amdgcn_s_waitcnt(0)
+extern "C" int tgnh_debug_read_trace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * GRID_CAP * 16);
+}
+extern "C" int tgnh_debug_clear_trace() {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_trace)) != hipSuccess) return 1;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * GRID_CAP * 16);
+}
+#else
+#define TRACE(slot) do {} while (0)
+#define TRACE_WAIT() do {} while (0)
+#endif
+
 template <int PREC, int OPS, int GB>
 __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileArgs a) {
     typedef typename Prec<PREC>::real real;
@@ -153,11 +172,13 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
         real4 p[SPT];
         float4 c[SPT];
         mixed4 pd[SPT];
+        int2 rt;                 // this lane's molecule entry (lane r < nres): fetched with the tile, not after the first barrier
     };
     auto load_tile = [&](int tt, TileIn& in) {
         const int t = a.reverse ? a.num_tiles - 1 - tt : tt;
         in.ts = a.tile_start[t]; in.te = a.tile_start[t + 1];
         in.rs = a.tile_res[t]; in.nres = a.tile_res[t + 1] - in.rs;
+        if ((DO_SCALE || DO_KE) && a.use_com && tid < in.nres) in.rt = a.res_table[in.rs + tid];
 #pragma unroll
         for (int k = 0; k < SPT; k++) {
             const int idx = in.ts + k * TBLOCK + tid;
@@ -182,28 +203,49 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
     };
 
     TileIn cur, nxt;
-    if ((int)blockIdx.x < a.num_tiles) load_tile(blockIdx.x, cur);
-
-    // ---- scale factors.  With a one-link chain the Nose-Hoover update itself runs here (A5), while the first
-    // tile's loads are in flight: every work-group computes the same factors from the same summed kinetic
-    // energies (fp64, deterministic), work-group 0 alone writes the advanced thermostat block -- to the other copy
-    // of the double buffer, because work-groups of this launch may start after work-group 0 has finished.
+    TRACE(0);
+    // ---- scale factors.  With a one-link chain the Nose-Hoover update itself runs here (A5): every work-group
+    // computes the same factors from the same summed kinetic energies (fp64, deterministic); work-group 0 alone
+    // writes the advanced thermostat block -- to a staging copy, because work-groups of this launch may start after
+    // work-group 0 has finished.  One wavefront per work-group runs the chain, and runs it BEFORE issuing its own
+    // tile loads: behind them, its wait for the thermostat state would be a wait for the whole tile (the counter
+    // of outstanding loads completes in order), and every wavefront of the work-group would stand at the barrier
+    // below for the latency of the memory phase PLUS the chain.  This way the chain (~3.5 us) hides behind the other
+    // three wavefronts' loads.  (Wavefront 0 everywhere: the dispatcher starts consecutive work-groups of a compute
+    // unit on consecutive SIMDs -- HW_ID, tools/trace_probe.py -- so the resident chains already sit on different
+    // SIMDs; rotating the wavefront by residency slot made two of three collide.)
     mixed s_com = 1, s_drude = 1;
+    const bool chain_wave = DO_SCALE && a.chain_on && tid < 64;
+    const bool have_tile = (int)blockIdx.x < a.num_tiles;
+    if (!chain_wave && have_tile) load_tile(blockIdx.x, cur);
+    TRACE(1);
+    int trace_tile = 0; (void)trace_tile;
+#ifdef TGNH_TRACE
+    if ((threadIdx.x & 63) == 0) {          // slots 11/12: where the hardware put wavefronts 0 and 1 (HW_ID, XCC_ID)
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        if (threadIdx.x == 0) g_trace[blockIdx.x * 16 + 11] = ((unsigned long long)xcc << 32) | hw;
+        if (threadIdx.x == 64) g_trace[blockIdx.x * 16 + 12] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     if (DO_SCALE) {
         const int NT = G + 2;
         if (a.chain_on) {
-            const ChainLayout& L = a.chain.L;
-            const bool write = blockIdx.x == 0;
-            {
-                int itg = -1;
-                if (tid < NT - 1) itg = tid;
-                else if (tid == 64) itg = NT - 1;
-                if (itg >= 0) run_tgnh<1, false>(a.chain, a.st_in, a.st_out, write, s_scale, itg, nullptr, a.st_in[L.off_ke_red + itg]);
-                if (write && tid == 128) {                           // Cu :493-497
+            if (chain_wave) {
+                const ChainLayout& L = a.chain.L;
+                const bool write = blockIdx.x == 0;
+                const int itg = tid & 63;
+                TRACE(13);
+                if (itg < NT) {
+                    const Chain1Regs creg = chain1_load(a.chain, a.st_in, itg);
+                    chain1_run(a.chain, creg, a.st_out, write, s_scale, itg);
+                }
+                TRACE(14);
+                if (write && itg == 63) {                            // Cu :493-497
                     double s = 0.0;
                     for (int i = 0; i < NT; i++) s += a.st_in[L.off_ke_red + i];
                     a.st_out[L.off_kesum] = 0.5 * s;
                 }
+                if (have_tile) load_tile(blockIdx.x, cur);
             }   // (dualNH keeps the separate chain launch: its coupled vectors would cost this kernel ~50 VGPRs)
         } else if (tid < NT) {
             s_scale[tid] = a.scale[tid];
@@ -211,11 +253,13 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
         __syncthreads();
         s_com = (mixed)s_scale[G]; s_drude = (mixed)s_scale[G + 1];
     }
+    TRACE(2);
     for (int t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
         const bool more = t + (int)gridDim.x < a.num_tiles;
         if (PREFETCH && more) load_tile(t + gridDim.x, nxt);
         const int ts = cur.ts, te = cur.te;
         const int rs = cur.rs, nres = cur.nres;
+        TRACE_WAIT(); TRACE(3 + 4 * trace_tile);
 
         mixed4 v[SPT];
         uint32_t meta[SPT];
@@ -253,7 +297,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
             __syncthreads();
             if (use_com) {
                 for (int r = tid; r < nres; r += TBLOCK) {            // K :86-111
-                    const int2 rt = a.res_table[rs + r];
+                    const int2 rt = r == tid ? cur.rt : a.res_table[rs + r];
                     if (rt.x < 0) { scom[r] = reinterpret_cast<const mixed4*>(a.big_com)[-rt.x - 1]; continue; }   // molecule longer than a tile
                     const int first = rt.y - ts;
                     mixed cx = 0, cy = 0, cz = 0, cm = 0;
@@ -302,6 +346,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
             lds_read = true;
         }
 
+        TRACE(4 + 4 * trace_tile);
         // ---------------- A8 (constrained path): x += posDelta, v = posDelta/dt (K :435-466) ---
         if (DO_MOVE) {
             const double invStep = 1.0 / a.dt;                       // K :436
@@ -424,6 +469,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
             lds_read = true;
         }
 
+        TRACE(5 + 4 * trace_tile);
         // ---------------- stores ----------------
 #pragma unroll
         for (int k = 0; k < SPT; k++) {
@@ -450,7 +496,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
             __syncthreads();
             if (use_com) {
                 for (int r = tid; r < nres; r += TBLOCK) {            // K :86-111, :152-158
-                    const int2 rt = a.res_table[rs + r];
+                    const int2 rt = r == tid ? cur.rt : a.res_table[rs + r];
                     if (rt.x < 0) { scom[r] = reinterpret_cast<const mixed4*>(a.big_com)[-rt.x - 1]; continue; }   // its M v_com^2 comes from big_com_kernel
                     const int first = rt.y - ts;
                     mixed cx = 0, cy = 0, cz = 0, cm = 0;
@@ -512,6 +558,10 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
             lds_read = true;
         }
         if (lds_read) __syncthreads();       // LDS image is reused by the next tile
+        TRACE(6 + 4 * trace_tile);
+#ifdef TGNH_TRACE
+        trace_tile++;
+#endif
         if (more) { if (PREFETCH) cur = nxt; else load_tile(t + gridDim.x, cur); }
     }
 
@@ -549,6 +599,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
             }
         }
     }
+    TRACE(15);
 }
 
 // ---------------------------------------------------------------------------
@@ -639,7 +690,7 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
         else if (tid == 64) itg = NT - 1;
         if (itg >= 0) {
             switch (L.C) {
-                case 1: run_tgnh<1>(a, a.st, a.st, true, nullptr, itg, s_chain, s_ke[itg]); break;
+                case 1: { Chain1Regs r = chain1_load(a, a.st, itg); r.ke = s_ke[itg]; chain1_run(a, r, a.st, true, nullptr, itg); } break;   // the arithmetic of the in-kernel chain
                 case 2: run_tgnh<2>(a, a.st, a.st, true, nullptr, itg, s_chain, s_ke[itg]); break;
                 case 3: run_tgnh<3>(a, a.st, a.st, true, nullptr, itg, s_chain, s_ke[itg]); break;
                 case 4: run_tgnh<4>(a, a.st, a.st, true, nullptr, itg, s_chain, s_ke[itg]); break;

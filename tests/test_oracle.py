@@ -89,6 +89,26 @@ def test_ke_partition_identity():
     assert od.kinetic_energies(s.velocities).sum() == pytest.approx(total, rel=1e-12)
 
 
+def test_two_body_analytic_split():
+    """G = 1 with the COM group, one molecule that is one Drude pair.  Everything is analytic: the
+    group bin holds the pair's centre of mass *relative to the molecule's* (zero), the COM bin M |v_cm|^2, the Drude
+    bin mu |v2 - v1|^2 (K :154, :184-185); rescaling by (s_g, s_COM, s_D) gives v_i = s_COM v_cm -/+ s_D (m_j/M) v_rel
+    (K :272-300)."""
+    s, g, ng = synth.single_pair()
+    o = _oracle(s, g, ng, MODE_TGNH, _integ())
+    m1, m2 = s.mass
+    v1, v2 = s.velocities
+    vcm, vrel = (m1 * v1 + m2 * v2) / (m1 + m2), v2 - v1
+    ke = o.kinetic_energies(s.velocities)
+    assert ke[0] == pytest.approx(0.0, abs=1e-28)
+    assert ke[1] == pytest.approx((m1 + m2) * vcm @ vcm, rel=1e-14)
+    assert ke[2] == pytest.approx(m1 * m2 / (m1 + m2) * vrel @ vrel, rel=1e-14)
+    v = s.velocities.copy()
+    o.scale_velocities(v, [0.7, 1.1, 0.9])
+    assert np.allclose(v[0], 1.1 * vcm - 0.9 * m2 / (m1 + m2) * vrel, rtol=1e-14)
+    assert np.allclose(v[1], 1.1 * vcm + 0.9 * m1 / (m1 + m2) * vrel, rtol=1e-14)
+
+
 def test_rescale_scales_ke_by_square():
     """After the rescale each KE bin is s^2 times its old value (single-group molecules)."""
     s, g, ng = synth.mixed(40, 5)
