@@ -453,11 +453,14 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     c->gb = c->L.G <= 1 ? 1 : (c->L.G <= 4 ? 4 : (c->L.G <= 8 ? 8 : 0));   // 0: KE bins in LDS
-    {   // One-link chains can run inside the rescale launch.  That trades a ~10 us launch for ~5 us of every
-        // work-group's start: a gain when launches are short (a shard of a sharded run), a wash at millions of slots,
-        // where it only makes the streaming launch look slower.  Default: below 1.5 M slots.  TGNH_INLINE_CHAIN=0/1 forces.
+    {   // One-link chains run inside the rescale launch: one wavefront per work-group computes the factors while
+        // the other three have their tile loads in flight, so the chain (~3.5 us) costs the launch nothing, and
+        // the chain launch that remains only sums the partial rows (profiles/r01_tuning_sweep.log: +7 % steps/s
+        // at 625 k slots, +1.5 % at 5 M).  TGNH_INLINE_CHAIN=0 forces the separate chain launch.
+        // (Summing the rows in that prologue too, to drop the launch altogether, was measured slower: the rows are
+        // an L2-missing read of a dozen dependent batches, 7-9 us on the critical path against a 6 us launch.)
         const char* e = getenv("TGNH_INLINE_CHAIN");
-        const bool want = e ? e[0] != '0' : d->num_particles < 1500000;
+        const bool want = e ? e[0] != '0' : true;
         const char* e3 = getenv("TGNH_ALTERNATE_SWEEPS");
         c->alternate_sweeps = !(e3 && e3[0] == '0');
         c->inline_chain = c->L.C == 1 && c->L.mode == TGNH_MODE_TGNH && want;
