@@ -125,6 +125,20 @@ tgnh_status tgnh_get_local_dof_terms(tgnh_handle h, double* terms, int* count);
 tgnh_status tgnh_set_global_dof_terms(tgnh_handle h, const double* terms, int count);
 tgnh_status tgnh_set_allreduce(tgnh_handle h, tgnh_allreduce_fn fn, void* user);
 
+/* Mailbox exchange: the same all-reduce of the NT kinetic-energy sums, done by the integrator's own kernels with
+ * plain stores into every peer's mailbox over xGMI (no collective launch on the step's critical path).  Optional;
+ * when attached it replaces the hook above.  One rank per GPU (or several handles in one process):
+ *   create  allocates this rank's mailbox and returns its IPC handle (TGNH_XCHG_HANDLE_BYTES, for peers in other
+ *           processes) and its device pointer (for peers in this process);
+ *   attach  takes every rank's IPC handle, rank-major (own entry ignored) -- or every rank's pointer;
+ * then all ranks step in lockstep.  Sums are added in rank order on every rank: bit-identical thermostats.
+ * A peer that never answers sets status bit 2 after a bounded wait (tgnh_get_status_flags); nothing hangs. */
+#define TGNH_XCHG_HANDLE_BYTES 64
+tgnh_status tgnh_exchange_create(tgnh_handle h, int world, int rank, void* ipc_handle_out, void** mailbox_out);
+tgnh_status tgnh_exchange_attach(tgnh_handle h, const void* ipc_handles);
+tgnh_status tgnh_exchange_attach_pointers(tgnh_handle h, void* const* mailboxes);
+tgnh_status tgnh_exchange_detach(tgnh_handle h);
+
 /* One time step, split at the force call-out:
  *   begin: [KE -> chain ->] rescale, half kick, drift, hard wall
  *   (caller: virtual sites, calcForcesAndEnergy)

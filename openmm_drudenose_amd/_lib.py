@@ -49,6 +49,10 @@ SIGNATURES = {
     "tgnh_get_local_dof_terms": (C.c_int, [C.c_void_p, c_f64p, C.POINTER(C.c_int)]),
     "tgnh_set_global_dof_terms": (C.c_int, [C.c_void_p, c_f64p, C.c_int]),
     "tgnh_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+    "tgnh_exchange_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "tgnh_exchange_attach": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "tgnh_exchange_attach_pointers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "tgnh_exchange_detach": (C.c_int, [C.c_void_p]),
     "tgnh_step_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_step_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_step_begin_kick": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -257,6 +257,51 @@ __device__ __forceinline__ void run_tgnh(const ChainArgs& a, const double* st_in
 // run_tgnh<1, false>.
 struct Chain1Regs { double eta, etaDot0, etaDot1, etaDotDot, etaMass, nkbt, ke; };
 
+// ---- mailbox exchange (XchgArgs in tgnh_internal.h) ----
+__device__ __forceinline__ void xchg_store(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double xchg_load(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Called by one work-group with `mine` = this rank's sum in thread tid < NT.  Contains __syncthreads().
+__device__ __forceinline__ void xchg_send(const XchgArgs& x, const int NT, const int tid, const double mine) {
+    __shared__ unsigned long long s_seq;
+    if (tid == 0) { const unsigned long long s = *x.seq + 1ull; *x.seq = s; s_seq = s; }
+    __syncthreads();
+    const unsigned long long seq = s_seq;
+    const size_t slot = ((size_t)(seq & 1ull) * x.world + x.rank) * XCHG_STRIDE;
+    if (tid < NT)
+        for (int p = 0; p < x.world; p++) xchg_store(x.peers[p] + slot + 1 + tid, mine);
+    __threadfence_system();
+    __syncthreads();
+    if (tid < x.world)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(x.peers[tid] + slot), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Called by (at least) the first max(world, NT) lanes of one wavefront, converged.  Returns the all-rank sum of
+// thermostat itg (lanes itg < NT).
+__device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT, const int lane) {
+    const unsigned long long seq = __hip_atomic_load(x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const size_t base = (size_t)(seq & 1ull) * x.world * XCHG_STRIDE;
+    if (lane < x.world && __hip_atomic_load(x.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(x.mine + base + (size_t)lane * XCHG_STRIDE);
+        unsigned n = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            if (++n > XCHG_SPIN_LIMIT) {
+                atomicOr(x.status, 4u);
+                __hip_atomic_store(x.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // the payload loads below stay behind every lane's flag
+    double s = 0.0;
+    if (lane < NT)
+        for (int r = 0; r < x.world; r++) s += xchg_load(x.mine + base + (size_t)r * XCHG_STRIDE + 1 + lane);   // rank order
+    return s;
+}
+
 __device__ __forceinline__ Chain1Regs chain1_load(const ChainArgs& a, const double* st_in, const int itg) {
     const ChainLayout& L = a.L;
     Chain1Regs r;

@@ -367,6 +367,17 @@ static void make_layout(tgnh_context* c) {
 // ---------------------------------------------------------------------------
 // create / destroy
 // ---------------------------------------------------------------------------
+static void exchange_release(tgnh_context* c) {
+    for (void* p : c->x_opened) (void)hipIpcCloseMemHandle(p);
+    c->x_opened.clear();
+    if (c->x_mailbox) (void)hipFree(c->x_mailbox);
+    if (c->d_x_seq) (void)hipFree(c->d_x_seq);
+    if (c->d_x_dead) (void)hipFree(c->d_x_dead);
+    if (c->d_x_peers) (void)hipFree(c->d_x_peers);
+    c->x_mailbox = nullptr; c->d_x_seq = nullptr; c->d_x_dead = nullptr; c->d_x_peers = nullptr;
+    c->xchg_on = false;
+}
+
 static void free_device(tgnh_context* c) {
     if (c->d_meta) (void)hipFree(c->d_meta);
     if (c->d_tile_start) (void)hipFree(c->d_tile_start);
@@ -377,6 +388,7 @@ static void free_device(tgnh_context* c) {
     if (c->d_partials) (void)hipFree(c->d_partials);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    exchange_release(c);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_scalar) (void)hipFree(c->d_scalar);
     if (c->d_cl_atoms) (void)hipFree(c->d_cl_atoms);
@@ -543,6 +555,89 @@ extern "C" tgnh_status tgnh_set_global_dof_terms(tgnh_handle h, const double* te
     h->global_terms.assign(terms, terms + count);
     return finalize_thermostat(h);
 }
+// ---------------------------------------------------------------------------
+// mailbox exchange (SURVEY 8e done with stores over xGMI; protocol in tgnh_internal.h)
+// ---------------------------------------------------------------------------
+extern "C" tgnh_status tgnh_exchange_create(tgnh_handle h, int world, int rank, void* ipc_handle_out, void** mailbox_out) {
+    CHECK_H(h);
+    if (h->host_only) return fail(TGNH_ERR_STATE, "host-only handle");
+    if (world < 1 || world > XCHG_MAX_WORLD || rank < 0 || rank >= world) return fail(TGNH_ERR_ARG, "bad world / rank");
+    if (h->L.NT + 1 > XCHG_STRIDE) return fail(TGNH_ERR_UNSUPPORTED, "too many thermostats for a mailbox slot");
+    if (h->x_mailbox) return fail(TGNH_ERR_STATE, "exchange already created");
+    HIP_OK(hipSetDevice(h->device));
+    const size_t bytes = sizeof(double) * 2 * (size_t)world * XCHG_STRIDE;
+    void* p = nullptr;
+    HIP_OK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached));
+    h->x_mailbox = static_cast<double*>(p);
+    HIP_OK(hipMemset(h->x_mailbox, 0, bytes));
+    HIP_OK(hipMalloc(&h->d_x_seq, sizeof(unsigned long long)));
+    HIP_OK(hipMemset(h->d_x_seq, 0, sizeof(unsigned long long)));
+    HIP_OK(hipMalloc(&h->d_x_dead, sizeof(unsigned int)));
+    HIP_OK(hipMemset(h->d_x_dead, 0, sizeof(unsigned int)));
+    HIP_OK(hipMalloc(&h->d_x_peers, sizeof(double*) * world));
+    HIP_OK(hipDeviceSynchronize());
+    h->x_world = world; h->x_rank = rank;
+    if (ipc_handle_out) {
+        static_assert(sizeof(hipIpcMemHandle_t) == TGNH_XCHG_HANDLE_BYTES, "IPC handle size");
+        hipIpcMemHandle_t ih;
+        HIP_OK(hipIpcGetMemHandle(&ih, h->x_mailbox));
+        std::memcpy(ipc_handle_out, &ih, sizeof(ih));
+    }
+    if (mailbox_out) *mailbox_out = h->x_mailbox;
+    return TGNH_OK;
+}
+
+static tgnh_status exchange_finish_attach(tgnh_handle h, const std::vector<double*>& peers) {
+    HIP_OK(hipMemcpy(h->d_x_peers, peers.data(), sizeof(double*) * peers.size(), hipMemcpyHostToDevice));
+    h->x = XchgArgs{};
+    h->x.on = 1; h->x.world = h->x_world; h->x.rank = h->x_rank;
+    h->x.peers = h->d_x_peers; h->x.mine = h->x_mailbox; h->x.seq = h->d_x_seq; h->x.dead = h->d_x_dead;
+    h->x.status = h->d_status;
+    h->xchg_on = true;
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_exchange_attach(tgnh_handle h, const void* ipc_handles) {
+    CHECK_H(h);
+    if (!h->x_mailbox) return fail(TGNH_ERR_STATE, "tgnh_exchange_create first");
+    if (!ipc_handles) return fail(TGNH_ERR_ARG, "null handles");
+    tgnh_status rc = deferred_guard(h, "tgnh_exchange_attach"); if (rc) return rc;
+    HIP_OK(hipSetDevice(h->device));
+    std::vector<double*> peers(h->x_world, nullptr);
+    for (int r = 0; r < h->x_world; r++) {
+        if (r == h->x_rank) { peers[r] = h->x_mailbox; continue; }
+        hipIpcMemHandle_t ih;
+        std::memcpy(&ih, static_cast<const char*>(ipc_handles) + (size_t)r * TGNH_XCHG_HANDLE_BYTES, sizeof(ih));
+        void* p = nullptr;
+        HIP_OK(hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess));
+        h->x_opened.push_back(p);
+        peers[r] = static_cast<double*>(p);
+    }
+    return exchange_finish_attach(h, peers);
+}
+
+extern "C" tgnh_status tgnh_exchange_attach_pointers(tgnh_handle h, void* const* mailboxes) {
+    CHECK_H(h);
+    if (!h->x_mailbox) return fail(TGNH_ERR_STATE, "tgnh_exchange_create first");
+    if (!mailboxes) return fail(TGNH_ERR_ARG, "null mailboxes");
+    tgnh_status rc = deferred_guard(h, "tgnh_exchange_attach_pointers"); if (rc) return rc;
+    HIP_OK(hipSetDevice(h->device));
+    std::vector<double*> peers(h->x_world, nullptr);
+    for (int r = 0; r < h->x_world; r++) {
+        peers[r] = r == h->x_rank ? h->x_mailbox : static_cast<double*>(mailboxes[r]);
+        if (!peers[r]) return fail(TGNH_ERR_ARG, "null mailbox pointer");
+    }
+    return exchange_finish_attach(h, peers);
+}
+
+extern "C" tgnh_status tgnh_exchange_detach(tgnh_handle h) {
+    CHECK_H(h);
+    tgnh_status rc = deferred_guard(h, "tgnh_exchange_detach"); if (rc) return rc;
+    if (h->chain_pending && h->xwait_pending) return fail(TGNH_ERR_STATE, "an exchange is in flight (query the state or step first)");
+    h->xchg_on = false;
+    return TGNH_OK;
+}
+
 extern "C" tgnh_status tgnh_set_allreduce(tgnh_handle h, tgnh_allreduce_fn fn, void* user) {
     CHECK_H(h);
     h->allreduce = fn; h->allreduce_user = user;
@@ -630,6 +725,7 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
         a.chain_on = 1;
         a.chain = chain_args(h);
         a.chain.chain_twice = h->chain_pending_twice ? 1 : 0;
+        a.x_wait = h->xwait_pending ? 1 : 0;
         a.st_in = h->d_state;
         a.st_out = h->d_stage;
         inline_chain = true;
@@ -651,7 +747,7 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
         Timed t(h, s, kid);
         HIP_OK(launch_tile(h->d.precision, ops, h->gb, a, grid, lds, s));
     }
-    if (inline_chain) { h->chain_pending = false; h->stage_pending = true; }   // d_stage now holds the advanced thermostat
+    if (inline_chain) { h->chain_pending = false; h->xwait_pending = false; h->stage_pending = true; }   // d_stage now holds the advanced thermostat
     if (h->alternate_sweeps) h->sweep_reverse ^= 1;      // the next streaming launch starts where this one ends
     return TGNH_OK;
 }
@@ -663,6 +759,7 @@ static ChainArgs chain_args(tgnh_handle h) {
     a.dt = h->d.step_size; a.S = h->d.drude_steps_per_real_step;
     a.realkbT = h->realkbT; a.drudekbT = h->drudekbT;
     a.stage = h->d_stage;
+    if (h->xchg_on) a.x = h->x;
     a.commit = h->stage_pending ? 1 : 0;     // every chain_kernel launch takes over a staged block first
     h->stage_pending = false;
     return a;
@@ -681,6 +778,19 @@ static tgnh_status commit_stage(tgnh_handle h, hipStream_t s) {
 static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
     ChainArgs a = chain_args(h);
     a.chain_twice = twice ? 1 : 0;
+    if (h->xchg_on) {                // sharded, mailbox exchange: the sum launch sends; whoever runs the chain waits
+        a.do_sum = 1; a.x_send = 1;
+        if (h->inline_chain) {
+            a.do_chain = 0;
+            { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
+            h->chain_pending = true; h->chain_pending_twice = twice; h->xwait_pending = true;
+        } else {
+            a.do_chain = 1; a.x_wait = 1;
+            Timed t(h, s, KID_CHAIN);
+            HIP_OK(launch_chain(a, s));
+        }
+        return TGNH_OK;
+    }
     if (h->inline_chain) {           // sum (and all-reduce) now, the chain itself inside the next rescale launch
         a.do_sum = 1; a.do_chain = 0;
         { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
@@ -709,8 +819,9 @@ static tgnh_status materialize_chain(tgnh_handle h, hipStream_t s) {
     if (!h->chain_pending) return commit_stage(h, s);
     ChainArgs a = chain_args(h);
     a.do_sum = 0; a.do_chain = 1; a.chain_twice = h->chain_pending_twice ? 1 : 0;
+    a.x_wait = h->xwait_pending ? 1 : 0;
     { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
-    h->chain_pending = false;
+    h->chain_pending = false; h->xwait_pending = false;
     return TGNH_OK;
 }
 
@@ -959,8 +1070,9 @@ extern "C" tgnh_status tgnh_compute_kinetic_energies(tgnh_handle h, void* stream
     rc = run_tile(h, OP_KE, KID_KE, s); if (rc) return rc;
     ChainArgs a = chain_args(h);
     a.do_sum = 1; a.do_chain = 0;
+    if (h->xchg_on) { a.x_send = 1; a.x_wait = 1; }
     HIP_OK(launch_chain(a, s));
-    if (h->allreduce && h->allreduce(h->d_state + h->L.off_ke_red, h->L.NT, (void*)s, h->allreduce_user) != 0)
+    if (!h->xchg_on && h->allreduce && h->allreduce(h->d_state + h->L.off_ke_red, h->L.NT, (void*)s, h->allreduce_user) != 0)
         return fail(TGNH_ERR_HIP, "all-reduce hook failed");
     HIP_OK(hipMemcpyAsync(h->d_state + h->L.off_ke, h->d_state + h->L.off_ke_red, sizeof(double) * h->L.NT,
                           hipMemcpyDeviceToDevice, s));

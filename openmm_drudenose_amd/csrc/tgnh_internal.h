@@ -76,8 +76,35 @@ struct ChainLayout {
     int numTempGroup, idxMaxNHChains, iNumNHChains;
 };
 
+// Mailbox exchange of the per-thermostat kinetic-energy sums between the ranks of a sharded run (one GPU each),
+// the all-reduce of SURVEY 8e done with plain stores over xGMI instead of a collective launch:
+//   mailbox (uncached device memory, one per rank, mapped into every peer by IPC):
+//       slot[parity][source rank] = { sequence number, NT doubles }        XCHG_STRIDE doubles apart
+//   send  (chain_kernel after the row sum): seq = ++*counter; payload to slot[seq & 1][my rank] of EVERY rank's
+//         mailbox (its own too), system fence, then the sequence number;
+//   wait  (the chain wavefront of every work-group of the next rescale launch, or chain_kernel): spin until all
+//         `world` slots of the own mailbox carry seq, add them in rank order -> the same bits on every rank.
+// Two parities: a rank can be at most one exchange ahead of a peer that is still reading.  Every spin is bounded; a
+// time-out sets status bit 2 and the `dead` latch (later waits return at once), so a broken link ends in an error
+// report, never in a hung device.
+constexpr int XCHG_STRIDE = 40;             // doubles per slot: [0] sequence number, [1..NT] payload (NT <= 34)
+constexpr int XCHG_MAX_WORLD = 16;
+constexpr unsigned XCHG_SPIN_LIMIT = 400000u;   // polls (each a round trip to memory, ~0.5-1 us) before giving up
+
+struct XchgArgs {
+    int on;                     // 0 off
+    int world, rank;
+    double* const* peers;       // [world] every rank's mailbox as mapped here (peers[rank] = mine)
+    double* mine;
+    unsigned long long* seq;    // this rank's exchange counter (device)
+    unsigned int* dead;         // latch: an exchange timed out
+    unsigned int* status;       // the handle's status word (bit 2: exchange time-out)
+};
+
 struct ChainArgs {
     ChainLayout L;
+    XchgArgs x;
+    int x_send, x_wait;        // this launch sends its sums after the row sum / waits for everybody's before the chain
     double* st;                // thermostat block
     const double* partials;    // [nparts][NT] rows of the tile work-groups, then [nbig][NT] rows at GRID_CAP
     int nparts;
@@ -119,6 +146,7 @@ struct TileArgs {
     // energies itself; work-group 0 writes the advanced thermostat block to a staging copy (work-groups of this
     // launch may start after work-group 0 has finished, so st_in must stay untouched); the next chain_kernel commits it
     int chain_on;
+    int x_wait;                // the chain wavefront takes the kinetic energies from the mailbox exchange
     const double* st_in;
     double* st_out;
     ChainArgs chain;
@@ -215,6 +243,15 @@ struct tgnh_context {
     int64_t step_count = 0;
     tgnh_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
+    // mailbox exchange (tgnh_exchange_*): replaces the hook when attached
+    tgnh::XchgArgs x{};
+    bool xchg_on = false, xwait_pending = false;
+    int x_world = 0, x_rank = 0;
+    double* x_mailbox = nullptr;              // mine (uncached device memory)
+    double** d_x_peers = nullptr;             // device table of every rank's mailbox
+    std::vector<void*> x_opened;              // peers' mailboxes opened by IPC (to close)
+    unsigned long long* d_x_seq = nullptr;
+    unsigned int* d_x_dead = nullptr;
     // timing
     bool timing = false;
     int timing_only = -1;             // >= 0: only this kernel id is timed

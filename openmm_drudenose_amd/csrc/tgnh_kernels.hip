@@ -235,16 +235,21 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                 const bool write = blockIdx.x == 0;
                 const int itg = tid & 63;
                 TRACE(13);
-                if (itg < NT) {
-                    const Chain1Regs creg = chain1_load(a.chain, a.st_in, itg);
-                    chain1_run(a.chain, creg, a.st_out, write, s_scale, itg);
+                Chain1Regs creg{};
+                if (itg < NT) creg = chain1_load(a.chain, a.st_in, itg);
+                if (a.x_wait) {                                      // sharded: everybody's sums arrive by mailbox
+                    const double tot = xchg_wait_sum(a.chain.x, NT, itg);
+                    creg.ke = tot;
+                    if (itg < NT) s_scale[itg] = tot;                // parked for the KESum below (same wavefront: in order)
+                    if (write && itg < NT) a.chain.st[L.off_ke_red + itg] = tot;   // nobody reads it there in this launch
                 }
-                TRACE(14);
                 if (write && itg == 63) {                            // Cu :493-497
                     double s = 0.0;
-                    for (int i = 0; i < NT; i++) s += a.st_in[L.off_ke_red + i];
+                    for (int i = 0; i < NT; i++) s += a.x_wait ? s_scale[i] : a.st_in[L.off_ke_red + i];
                     a.st_out[L.off_kesum] = 0.5 * s;
                 }
+                if (itg < NT) chain1_run(a.chain, creg, a.st_out, write, s_scale, itg);
+                TRACE(14);
                 if (have_tile) load_tile(blockIdx.x, cur);
             }   // (dualNH keeps the separate chain launch: its coupled vectors would cost this kernel ~50 VGPRs)
         } else if (tid < NT) {
@@ -679,6 +684,15 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
         __syncthreads();
     } else if (tid < NT) {
         s_ke[tid] = st[L.off_ke_red + tid];      // summed (and all-reduced) by an earlier launch
+    }
+    if (a.x_send) xchg_send(a.x, NT, tid, tid < NT ? s_ke[tid] : 0.0);
+    if (a.x_wait) {
+        __syncthreads();
+        if (tid < 64) {
+            const double tot = xchg_wait_sum(a.x, NT, tid);
+            if (tid < NT) { s_ke[tid] = tot; st[L.off_ke_red + tid] = tot; }
+        }
+        __syncthreads();
     }
     if (!a.do_chain) return;
     if (!a.do_sum) __syncthreads();

@@ -357,6 +357,28 @@ class HipContext(_HandleQueries):
         self._views = {}
         _check(self.lib.tgnh_set_allreduce(self.h, self._hook, None))
 
+    # ---- mailbox exchange over xGMI (include/drude_tgnh.h: tgnh_exchange_*) ----
+    XCHG_HANDLE_BYTES = 64
+
+    def exchange_create(self, world, rank):
+        """-> (IPC handle bytes for peers in other processes, device pointer for peers in this process)"""
+        buf = C.create_string_buffer(self.XCHG_HANDLE_BYTES)
+        ptr = C.c_void_p()
+        _check(self.lib.tgnh_exchange_create(self.h, int(world), int(rank), buf, C.byref(ptr)))
+        return buf.raw, ptr.value
+
+    def exchange_attach(self, handles):
+        """handles: every rank's IPC handle bytes, in rank order (own entry ignored)."""
+        blob = b"".join(handles)
+        _check(self.lib.tgnh_exchange_attach(self.h, blob))
+
+    def exchange_attach_pointers(self, pointers):
+        arr = (C.c_void_p * len(pointers))(*[C.c_void_p(p) for p in pointers])
+        _check(self.lib.tgnh_exchange_attach_pointers(self.h, arr))
+
+    def exchange_detach(self):
+        _check(self.lib.tgnh_exchange_detach(self.h))
+
     def _ke_view(self, ptr, count):
         key = (ptr, count)
         v = self._views.get(key)

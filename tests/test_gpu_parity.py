@@ -538,6 +538,77 @@ def test_particle_sharded_hip_path_on_one_gpu():
         c.close()
 
 
+@pytest.mark.parametrize("variant,chains,nranks", [(FLAG_DEFER_SCALE, 1, 2), (0, 1, 2), (FLAG_DEFER_SCALE, 3, 2), (0, 3, 2)])
+def test_particle_sharded_mailbox_exchange_on_one_gpu(variant, chains, nranks):
+    """The mailbox exchange (tgnh_exchange_*: the KE all-reduce done by the integrator's own kernels with stores into
+    every peer's mailbox) with the 'ranks' as handles on this one GPU, each on its own stream, mailboxes attached by
+    pointer: every rank's rescale launch spins until all ranks' sum launches have delivered.  Trajectory = the
+    unsharded one; thermostats bit-identical on all ranks.  chains = 1 waits inside the rescale launch's prologue,
+    chains = 3 inside the chain launch.  (Two ranks, on a normal- and a high-priority stream: streams of one process
+    share a few hardware queues, and a rank spinning in front of its peer's sum launch in the same queue could only
+    time out; one process per GPU has no such coupling.)"""
+    from openmm_drudenose_amd.system import shard_bounds
+    s, g, ng = synth.mixed(400, 30)
+    it = integ(chains=chains, hardwall=0.02)
+    bind_groups(it, g, ng)
+    ref = HipContext(s, it, mode="TGNH", precision="double", flags=variant)
+    torch = ref.torch
+    b = shard_bounds(s, nranks)
+    parts, terms, streams = [], [], []
+    for r in range(nranks):
+        loc, lg = s.slice_molecules(b[r], b[r + 1]), g[b[r]:b[r + 1]]
+        itr = integ(chains=chains, hardwall=0.02)
+        bind_groups(itr, lg, ng)
+        parts.append(HipContext(loc, itr, mode="TGNH", precision="double", flags=variant))
+        terms.append(parts[-1].local_dof_terms())
+        streams.append(torch.cuda.Stream(priority=-r))       # normal / high priority: two different hardware queues
+    total = sum(terms)
+    boxes = [c.exchange_create(nranks, r)[1] for r, c in enumerate(parts)]
+    for c in parts:
+        c.set_global_dof_terms(total)
+        c.exchange_attach_pointers(boxes)
+    torch.cuda.synchronize()
+    for _ in range(40):
+        ref.step_begin(); ref.compute_forces(); ref.step_end()
+        for c, st in zip(parts, streams):
+            with torch.cuda.stream(st):
+                c.step_begin(); c.compute_forces(); c.step_end()
+    torch.cuda.synchronize()
+    for c in parts:
+        assert c.check() & 4 == 0                  # no exchange time-out
+    pos = np.concatenate([c.getPositions() for c in parts])
+    vel = np.concatenate([c.getVelocities() for c in parts])
+    assert rel_err(pos, ref.getPositions()) < 1e-12 and rel_err(vel, ref.getVelocities()) < 1e-10
+    for c in parts[1:]:
+        for which in (0, 1):
+            assert np.array_equal(parts[0].thermostat_state(which), c.thermostat_state(which))   # rank-order sums: bitwise
+    assert np.allclose(parts[0].thermostat_state(1), ref.thermostat_state(1), rtol=1e-9, atol=1e-13)
+    for c in parts + [ref]:
+        c.close()
+
+
+def test_mailbox_exchange_times_out_instead_of_hanging():
+    """A peer that never sends: the wait is bounded, status bit 2 is raised, later waits return at once."""
+    import time
+    s, g, ng = synth.water_box(27)
+    it = integ(chains=1)
+    bind_groups(it, g, ng)
+    a, b = HipContext(s, it, mode="TGNH", precision="double"), HipContext(s, integ(chains=1), mode="TGNH", precision="double")
+    boxes = [a.exchange_create(2, 0)[1], b.exchange_create(2, 1)[1]]
+    a.exchange_attach_pointers(boxes)
+    t0 = time.time()
+    a.step_begin()                                   # rank 1 never steps
+    a.torch.cuda.synchronize()
+    first = time.time() - t0
+    assert a.check() & 4
+    t0 = time.time()
+    a.compute_forces(); a.step_end(); a.step_begin()
+    a.torch.cuda.synchronize()
+    assert time.time() - t0 < 0.5 * first + 0.05     # the latch: no second long wait
+    assert first < 30.0
+    a.close(); b.close()
+
+
 def test_against_committed_regression_vectors():
     """The HIP path against tests/golden/oracle_regression.npz (the oracle's frozen outputs; data only, so this check
     does not need the oracle at run time)."""
