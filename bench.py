@@ -7,7 +7,9 @@ SWM4-NDP water box of 1,000,000 molecules (5,000,000 particle slots, 1,000,000 D
 state resident in HBM.  The force call-out (OpenMM's calcForcesAndEnergy in a real context) is
 the harness spring kernel and is INSIDE the timed region.  N > 1 shards whole molecules over the
 ranks (strong scaling: the 1 M-pair system is fixed) with one all-reduce of the per-thermostat
-kinetic-energy sums per thermostat half step (RCCL through torch.distributed).
+kinetic-energy sums per thermostat half step: RCCL through torch.distributed, or -- after a short
+run on a small box has shown both to agree on this node -- the library's mailbox exchange (stores
+into every peer's mailbox over xGMI, waited for inside the rescale launch; --exchange).
 
 Prints ONE JSON line on rank 0.
 """
@@ -44,6 +46,9 @@ def parse():
     p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                    help="replay the step loop from a hipGraph (auto: on when sharded over >1 GPU, where launches are short)")
     p.add_argument("--graph-steps", type=int, default=10, help="time steps per captured graph")
+    p.add_argument("--exchange", default="auto", choices=["auto", "mailbox", "rccl"],
+                   help="KE all-reduce of a sharded run: rccl = torch.distributed all_reduce; mailbox = tgnh_exchange_* "
+                        "(stores over xGMI); auto = mailbox if a validation run on a small box agrees with rccl on every rank")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the extra single-precision / variant legs")
     return p.parse_args()
@@ -75,7 +80,79 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
             dist.all_reduce(t)
             return t.cpu().numpy()
         kw = dict(allreduce=lambda t: dist.all_reduce(t), global_dof_sum=dof_sum)
-    return HipContext(local, it, mode=args.mode, precision=precision, device=dev, flags=flags, **kw)
+    ctx = HipContext(local, it, mode=args.mode, precision=precision, device=dev, flags=flags, **kw)
+    ctx.exchange = "rccl" if kw else None
+    return ctx
+
+
+def attach_mailbox(ctx, rank, world):
+    """Every rank's mailbox mapped into every other rank (IPC handles through the process group).  All ranks end up
+    with the same answer: True = mailbox exchange attached everywhere, False = nobody uses it."""
+    import torch
+    import torch.distributed as dist
+    ok = 1
+    try:
+        handle, _ = ctx.exchange_create(world, rank)
+        handles = [None] * world
+        dist.all_gather_object(handles, handle)
+        ctx.exchange_attach(handles)
+    except Exception as e:
+        print(f"[bench] rank {rank}: mailbox exchange not available ({type(e).__name__}: {e})", file=sys.stderr)
+        ok = 0
+    t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if int(t.item()) == 0:
+        if ok:
+            ctx.exchange_detach()
+        return False
+    ctx.exchange = "mailbox"
+    return True
+
+
+def all_ranks_agree(ok):
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
+def validate_mailbox(args, rank, world):
+    """A small sharded box stepped twice, with the RCCL hook and with the mailbox exchange: the thermostats must agree
+    (different summation order: 1e-9), be bit-identical over the ranks with the mailbox, and no wait may time out."""
+    import copy
+    import torch
+    import torch.distributed as dist
+    from openmm_drudenose_amd import synth
+    small = copy.copy(args)
+    system, group, ngroups = synth.water_box(3000 * world)
+    res = {}
+    for which in ("rccl", "mailbox"):
+        ctx = build_context(small, system, group, ngroups, rank, world, args.precision, args.variant)
+        attached = which == "rccl" or attach_mailbox(ctx, rank, world)
+        if not attached:
+            ctx.close()
+            return False
+        ctx.step(60)
+        torch.cuda.synchronize()
+        eta = torch.from_numpy(np.concatenate([ctx.thermostat_state(0), ctx.thermostat_state(1)])).cuda()
+        flags = ctx.check()
+        if which == "mailbox":
+            every = [torch.empty_like(eta) for _ in range(world)]
+            dist.all_gather(every, eta)
+            same = all(torch.equal(every[0], e) for e in every)
+            if not all_ranks_agree(same and (flags & 4) == 0):
+                print(f"[bench] rank {rank}: mailbox validation failed (identical over ranks: {same}, flags {flags})", file=sys.stderr)
+                ctx.close()
+                return False
+        res[which] = eta.cpu().numpy()
+        dist.barrier()
+        ctx.close()
+    close = np.allclose(res["mailbox"], res["rccl"], rtol=1e-9, atol=1e-13)
+    if not all_ranks_agree(close):
+        print(f"[bench] rank {rank}: mailbox and rccl thermostats differ", file=sys.stderr)
+        return False
+    return True
 
 
 def timed_run(ctx, steps, warmup, world, graph_steps=0):
@@ -89,11 +166,17 @@ def timed_run(ctx, steps, warmup, world, graph_steps=0):
     if graph_steps > 0:
         try:
             replay = ctx.capture_steps(graph_steps)
-            replay()                                   # first replay = the steps the capture recorded; untimed
-            torch.cuda.synchronize()
         except Exception as e:                         # capture unsupported here: stay eager
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             replay = None
+        if world > 1:                                  # every rank replays, or none does: their exchanges must pair up
+            t = torch.tensor([1 if replay is not None else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)   # (also a barrier: captures take different times, mailbox waits are bounded)
+            if int(t.item()) == 0:
+                replay = None
+        torch.cuda.synchronize()
+        if replay is not None:
+            replay()                                   # first replay = the steps the capture recorded; untimed
             torch.cuda.synchronize()
     ctx.graph_used = replay is not None
     if replay is None:
@@ -232,10 +315,26 @@ def main():
     from openmm_drudenose_amd import synth, _lib
     system, group, ngroups = synth.water_box(args.molecules)
 
-    ctx = build_context(args, system, group, ngroups, rank, world, args.precision, args.variant)
     use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
-    dt = timed_run(ctx, args.steps, args.warmup, world, args.graph_steps if use_graph else 0)
+    want_mailbox = use_dist and args.exchange != "rccl" and args.mode == "TGNH"
+    if want_mailbox and args.exchange == "auto":
+        want_mailbox = validate_mailbox(args, rank, world)
+        if rank == 0:
+            print(f"[bench] mailbox exchange validated against rccl: {want_mailbox}", file=sys.stderr)
+    while True:
+        ctx = build_context(args, system, group, ngroups, rank, world, args.precision, args.variant)
+        if want_mailbox:
+            attach_mailbox(ctx, rank, world)
+        dt = timed_run(ctx, args.steps, args.warmup, world, args.graph_steps if use_graph else 0)
+        if ctx.exchange == "mailbox" and not all_ranks_agree((ctx.check() & 4) == 0):
+            # a wait timed out during the measurement: that number means nothing -- measure again over RCCL
+            print(f"[bench] rank {rank}: mailbox exchange timed out in the timed run; repeating with rccl", file=sys.stderr)
+            ctx.close()
+            want_mailbox = False
+            continue
+        break
     graph_used = ctx.graph_used
+    exchange_used = ctx.exchange
     rows = kernel_table(ctx)
     assert ctx.check() == 0
     # dominant kernel: the fused rescale + half kick + drift (+ hard wall) pass
@@ -282,6 +381,7 @@ def main():
                             f"{args.hardwall} nm, harness force call-out inside the timed region",
                 "precision": args.precision, "variant": args.variant, "hipgraph": graph_used,
                 "parallelism": f"particle-sharded x{world} (whole molecules), KE all-reduce per thermostat half step",
+                "exchange": exchange_used,
                 "slots_per_gpu": local_slots,
                 "model_bytes_per_step": b_step,
                 "step_GBps_vs_model": round(b_step / (dt / args.steps) / 1e9 / world, 1),

@@ -257,48 +257,71 @@ __device__ __forceinline__ void run_tgnh(const ChainArgs& a, const double* st_in
 // run_tgnh<1, false>.
 struct Chain1Regs { double eta, etaDot0, etaDot1, etaDotDot, etaMass, nkbt, ke; };
 
-// ---- mailbox exchange (XchgArgs in tgnh_internal.h) ----
-__device__ __forceinline__ void xchg_store(double* p, double v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// ---- mailbox exchange (protocol: XchgArgs in tgnh_internal.h) ----
+__device__ __forceinline__ size_t xchg_cell(const XchgArgs& x, const unsigned par, const int src, const int i) {
+    return (((size_t)par * x.world + src) * XCHG_NT_PAD + i) * XCHG_CELL_U64;
 }
-__device__ __forceinline__ double xchg_load(const double* p) {
+__device__ __forceinline__ unsigned long long xchg_ld(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// Called by one work-group with `mine` = this rank's sum in thread tid < NT.  Contains __syncthreads().
-__device__ __forceinline__ void xchg_send(const XchgArgs& x, const int NT, const int tid, const double mine) {
+// Called by one work-group with `mine` = this rank's sum in thread tid < NT, handed over through s_val (LDS, NT doubles).
+// Contains __syncthreads().
+__device__ __forceinline__ void xchg_send(const XchgArgs& x, const int NT, const int tid, const int nthreads, double* s_val,
+                                          const double mine) {
     __shared__ unsigned long long s_seq;
     if (tid == 0) { const unsigned long long s = *x.seq + 1ull; *x.seq = s; s_seq = s; }
+    if (tid < NT) s_val[tid] = mine;
     __syncthreads();
-    const unsigned long long seq = s_seq;
-    const size_t slot = ((size_t)(seq & 1ull) * x.world + x.rank) * XCHG_STRIDE;
-    if (tid < NT)
-        for (int p = 0; p < x.world; p++) xchg_store(x.peers[p] + slot + 1 + tid, mine);
-    __threadfence_system();
-    __syncthreads();
-    if (tid < x.world)
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(x.peers[tid] + slot), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// Called by (at least) the first max(world, NT) lanes of one wavefront, converged.  Returns the all-rank sum of
-// thermostat itg (lanes itg < NT).
-__device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT, const int lane) {
-    const unsigned long long seq = __hip_atomic_load(x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const size_t base = (size_t)(seq & 1ull) * x.world * XCHG_STRIDE;
-    if (lane < x.world && __hip_atomic_load(x.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-        const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(x.mine + base + (size_t)lane * XCHG_STRIDE);
-        unsigned n = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-            if (++n > XCHG_SPIN_LIMIT) {
-                atomicOr(x.status, 4u);
-                __hip_atomic_store(x.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(8);
-        }
+    const unsigned long long seq = s_seq, tag = (seq & 0xffffffffull) << 32;
+    for (int k = tid; k < x.world * NT; k += nthreads) {
+        const int p = k / NT, i = k - p * NT;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(s_val[i]);
+        unsigned long long* cell = x.peers[p] + xchg_cell(x, (unsigned)(seq & 1ull), x.rank, i);
+        __hip_atomic_store(cell, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(cell + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // the payload loads below stay behind every lane's flag
+}
+// Called by all 64 lanes of one wavefront, converged; s_val = LDS scratch of world*NT doubles owned by that wavefront.
+// Returns the all-rank sum of thermostat `lane` (lanes < NT).
+__device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT, const int lane, double* s_val) {
+    const int cells = x.world * NT;
+    // first batch: counter, latch and both parities of this lane's first cell, all in flight together
+    const unsigned long long seq_raw = __hip_atomic_load(x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned dead = __hip_atomic_load(x.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    if (lane < cells) {
+        const int r = lane / NT, i = lane - r * NT;
+        const unsigned long long* c0 = x.mine + xchg_cell(x, 0u, r, i);
+        const unsigned long long* c1 = x.mine + xchg_cell(x, 1u, r, i);
+        a0 = xchg_ld(c0); a1 = xchg_ld(c0 + 1); b0 = xchg_ld(c1); b1 = xchg_ld(c1 + 1);
+    }
+    const unsigned par = (unsigned)(seq_raw & 1ull);
+    const unsigned long long tag = seq_raw & 0xffffffffull;
+    bool timed_out = false;
+    for (int k = lane; k < cells; k += 64) {
+        const int r = k / NT, i = k - r * NT;
+        const unsigned long long* c = x.mine + xchg_cell(x, par, r, i);
+        unsigned long long w0, w1;
+        if (k == lane) { w0 = par ? b0 : a0; w1 = par ? b1 : a1; }
+        else { w0 = xchg_ld(c); w1 = xchg_ld(c + 1); }
+        unsigned n = 0;
+        while (((w0 >> 32) != tag || (w1 >> 32) != tag) && dead == 0u && !timed_out) {
+            if (++n > XCHG_SPIN_LIMIT) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(4);
+            w0 = xchg_ld(c); w1 = xchg_ld(c + 1);
+        }
+        s_val[k] = __longlong_as_double((long long)((w1 << 32) | (w0 & 0xffffffffull)));
+    }
+    if (timed_out) {
+        atomicOr(x.status, 4u);
+        __hip_atomic_store(x.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double s = 0.0;
     if (lane < NT)
-        for (int r = 0; r < x.world; r++) s += xchg_load(x.mine + base + (size_t)r * XCHG_STRIDE + 1 + lane);   // rank order
+        for (int r = 0; r < x.world; r++) s += s_val[r * NT + lane];       // rank order, on every rank
     return s;
 }
 

@@ -562,19 +562,19 @@ extern "C" tgnh_status tgnh_exchange_create(tgnh_handle h, int world, int rank, 
     CHECK_H(h);
     if (h->host_only) return fail(TGNH_ERR_STATE, "host-only handle");
     if (world < 1 || world > XCHG_MAX_WORLD || rank < 0 || rank >= world) return fail(TGNH_ERR_ARG, "bad world / rank");
-    if (h->L.NT + 1 > XCHG_STRIDE) return fail(TGNH_ERR_UNSUPPORTED, "too many thermostats for a mailbox slot");
+    if (h->L.NT > XCHG_NT_PAD) return fail(TGNH_ERR_UNSUPPORTED, "too many thermostats for a mailbox");
     if (h->x_mailbox) return fail(TGNH_ERR_STATE, "exchange already created");
     HIP_OK(hipSetDevice(h->device));
-    const size_t bytes = sizeof(double) * 2 * (size_t)world * XCHG_STRIDE;
+    const size_t bytes = XCHG_MAILBOX_BYTES(world);
     void* p = nullptr;
     HIP_OK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached));
-    h->x_mailbox = static_cast<double*>(p);
+    h->x_mailbox = static_cast<unsigned long long*>(p);
     HIP_OK(hipMemset(h->x_mailbox, 0, bytes));
     HIP_OK(hipMalloc(&h->d_x_seq, sizeof(unsigned long long)));
     HIP_OK(hipMemset(h->d_x_seq, 0, sizeof(unsigned long long)));
     HIP_OK(hipMalloc(&h->d_x_dead, sizeof(unsigned int)));
     HIP_OK(hipMemset(h->d_x_dead, 0, sizeof(unsigned int)));
-    HIP_OK(hipMalloc(&h->d_x_peers, sizeof(double*) * world));
+    HIP_OK(hipMalloc(&h->d_x_peers, sizeof(unsigned long long*) * world));
     HIP_OK(hipDeviceSynchronize());
     h->x_world = world; h->x_rank = rank;
     if (ipc_handle_out) {
@@ -587,8 +587,8 @@ extern "C" tgnh_status tgnh_exchange_create(tgnh_handle h, int world, int rank, 
     return TGNH_OK;
 }
 
-static tgnh_status exchange_finish_attach(tgnh_handle h, const std::vector<double*>& peers) {
-    HIP_OK(hipMemcpy(h->d_x_peers, peers.data(), sizeof(double*) * peers.size(), hipMemcpyHostToDevice));
+static tgnh_status exchange_finish_attach(tgnh_handle h, const std::vector<unsigned long long*>& peers) {
+    HIP_OK(hipMemcpy(h->d_x_peers, peers.data(), sizeof(unsigned long long*) * peers.size(), hipMemcpyHostToDevice));
     h->x = XchgArgs{};
     h->x.on = 1; h->x.world = h->x_world; h->x.rank = h->x_rank;
     h->x.peers = h->d_x_peers; h->x.mine = h->x_mailbox; h->x.seq = h->d_x_seq; h->x.dead = h->d_x_dead;
@@ -603,7 +603,7 @@ extern "C" tgnh_status tgnh_exchange_attach(tgnh_handle h, const void* ipc_handl
     if (!ipc_handles) return fail(TGNH_ERR_ARG, "null handles");
     tgnh_status rc = deferred_guard(h, "tgnh_exchange_attach"); if (rc) return rc;
     HIP_OK(hipSetDevice(h->device));
-    std::vector<double*> peers(h->x_world, nullptr);
+    std::vector<unsigned long long*> peers(h->x_world, nullptr);
     for (int r = 0; r < h->x_world; r++) {
         if (r == h->x_rank) { peers[r] = h->x_mailbox; continue; }
         hipIpcMemHandle_t ih;
@@ -611,7 +611,7 @@ extern "C" tgnh_status tgnh_exchange_attach(tgnh_handle h, const void* ipc_handl
         void* p = nullptr;
         HIP_OK(hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess));
         h->x_opened.push_back(p);
-        peers[r] = static_cast<double*>(p);
+        peers[r] = static_cast<unsigned long long*>(p);
     }
     return exchange_finish_attach(h, peers);
 }
@@ -622,9 +622,9 @@ extern "C" tgnh_status tgnh_exchange_attach_pointers(tgnh_handle h, void* const*
     if (!mailboxes) return fail(TGNH_ERR_ARG, "null mailboxes");
     tgnh_status rc = deferred_guard(h, "tgnh_exchange_attach_pointers"); if (rc) return rc;
     HIP_OK(hipSetDevice(h->device));
-    std::vector<double*> peers(h->x_world, nullptr);
+    std::vector<unsigned long long*> peers(h->x_world, nullptr);
     for (int r = 0; r < h->x_world; r++) {
-        peers[r] = r == h->x_rank ? h->x_mailbox : static_cast<double*>(mailboxes[r]);
+        peers[r] = r == h->x_rank ? h->x_mailbox : static_cast<unsigned long long*>(mailboxes[r]);
         if (!peers[r]) return fail(TGNH_ERR_ARG, "null mailbox pointer");
     }
     return exchange_finish_attach(h, peers);

@@ -79,23 +79,27 @@ struct ChainLayout {
 // Mailbox exchange of the per-thermostat kinetic-energy sums between the ranks of a sharded run (one GPU each),
 // the all-reduce of SURVEY 8e done with plain stores over xGMI instead of a collective launch:
 //   mailbox (uncached device memory, one per rank, mapped into every peer by IPC):
-//       slot[parity][source rank] = { sequence number, NT doubles }        XCHG_STRIDE doubles apart
-//   send  (chain_kernel after the row sum): seq = ++*counter; payload to slot[seq & 1][my rank] of EVERY rank's
-//         mailbox (its own too), system fence, then the sequence number;
-//   wait  (the chain wavefront of every work-group of the next rescale launch, or chain_kernel): spin until all
-//         `world` slots of the own mailbox carry seq, add them in rank order -> the same bits on every rank.
+//       cell[parity][source rank][thermostat] = 16 bytes: two words { 32 bits of the double, 32-bit sequence number }
+//   send  (chain_kernel after the row sum): seq = ++*counter; every value goes into cell[seq & 1][my rank][i] of EVERY
+//         rank's mailbox (its own too).  Data and sequence number travel in the same 8-byte store, which is atomic,
+//         so there is no flag to order behind the data and no fence on either side;
+//   wait  (the chain wavefront of every work-group of the next rescale launch, or chain_kernel): read the cells of
+//         the own mailbox until all world x NT of them carry seq, add them in rank order -> same bits on every rank.
+//         Both parities and the counter are fetched in one batch: one memory round trip when the data is already there.
 // Two parities: a rank can be at most one exchange ahead of a peer that is still reading.  Every spin is bounded; a
 // time-out sets status bit 2 and the `dead` latch (later waits return at once), so a broken link ends in an error
 // report, never in a hung device.
-constexpr int XCHG_STRIDE = 40;             // doubles per slot: [0] sequence number, [1..NT] payload (NT <= 34)
+constexpr int XCHG_NT_PAD = 40;             // cells per source rank (NT <= 34)
+constexpr int XCHG_CELL_U64 = 2;            // 8-byte words per cell
 constexpr int XCHG_MAX_WORLD = 16;
-constexpr unsigned XCHG_SPIN_LIMIT = 400000u;   // polls (each a round trip to memory, ~0.5-1 us) before giving up
+constexpr unsigned XCHG_SPIN_LIMIT = 1000000u;  // polls (each a round trip to memory, ~2 us) before giving up: seconds
+constexpr size_t XCHG_MAILBOX_BYTES(int world) { return sizeof(unsigned long long) * 2 * (size_t)world * XCHG_NT_PAD * XCHG_CELL_U64; }
 
 struct XchgArgs {
     int on;                     // 0 off
     int world, rank;
-    double* const* peers;       // [world] every rank's mailbox as mapped here (peers[rank] = mine)
-    double* mine;
+    unsigned long long* const* peers;   // [world] every rank's mailbox as mapped here (peers[rank] = mine)
+    unsigned long long* mine;
     unsigned long long* seq;    // this rank's exchange counter (device)
     unsigned int* dead;         // latch: an exchange timed out
     unsigned int* status;       // the handle's status word (bit 2: exchange time-out)
@@ -247,8 +251,8 @@ struct tgnh_context {
     tgnh::XchgArgs x{};
     bool xchg_on = false, xwait_pending = false;
     int x_world = 0, x_rank = 0;
-    double* x_mailbox = nullptr;              // mine (uncached device memory)
-    double** d_x_peers = nullptr;             // device table of every rank's mailbox
+    unsigned long long* x_mailbox = nullptr;  // mine (uncached device memory)
+    unsigned long long** d_x_peers = nullptr; // device table of every rank's mailbox
     std::vector<void*> x_opened;              // peers' mailboxes opened by IPC (to close)
     unsigned long long* d_x_seq = nullptr;
     unsigned int* d_x_dead = nullptr;

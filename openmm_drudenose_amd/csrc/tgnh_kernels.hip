@@ -238,7 +238,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                 Chain1Regs creg{};
                 if (itg < NT) creg = chain1_load(a.chain, a.st_in, itg);
                 if (a.x_wait) {                                      // sharded: everybody's sums arrive by mailbox
-                    const double tot = xchg_wait_sum(a.chain.x, NT, itg);
+                    const double tot = xchg_wait_sum(a.chain.x, NT, itg, reinterpret_cast<double*>(smem));   // the images are not in use yet
                     creg.ke = tot;
                     if (itg < NT) s_scale[itg] = tot;                // parked for the KESum below (same wavefront: in order)
                     if (write && itg < NT) a.chain.st[L.off_ke_red + itg] = tot;   // nobody reads it there in this launch
@@ -685,11 +685,11 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
     } else if (tid < NT) {
         s_ke[tid] = st[L.off_ke_red + tid];      // summed (and all-reduced) by an earlier launch
     }
-    if (a.x_send) xchg_send(a.x, NT, tid, tid < NT ? s_ke[tid] : 0.0);
+    if (a.x_send) xchg_send(a.x, NT, tid, BLOCK, s_chain, tid < NT ? s_ke[tid] : 0.0);
     if (a.x_wait) {
         __syncthreads();
         if (tid < 64) {
-            const double tot = xchg_wait_sum(a.x, NT, tid);
+            const double tot = xchg_wait_sum(a.x, NT, tid, s_chain);
             if (tid < NT) { s_ke[tid] = tot; st[L.off_ke_red + tid] = tot; }
         }
         __syncthreads();
