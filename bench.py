@@ -109,6 +109,18 @@ def attach_mailbox(ctx, rank, world):
     return True
 
 
+def close_sharded(ctx):
+    """unmap the peers' mailboxes, wait for everybody, then free (a mailbox must outlive its mappings)"""
+    import torch
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if ctx.exchange == "mailbox":
+        ctx.exchange_detach()
+    if ctx.exchange is not None:
+        dist.barrier()
+    ctx.close()
+
+
 def all_ranks_agree(ok):
     import torch
     import torch.distributed as dist
@@ -131,7 +143,7 @@ def validate_mailbox(args, rank, world):
         ctx = build_context(small, system, group, ngroups, rank, world, args.precision, args.variant)
         attached = which == "rccl" or attach_mailbox(ctx, rank, world)
         if not attached:
-            ctx.close()
+            close_sharded(ctx)
             return False
         ctx.step(60)
         torch.cuda.synchronize()
@@ -143,11 +155,10 @@ def validate_mailbox(args, rank, world):
             same = all(torch.equal(every[0], e) for e in every)
             if not all_ranks_agree(same and (flags & 4) == 0):
                 print(f"[bench] rank {rank}: mailbox validation failed (identical over ranks: {same}, flags {flags})", file=sys.stderr)
-                ctx.close()
+                close_sharded(ctx)
                 return False
         res[which] = eta.cpu().numpy()
-        dist.barrier()
-        ctx.close()
+        close_sharded(ctx)
     close = np.allclose(res["mailbox"], res["rccl"], rtol=1e-9, atol=1e-13)
     if not all_ranks_agree(close):
         print(f"[bench] rank {rank}: mailbox and rccl thermostats differ", file=sys.stderr)
@@ -329,7 +340,7 @@ def main():
         if ctx.exchange == "mailbox" and not all_ranks_agree((ctx.check() & 4) == 0):
             # a wait timed out during the measurement: that number means nothing -- measure again over RCCL
             print(f"[bench] rank {rank}: mailbox exchange timed out in the timed run; repeating with rccl", file=sys.stderr)
-            ctx.close()
+            close_sharded(ctx)
             want_mailbox = False
             continue
         break
@@ -346,7 +357,7 @@ def main():
         dom = dict(rows.get("scale+kick+drift"), where="HIP events in the instrumented repeat (timed region was a hipGraph replay)")
     achieved = bytes_dom / (dom["avg_us"] * 1e-6) / 1e9
     local_slots = ctx.n
-    ctx.close()
+    close_sharded(ctx)
 
     copy_gbps = device_copy_gbps() if rank == 0 else None
     extra = {}

@@ -132,7 +132,9 @@ tgnh_status tgnh_set_allreduce(tgnh_handle h, tgnh_allreduce_fn fn, void* user);
  *           processes) and its device pointer (for peers in this process);
  *   attach  takes every rank's IPC handle, rank-major (own entry ignored) -- or every rank's pointer;
  * then all ranks step in lockstep.  Sums are added in rank order on every rank: bit-identical thermostats.
- * A peer that never answers sets status bit 2 after a bounded wait (tgnh_get_status_flags); nothing hangs. */
+ * A peer that never answers sets status bit 2 after a bounded wait (tgnh_get_status_flags); nothing hangs.
+ * Teardown across processes: every rank detaches (unmaps the peers' mailboxes), then -- after a barrier of the
+ * caller's -- destroys its handle (frees its own mailbox). */
 #define TGNH_XCHG_HANDLE_BYTES 64
 tgnh_status tgnh_exchange_create(tgnh_handle h, int world, int rank, void* ipc_handle_out, void** mailbox_out);
 tgnh_status tgnh_exchange_attach(tgnh_handle h, const void* ipc_handles);

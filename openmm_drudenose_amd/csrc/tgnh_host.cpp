@@ -555,6 +555,8 @@ extern "C" tgnh_status tgnh_set_global_dof_terms(tgnh_handle h, const double* te
     h->global_terms.assign(terms, terms + count);
     return finalize_thermostat(h);
 }
+static tgnh_status materialize_chain(tgnh_handle h, hipStream_t s);
+
 // ---------------------------------------------------------------------------
 // mailbox exchange (SURVEY 8e done with stores over xGMI; protocol in tgnh_internal.h)
 // ---------------------------------------------------------------------------
@@ -632,9 +634,16 @@ extern "C" tgnh_status tgnh_exchange_attach_pointers(tgnh_handle h, void* const*
 
 extern "C" tgnh_status tgnh_exchange_detach(tgnh_handle h) {
     CHECK_H(h);
-    tgnh_status rc = deferred_guard(h, "tgnh_exchange_detach"); if (rc) return rc;
-    if (h->chain_pending && h->xwait_pending) return fail(TGNH_ERR_STATE, "an exchange is in flight (query the state or step first)");
+    if (!h->xchg_on) return TGNH_OK;
+    HIP_OK(hipSetDevice(h->device));
+    HIP_OK(hipDeviceSynchronize());
+    if (h->chain_pending && h->xwait_pending) {       // an exchange is half done (sent, not yet waited for): finish it
+        tgnh_status rc = materialize_chain(h, (hipStream_t)0); if (rc) return rc;
+        HIP_OK(hipDeviceSynchronize());
+    }
     h->xchg_on = false;
+    for (void* p : h->x_opened) (void)hipIpcCloseMemHandle(p);      // the peers' mailboxes; mine stays until tgnh_destroy
+    h->x_opened.clear();
     return TGNH_OK;
 }
 

@@ -60,7 +60,8 @@ def main():
     publish(os.path.join(out, f"vel{rank}.npy"), ctx.getVelocities())
     publish(os.path.join(out, f"eta{rank}.npy"), np.concatenate([ctx.thermostat_state(0), ctx.thermostat_state(1)]))
     publish(os.path.join(out, f"flags{rank}.npy"), np.array([flags]))
-    # keep the mailbox mapped until every peer has finished reading / writing it
+    # unmap the peers' mailboxes; free the own one only when every peer has unmapped it
+    ctx.exchange_detach()
     publish(os.path.join(out, f"done{rank}.npy"), np.zeros(1))
     for r in range(world):
         wait_for(os.path.join(out, f"done{r}.npy"))
