@@ -25,6 +25,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Rehearsal knobs (not for measurements): TGNH_BENCH_BACKEND=gloo with TGNH_BENCH_DEVICE=0 runs several ranks of a
+# sharded bench on ONE GPU, to exercise the multi-process flow (sharding, mailbox attach, lockstep graph replays).
+BACKEND = os.environ.get("TGNH_BENCH_BACKEND", "nccl")
+CDEV = "cuda" if BACKEND == "nccl" else "cpu"          # where the small tensors of the setup collectives live
+
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s measured achievable)
 
 
@@ -76,7 +81,7 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
     kw = {}
     if world > 1 or os.environ.get("TGNH_FORCE_DIST") == "1":
         def dof_sum(terms):
-            t = torch.tensor(terms, dtype=torch.float64, device="cuda")
+            t = torch.tensor(terms, dtype=torch.float64, device=CDEV)
             dist.all_reduce(t)
             return t.cpu().numpy()
         kw = dict(allreduce=lambda t: dist.all_reduce(t), global_dof_sum=dof_sum)
@@ -99,7 +104,7 @@ def attach_mailbox(ctx, rank, world):
     except Exception as e:
         print(f"[bench] rank {rank}: mailbox exchange not available ({type(e).__name__}: {e})", file=sys.stderr)
         ok = 0
-    t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+    t = torch.tensor([ok], dtype=torch.int32, device=CDEV)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if int(t.item()) == 0:
         if ok:
@@ -124,7 +129,7 @@ def close_sharded(ctx):
 def all_ranks_agree(ok):
     import torch
     import torch.distributed as dist
-    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=CDEV)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return int(t.item()) == 1
 
@@ -147,7 +152,7 @@ def validate_mailbox(args, rank, world):
             return False
         ctx.step(60)
         torch.cuda.synchronize()
-        eta = torch.from_numpy(np.concatenate([ctx.thermostat_state(0), ctx.thermostat_state(1)])).cuda()
+        eta = torch.from_numpy(np.concatenate([ctx.thermostat_state(0), ctx.thermostat_state(1)])).to(CDEV)
         flags = ctx.check()
         if which == "mailbox":
             every = [torch.empty_like(eta) for _ in range(world)]
@@ -181,7 +186,7 @@ def timed_run(ctx, steps, warmup, world, graph_steps=0):
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             replay = None
         if world > 1:                                  # every rank replays, or none does: their exchanges must pair up
-            t = torch.tensor([1 if replay is not None else 0], dtype=torch.int32, device="cuda")
+            t = torch.tensor([1 if replay is not None else 0], dtype=torch.int32, device=CDEV)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)   # (also a barrier: captures take different times, mailbox waits are bounded)
             if int(t.item()) == 0:
                 replay = None
@@ -207,7 +212,7 @@ def timed_run(ctx, steps, warmup, world, graph_steps=0):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=CDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     dom = None
@@ -313,6 +318,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    local_rank = int(os.environ.get("TGNH_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
     # TGNH_FORCE_DIST=1 exercises the sharded code path (process group, dof all-reduce, KE all-reduce hook) on one rank
     use_dist = world > 1 or os.environ.get("TGNH_FORCE_DIST") == "1"
@@ -321,7 +327,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if BACKEND == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(BACKEND)
 
     from openmm_drudenose_amd import synth, _lib
     system, group, ngroups = synth.water_box(args.molecules)
