@@ -538,8 +538,10 @@ def test_particle_sharded_hip_path_on_one_gpu():
         c.close()
 
 
-@pytest.mark.parametrize("variant,chains,nranks", [(FLAG_DEFER_SCALE, 1, 2), (0, 1, 2), (FLAG_DEFER_SCALE, 3, 2), (0, 3, 2)])
-def test_particle_sharded_mailbox_exchange_on_one_gpu(variant, chains, nranks):
+@pytest.mark.parametrize("variant,chains,nranks,sysname", [
+    (FLAG_DEFER_SCALE, 1, 2, "mixed"), (0, 1, 2, "mixed"), (FLAG_DEFER_SCALE, 3, 2, "mixed"), (0, 3, 2, "mixed"),
+    (FLAG_DEFER_SCALE, 1, 2, "groups32")])          # 2 ranks x 34 thermostats = 68 cells: more than one wavefront's worth
+def test_particle_sharded_mailbox_exchange_on_one_gpu(variant, chains, nranks, sysname):
     """The mailbox exchange (tgnh_exchange_*: the KE all-reduce done by the integrator's own kernels with stores into
     every peer's mailbox) with the 'ranks' as handles on this one GPU, each on its own stream, mailboxes attached by
     pointer: every rank's rescale launch spins until all ranks' sum launches have delivered.  Trajectory = the
@@ -548,7 +550,7 @@ def test_particle_sharded_mailbox_exchange_on_one_gpu(variant, chains, nranks):
     share a few hardware queues, and a rank spinning in front of its peer's sum launch in the same queue could only
     time out; one process per GPU has no such coupling.)"""
     from openmm_drudenose_amd.system import shard_bounds
-    s, g, ng = synth.mixed(400, 30)
+    s, g, ng = synth.mixed(400, 30) if sysname == "mixed" else SYSTEMS[sysname]()
     it = integ(chains=chains, hardwall=0.02)
     bind_groups(it, g, ng)
     ref = HipContext(s, it, mode="TGNH", precision="double", flags=variant)
