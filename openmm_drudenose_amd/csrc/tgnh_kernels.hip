@@ -32,7 +32,14 @@ template <> struct Prec<TGNH_PREC_DOUBLE> { typedef double real; typedef double 
 __device__ __forceinline__ float4 mk4(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
 __device__ __forceinline__ double4 mk4(double x, double y, double z, double w) { return make_double4(x, y, z, w); }
 __device__ __forceinline__ float rcp_(float x) { return 1.0f / x; }
-__device__ __forceinline__ double rcp_(double x) { return 1.0 / x; }
+// fp64 reciprocal of a normal, non-zero number (masses and their sums): hardware seed + two Newton steps, 5
+// instructions and <= 1-2 ulp, where the IEEE division is 11 (it also scales denormals and fixes up specials).
+__device__ __forceinline__ double rcp_(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
 __device__ __forceinline__ float sqrt_(float x) { return sqrtf(x); }
 __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
 __device__ __forceinline__ float abs_(float x) { return fabsf(x); }
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     const double r1x = v[k].x - cx, r1y = v[k].y - cy, r1z = v[k].z - cz;
                     const double r2x = u.x - cx, r2y = u.y - cy, r2z = u.z - cz;
                     const double mass1 = mass[k], mass2 = u.w;               // image .w = mass
-                    const double invTot = 1.0 / (mass1 + mass2);
+                    const double invTot = rcp_(mass1 + mass2);
                     const double m1f = invTot * mass1, m2f = invTot * mass2;
                     const double cmx = r1x * m1f + r2x * m2f, cmy = r1y * m1f + r2y * m2f, cmz = r1z * m1f + r2z * m2f;
                     const double rlx = r2x - r1x, rly = r2y - r1y, rlz = r2z - r1z;
