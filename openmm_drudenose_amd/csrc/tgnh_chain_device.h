@@ -70,6 +70,38 @@ __device__ __forceinline__ double chain_exp(double x) {
     return p;
 }
 
+// exp(y) for the fast paths below: Taylor polynomials in Estrin form -- the serial chain there is bound by the
+// latency of dependent fp64 operations (~17 cycles each, measured), so depth counts: degree 7 at depth 3 for
+// |y| < 2^-6 (truncation y^8/8! < 2^-63), degree 12 at depth 4 for |y| < 2^-2 (y^13/13! < 2^-58).
+__device__ __forceinline__ double chain_exp7(const double y) {
+    const double y2 = y * y;
+    const double p0 = 1.0 + y;
+    const double p1 = fma(y, 1.0 / 6.0, 0.5);
+    const double p2 = fma(y, 1.0 / 120.0, 1.0 / 24.0);
+    const double p3 = fma(y, 1.0 / 5040.0, 1.0 / 720.0);
+    const double y4 = y2 * y2;
+    const double q0 = fma(p1, y2, p0);
+    const double q1 = fma(p3, y2, p2);
+    return fma(q1, y4, q0);
+}
+__device__ __forceinline__ double chain_exp12(const double y) {
+    const double y2 = y * y;
+    const double p0 = 1.0 + y;
+    const double p1 = fma(y, 1.0 / 6.0, 0.5);
+    const double p2 = fma(y, 1.0 / 120.0, 1.0 / 24.0);
+    const double p3 = fma(y, 1.0 / 5040.0, 1.0 / 720.0);
+    const double p4 = fma(y, 1.0 / 362880.0, 1.0 / 40320.0);
+    const double p5 = fma(y, 1.0 / 39916800.0, 1.0 / 3628800.0);
+    const double y4 = y2 * y2;
+    const double q0 = fma(p1, y2, p0);
+    const double q1 = fma(p3, y2, p2);
+    const double q2 = fma(p5, y2, p4);
+    const double y8 = y4 * y4;
+    const double r0 = fma(q1, y4, q0);
+    const double r1 = fma(y4, 1.0 / 479001600.0, q2);
+    return fma(r1, y8, r0);
+}
+
 struct ChainConst {
     double dtc2, dtc4, dtc8;
     int S;
@@ -107,6 +139,55 @@ __device__ __forceinline__ void chain_real_core(double* eta, double* etaDot, dou
     double invM[CMI];                                                // 1/Q of the higher links (CC == 0: divide)
 #pragma unroll
     for (int i = 0; i < CMI; i++) invM[i] = (CC > 0) ? 1.0 / etaMass[i] : 0.0;
+    if constexpr (CC >= 2) {
+        // Register-resident chains: the same arithmetic with the exponentials that repeat taken once.  Per sub-step
+        // the reference evaluates expfac = exp(-dtc8*etaDot[i+1]) in the descending loop (Cu :566-571) and AGAIN in
+        // the ascending loop (Cu :586-592), where etaDot[i+1] still holds the descending loop's value: same argument,
+        // same result, computed once here (C instead of 2C exponentials per sub-step, none for the top link, whose
+        // neighbour is the constant dummy).  exp() is the depth-3 polynomial without a range test; the largest
+        // argument seen is checked once after the loop and the call repeated with the careful code below if the
+        // polynomial's range was ever left (never in practice).
+        double s_eta[CC], s_ed[CC + 1], s_edd[CC];
+#pragma unroll
+        for (int i = 0; i < CC; i++) { s_eta[i] = eta[i]; s_ed[i] = etaDot[i]; s_edd[i] = etaDotDot[i]; }
+        s_ed[CC] = etaDot[CC];
+        const double ke_in = ke;
+        double ef[CC], xmax = 0.0;
+        ef[CC - 1] = chain_exp<LIBM>(-k.dtc8 * etaDot[CC]);          // the dummy link never moves: constant of the call
+        for (int iter = 0; iter < k.S; iter++) {
+#pragma unroll
+            for (int i = CC - 1; i >= 0; i--) {                      // Cu :566-571
+                if (i < CC - 1) { const double x = -k.dtc8 * etaDot[i + 1]; xmax = fmax(xmax, fabs(x)); ef[i] = chain_exp7(x); }
+                etaDot[i] *= ef[i];
+                etaDot[i] += etaDotDot[i] * k.dtc4;
+                etaDot[i] *= ef[i];
+            }
+            { const double x = -k.dtc2 * etaDot[0]; xmax = fmax(xmax, fabs(x)); const double e = chain_exp7(x); scale *= e; ke *= e * e; }   // Cu :573-574
+#pragma unroll
+            for (int i = 0; i < CC; i++) eta[i] += k.dtc2 * etaDot[i];    // Cu :575-577
+            if (live) etaDotDot[0] = (ke - nkbt) * invQ0;            // Cu :579-581
+            etaDot[0] *= ef[0];                                      // Cu :583-585
+            etaDot[0] += etaDotDot[0] * k.dtc4;
+            etaDot[0] *= ef[0];
+#pragma unroll
+            for (int i = 1; i < CC; i++) {                           // Cu :586-592, expfac as in the descending loop
+                etaDot[i] *= ef[i];
+                etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - kbT) * invM[i];
+                etaDot[i] += etaDotDot[i] * k.dtc4;
+                etaDot[i] *= ef[i];
+            }
+        }
+        if (__builtin_expect(!__any(xmax >= 0.015625), 1)) {
+            *scale_out = scale;
+            *ke_out = ke;
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < CC; i++) { eta[i] = s_eta[i]; etaDot[i] = s_ed[i]; etaDotDot[i] = s_edd[i]; }
+        etaDot[CC] = s_ed[CC];
+        ke = ke_in; scale = 1.0;
+        if (live) etaDotDot[0] = (ke - nkbt) * invQ0;
+    }
     for (int iter = 0; iter < k.S; iter++) {
 #pragma unroll
         for (int i = C - 1; i >= 0; i--) {                           // Cu :566-571
@@ -164,6 +245,50 @@ __device__ __forceinline__ void chain_drude_core(double* eta, double* etaDot, do
         *scale_out = scale;
         *ke_out = ke;
         return;
+    }
+    if constexpr (CC >= 2) {                                         // as in chain_real_core: repeated exponentials once
+        double s_eta[CC], s_ed[CC + 1], s_edd[CC];
+#pragma unroll
+        for (int i = 0; i < CC; i++) { s_eta[i] = eta[i]; s_ed[i] = etaDot[i]; s_edd[i] = etaDotDot[i]; }
+        s_ed[CC] = etaDot[CC];
+        const double ke_in = ke;
+        double invM[CC], ef[CC], xmax = 0.0;
+#pragma unroll
+        for (int i = 0; i < CC; i++) invM[i] = 1.0 / etaMass[i];
+        ef[CC - 1] = chain_exp<LIBM>(-k.dtc8 * etaDot[CC]);
+        for (int iter = 0; iter < k.S; iter++) {                     // Cu :606-642
+#pragma unroll
+            for (int i = CC - 1; i >= 0; i--) {                      // Cu :607-618
+                if (i < CC - 1) { const double x = -k.dtc8 * etaDot[i + 1]; xmax = fmax(xmax, fabs(x)); ef[i] = chain_exp7(x); }
+                etaDot[i] *= ef[i];
+                etaDot[i] += etaDotDot[i] * k.dtc4;
+                etaDot[i] *= ef[i];
+            }
+            { const double x = -k.dtc2 * etaDot[0]; xmax = fmax(xmax, fabs(x)); const double e = chain_exp7(x); scale *= e; ke *= e * e; }   // Cu :620-621
+#pragma unroll
+            for (int i = 0; i < CC; i++) eta[i] += k.dtc2 * etaDot[i];
+            etaDotDot[0] = (ke - nkbt) * invQ0;
+            etaDot[0] *= ef[0];
+            etaDot[0] += etaDotDot[0] * k.dtc4;
+            etaDot[0] *= ef[0];
+#pragma unroll
+            for (int i = 1; i < CC; i++) {                           // Cu :633-641
+                etaDot[i] *= ef[i];
+                etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - kbT) * invM[i];
+                etaDot[i] += etaDotDot[i] * k.dtc4;
+                etaDot[i] *= ef[i];
+            }
+        }
+        if (__builtin_expect(!__any(xmax >= 0.015625), 1)) {
+            *scale_out = scale;
+            *ke_out = ke;
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < CC; i++) { eta[i] = s_eta[i]; etaDot[i] = s_ed[i]; etaDotDot[i] = s_edd[i]; }
+        etaDot[CC] = s_ed[CC];
+        ke = ke_in; scale = 1.0;
+        etaDotDot[0] = (ke - nkbt) * invQ0;
     }
     for (int iter = 0; iter < k.S; iter++) {                         // Cu :606-642
 #pragma unroll
@@ -336,38 +461,6 @@ __device__ __forceinline__ Chain1Regs chain1_load(const ChainArgs& a, const doub
     r.nkbt = st_in[L.off_nkbt + itg];
     r.ke = st_in[L.off_ke_red + itg];
     return r;
-}
-
-// exp(y) for the one-link fast path: Taylor polynomials in Estrin form -- the serial chain there is bound by the
-// latency of dependent fp64 operations (~17 cycles each, measured), so depth counts: degree 7 at depth 3 for
-// |y| < 2^-6 (truncation y^8/8! < 2^-63), degree 12 at depth 4 for |y| < 2^-2 (y^13/13! < 2^-58).
-__device__ __forceinline__ double chain_exp7(const double y) {
-    const double y2 = y * y;
-    const double p0 = 1.0 + y;
-    const double p1 = fma(y, 1.0 / 6.0, 0.5);
-    const double p2 = fma(y, 1.0 / 120.0, 1.0 / 24.0);
-    const double p3 = fma(y, 1.0 / 5040.0, 1.0 / 720.0);
-    const double y4 = y2 * y2;
-    const double q0 = fma(p1, y2, p0);
-    const double q1 = fma(p3, y2, p2);
-    return fma(q1, y4, q0);
-}
-__device__ __forceinline__ double chain_exp12(const double y) {
-    const double y2 = y * y;
-    const double p0 = 1.0 + y;
-    const double p1 = fma(y, 1.0 / 6.0, 0.5);
-    const double p2 = fma(y, 1.0 / 120.0, 1.0 / 24.0);
-    const double p3 = fma(y, 1.0 / 5040.0, 1.0 / 720.0);
-    const double p4 = fma(y, 1.0 / 362880.0, 1.0 / 40320.0);
-    const double p5 = fma(y, 1.0 / 39916800.0, 1.0 / 3628800.0);
-    const double y4 = y2 * y2;
-    const double q0 = fma(p1, y2, p0);
-    const double q1 = fma(p3, y2, p2);
-    const double q2 = fma(p5, y2, p4);
-    const double y8 = y4 * y4;
-    const double r0 = fma(q1, y4, q0);
-    const double r1 = fma(y4, 1.0 / 479001600.0, q2);
-    return fma(r1, y8, r0);
 }
 
 // All NT thermostats in the lanes of ONE wavefront, one instruction stream: with one link the real thermostats
