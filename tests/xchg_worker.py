@@ -39,7 +39,8 @@ def publish(path, arr):
 
 def main():
     rank, world, out, nsteps, variant = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
-    s, g, ng = synth.mixed(400, 30)
+    n_water, n_pairs = int(os.environ.get("TGNH_XW_WATERS", "400")), int(os.environ.get("TGNH_XW_PAIRS", "30"))   # soak runs: bigger boxes
+    s, g, ng = synth.mixed(n_water, n_pairs)
     b = shard_bounds(s, world)
     loc, lg = s.slice_molecules(b[rank], b[rank + 1]), g[b[rank]:b[rank + 1]]
     ctx = HipContext(loc, make_integrator(lg, ng), mode="TGNH", precision="double", flags=variant)
