@@ -129,6 +129,13 @@ def test_host_only_handle_cannot_launch():
     assert t.lib.tgnh_step_begin(t.h, None) == _lib.ERR_STATE
     assert b"host-only" in t.lib.tgnh_last_error()
     assert t.lib.tgnh_bind_buffers(t.h, None, None, None, None, None) == _lib.ERR_STATE
+    # the mailbox exchange needs device memory too, and its calls check their arguments before touching anything
+    import ctypes as C
+    buf, ptr = C.create_string_buffer(64), C.c_void_p()
+    assert t.lib.tgnh_exchange_create(t.h, 2, 0, buf, C.byref(ptr)) == _lib.ERR_STATE
+    assert t.lib.tgnh_exchange_attach(t.h, buf.raw * 2) == _lib.ERR_STATE          # no mailbox created
+    assert t.lib.tgnh_exchange_attach_pointers(t.h, (C.c_void_p * 2)()) == _lib.ERR_STATE
+    assert t.lib.tgnh_exchange_detach(t.h) == 0                                     # nothing attached: a no-op
 
 
 def test_deferred_rescale_needs_single_group_molecules():
