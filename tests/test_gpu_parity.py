@@ -540,6 +540,7 @@ def test_particle_sharded_hip_path_on_one_gpu():
 
 @pytest.mark.parametrize("variant,chains,nranks,sysname", [
     (FLAG_DEFER_SCALE, 1, 2, "mixed"), (0, 1, 2, "mixed"), (FLAG_DEFER_SCALE, 3, 2, "mixed"), (0, 3, 2, "mixed"),
+    (FLAG_MERGE_SCALE_KE, 1, 2, "mixed"),
     (FLAG_DEFER_SCALE, 1, 2, "groups32")])          # 2 ranks x 34 thermostats = 68 cells: more than one wavefront's worth
 def test_particle_sharded_mailbox_exchange_on_one_gpu(variant, chains, nranks, sysname):
     """The mailbox exchange (tgnh_exchange_*: the KE all-reduce done by the integrator's own kernels with stores into
