@@ -91,24 +91,13 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
 
 
 def attach_mailbox(ctx, rank, world):
-    """Every rank's mailbox mapped into every other rank (IPC handles through the process group).  All ranks end up
-    with the same answer: True = mailbox exchange attached everywhere, False = nobody uses it."""
-    import torch
+    """Every rank's mailbox mapped into every other rank (HipContext.attach_exchange_over: IPC handles through the
+    process group).  All ranks end up with the same answer: True = attached everywhere, False = nobody uses it."""
     import torch.distributed as dist
-    ok = 1
-    try:
-        handle, _ = ctx.exchange_create(world, rank)
-        handles = [None] * world
-        dist.all_gather_object(handles, handle)
-        ctx.exchange_attach(handles)
-    except Exception as e:
-        print(f"[bench] rank {rank}: mailbox exchange not available ({type(e).__name__}: {e})", file=sys.stderr)
-        ok = 0
-    t = torch.tensor([ok], dtype=torch.int32, device=CDEV)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    if int(t.item()) == 0:
-        if ok:
-            ctx.exchange_detach()
+    if not ctx.attach_exchange_over(dist, rank, world, tensor_device=CDEV):
+        e = getattr(ctx, "exchange_error", None)
+        if e is not None:
+            print(f"[bench] rank {rank}: mailbox exchange not available ({type(e).__name__}: {e})", file=sys.stderr)
         return False
     ctx.exchange = "mailbox"
     return True

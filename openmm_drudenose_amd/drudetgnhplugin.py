@@ -379,6 +379,29 @@ class HipContext(_HandleQueries):
     def exchange_detach(self):
         _check(self.lib.tgnh_exchange_detach(self.h))
 
+    def attach_exchange_over(self, dist, rank, world, tensor_device="cuda"):
+        """Collective over a torch.distributed process group: every rank creates its mailbox, the hipIpc handles go
+        round with all_gather_object, every rank maps its peers.  All ranks return the same answer: True = the
+        mailbox exchange is attached everywhere; False = nowhere (a rank could not create / map: the all-reduce hook,
+        if set, keeps doing the exchange)."""
+        torch = self.torch
+        ok, err = 1, None
+        try:
+            handle, _ = self.exchange_create(world, rank)
+            handles = [None] * world
+            dist.all_gather_object(handles, handle)
+            self.exchange_attach(handles)
+        except Exception as e:                      # noqa: BLE001 -- any failure means "not here", decided collectively below
+            ok, err = 0, e
+        t = torch.tensor([ok], dtype=torch.int32, device=tensor_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 0:
+            if ok:
+                self.exchange_detach()
+            self.exchange_error = err
+            return False
+        return True
+
     def _ke_view(self, ptr, count):
         key = (ptr, count)
         v = self._views.get(key)
