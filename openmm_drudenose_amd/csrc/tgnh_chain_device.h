@@ -381,6 +381,25 @@ __device__ __forceinline__ void run_tgnh(const ChainArgs& a, const double* st_in
 // waits on its scale factors), the arithmetic runs while the tile loads are in flight.  Same arithmetic as
 // run_tgnh<1, false>.
 struct Chain1Regs { double eta, etaDot0, etaDot1, etaDotDot, etaMass, nkbt, ke; };
+// Where thermostat-lane itg (index into the NT-long KE / scale vectors) keeps its one-link chain in the block.
+//   TGNH:   [thermostat][link] rows, etaDot rows of 2 (link 0, dummy).
+//   dualNH with useDrudeNHChains (the self-consistent layout, Ref :186-217): the interleaved vectors
+//           [real0, drude0 | dummy, dummy]; lanes 0 (real) and 2 (Drude) of the internal [real, unused, Drude] order.
+//           Link i couples to link i+2 there (Ref :477, :495), i.e. to its dummy: two independent one-link chains --
+//           the arithmetic of the TGNH ones (SURVEY A9's bridge identity), so they take the same code.
+struct Chain1Map { int eta, ed0, ed1, edd, mass; bool used, guard; };
+__device__ __forceinline__ Chain1Map chain1_map(const ChainLayout& L, const int itg) {
+    Chain1Map m;
+    if (L.mode == TGNH_MODE_TGNH) {
+        m.eta = itg; m.ed0 = 2 * itg; m.ed1 = 2 * itg + 1; m.edd = itg; m.mass = itg;
+        m.used = true; m.guard = itg != L.NT - 1;                     // etaMass > 0 guard: real thermostats only (Cu :561 vs :605)
+    } else {
+        const int t = itg >> 1;
+        m.eta = t; m.ed0 = t; m.ed1 = 2 + t; m.edd = t; m.mass = t;
+        m.used = itg != 1; m.guard = false;                           // Ref :471-472 divides unconditionally
+    }
+    return m;
+}
 
 // ---- mailbox exchange (protocol: XchgArgs in tgnh_internal.h) ----
 __device__ __forceinline__ size_t xchg_cell(const XchgArgs& x, const unsigned par, const int src, const int i) {
@@ -452,14 +471,16 @@ __device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT,
 
 __device__ __forceinline__ Chain1Regs chain1_load(const ChainArgs& a, const double* st_in, const int itg) {
     const ChainLayout& L = a.L;
-    Chain1Regs r;
-    r.eta = st_in[L.off_eta + itg];
-    r.etaDot0 = st_in[L.off_etaDot + itg * 2];
-    r.etaDot1 = st_in[L.off_etaDot + itg * 2 + 1];
-    r.etaDotDot = st_in[L.off_etaDotDot + itg];
-    r.etaMass = st_in[L.off_etaMass + itg];
-    r.nkbt = st_in[L.off_nkbt + itg];
+    const Chain1Map m = chain1_map(L, itg);
+    Chain1Regs r{};
     r.ke = st_in[L.off_ke_red + itg];
+    if (!m.used) { r.etaMass = 1.0; return r; }
+    r.eta = st_in[L.off_eta + m.eta];
+    r.etaDot0 = st_in[L.off_etaDot + m.ed0];
+    r.etaDot1 = st_in[L.off_etaDot + m.ed1];
+    r.etaDotDot = st_in[L.off_etaDotDot + m.edd];
+    r.etaMass = st_in[L.off_etaMass + m.mass];
+    r.nkbt = st_in[L.off_nkbt + itg];
     return r;
 }
 
@@ -481,12 +502,20 @@ __device__ __forceinline__ Chain1Regs chain1_load(const ChainArgs& a, const doub
 __device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs& r, double* st_out, const bool write,
                                            double* s_scale, const int itg) {
     const ChainLayout& L = a.L;
-    const bool drude = itg == L.NT - 1;
+    const Chain1Map m = chain1_map(L, itg);
     const double dtc = a.dt / a.S;                                   // Cu :440-443
     const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
     double ke = r.ke;
     if (write) st_out[L.off_ke + itg] = ke;                          // KE before the chain (Cu :490)
-    const bool live = drude || r.etaMass > 0;
+    if (!m.used) {                                                   // dualNH's middle slot: no thermostat, factor 1
+        if (s_scale) s_scale[itg] = 1.0;
+        if (write) {
+            st_out[L.off_scale_a + itg] = 1.0; st_out[L.off_scale_b + itg] = 1.0; st_out[L.off_scale + itg] = 1.0;
+            st_out[L.off_ke_post + itg] = 0.0;
+        }
+        return;
+    }
+    const bool live = !m.guard || r.etaMass > 0;
     const double invQ0 = live ? 1.0 / r.etaMass : 0.0;
     const double expfac = chain_exp<false>(-dtc8 * r.etaDot1);       // Cu :615 ; real: exp(-0) = 1
     const bool all_unit = !__any(expfac != 1.0);
@@ -547,10 +576,10 @@ __device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs&
     if (!write) return;
     if (reps == 1) st_out[L.off_scale_b + itg] = 1.0;
     st_out[L.off_scale + itg] = total;
-    st_out[L.off_eta + itg] = et;
-    st_out[L.off_etaDotDot + itg] = edd;
-    st_out[L.off_etaDot + itg * 2] = ed;
-    st_out[L.off_etaDot + itg * 2 + 1] = r.etaDot1;
+    st_out[L.off_eta + m.eta] = et;
+    st_out[L.off_etaDotDot + m.edd] = edd;
+    st_out[L.off_etaDot + m.ed0] = ed;
+    st_out[L.off_etaDot + m.ed1] = r.etaDot1;
 }
 
 // The Reference platform's coupled real/Drude chain on its interleaved vectors.  Ref :467-504.

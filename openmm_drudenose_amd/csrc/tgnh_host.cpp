@@ -475,7 +475,8 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         const bool want = e ? e[0] != '0' : true;
         const char* e3 = getenv("TGNH_ALTERNATE_SWEEPS");
         c->alternate_sweeps = !(e3 && e3[0] == '0');
-        c->inline_chain = c->L.C == 1 && c->L.mode == TGNH_MODE_TGNH && want;
+        // dualNH qualifies with useDrudeNHChains: its real and Drude chains are then independent (Chain1Map)
+        c->inline_chain = c->L.C == 1 && want && (c->L.mode == TGNH_MODE_TGNH || c->L.numTempGroup == 2);
     }
     auto alloc = [&]() -> tgnh_status {
         if (host_only) return TGNH_OK;

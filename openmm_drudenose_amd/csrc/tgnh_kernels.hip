@@ -258,7 +258,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                 if (itg < NT) chain1_run(a.chain, creg, a.st_out, write, s_scale, itg);
                 TRACE(14);
                 if (have_tile) load_tile(blockIdx.x, cur);
-            }   // (dualNH keeps the separate chain launch: its coupled vectors would cost this kernel ~50 VGPRs)
+            }   // (dualNH without useDrudeNHChains keeps the separate chain launch: its coupled vectors would cost this kernel ~50 VGPRs)
         } else if (tid < NT) {
             s_scale[tid] = a.scale[tid];
         }
@@ -723,6 +723,10 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
             for (int i = 0; i < NT; i++) s += s_ke[i];
             st[L.off_kesum] = 0.5 * s;
         }
+    } else if (L.C == 1 && L.numTempGroup == 2) {
+        // one link, self-consistent layout: two independent one-link chains, the code of the TGNH ones (Chain1Map)
+        if (tid < 3) { Chain1Regs r = chain1_load(a, a.st, tid); r.ke = s_ke[tid]; chain1_run(a, r, a.st, true, nullptr, tid); }
+        if (tid == 64) st[L.off_kesum] = 0.5 * (s_ke[0] + s_ke[2]);                  // Ref :586-588 (cached KE)
     } else if (tid == 0) {
         switch (L.C) {
             case 1: run_dualnh<1>(a, a.st, a.st, true, nullptr, s_chain, s_ke[0], s_ke[1], s_ke[2]); break;

@@ -168,6 +168,8 @@ CASES = [
     ("polymer", "TGNH", 1, True, True, 0.0),              # molecule longer than a tile: COM from big_com_kernel
     ("polymer", "TGNH", 3, True, True, 0.0),
     ("polymer", "dualNH", 1, True, True, 0.0),
+    ("water27", "dualNH", 1, True, True, 0.02),           # dualNH one-link chains: the in-kernel chain's code path
+    ("mixed", "dualNH", 1, True, True, 0.0),
 ]
 
 
@@ -370,13 +372,14 @@ def test_100_step_parity_deferred_rescale(mode, precision):
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["TGNH", "dualNH"])
 @pytest.mark.parametrize("chains", [1, 3])          # 1: the chain runs inside the rescale launch (staged block + commit)
 @pytest.mark.parametrize("flags", [0, FLAG_DEFER_SCALE])
-def test_graph_replay_matches_eager(flags, chains):
+def test_graph_replay_matches_eager(flags, chains, mode):
     """hipGraph capture of the step loop (HipContext.capture_steps) replays the very same launches: bitwise equal.
     Five steps per graph on purpose: nothing in the captured launch arguments may alternate between replays."""
-    ref = make("mixed", "TGNH", "mixed", flags=flags, hardwall=0.02, chains=chains)
-    alt = make("mixed", "TGNH", "mixed", flags=flags, hardwall=0.02, chains=chains)
+    ref = make("mixed", mode, "mixed", flags=flags, hardwall=0.02, chains=chains)
+    alt = make("mixed", mode, "mixed", flags=flags, hardwall=0.02, chains=chains)
     ref[4].step(3 + 4 * 5)
     alt[4].step(3)
     replay = alt[4].capture_steps(5)
