@@ -325,7 +325,7 @@ def main():
     system, group, ngroups = synth.water_box(args.molecules)
 
     use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
-    want_mailbox = use_dist and args.exchange != "rccl" and args.mode == "TGNH"
+    want_mailbox = use_dist and args.exchange != "rccl"
     if want_mailbox and args.exchange == "auto":
         want_mailbox = validate_mailbox(args, rank, world)
         if rank == 0:

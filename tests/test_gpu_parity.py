@@ -541,11 +541,12 @@ def test_particle_sharded_hip_path_on_one_gpu():
         c.close()
 
 
-@pytest.mark.parametrize("variant,chains,nranks,sysname", [
-    (FLAG_DEFER_SCALE, 1, 2, "mixed"), (0, 1, 2, "mixed"), (FLAG_DEFER_SCALE, 3, 2, "mixed"), (0, 3, 2, "mixed"),
-    (FLAG_MERGE_SCALE_KE, 1, 2, "mixed"),
-    (FLAG_DEFER_SCALE, 1, 2, "groups32")])          # 2 ranks x 34 thermostats = 68 cells: more than one wavefront's worth
-def test_particle_sharded_mailbox_exchange_on_one_gpu(variant, chains, nranks, sysname):
+@pytest.mark.parametrize("variant,chains,nranks,sysname,mode", [
+    (FLAG_DEFER_SCALE, 1, 2, "mixed", "TGNH"), (0, 1, 2, "mixed", "TGNH"), (FLAG_DEFER_SCALE, 3, 2, "mixed", "TGNH"),
+    (0, 3, 2, "mixed", "TGNH"), (FLAG_MERGE_SCALE_KE, 1, 2, "mixed", "TGNH"),
+    (FLAG_DEFER_SCALE, 1, 2, "groups32", "TGNH"),   # 2 ranks x 34 thermostats = 68 cells: more than one wavefront's worth
+    (FLAG_DEFER_SCALE, 1, 2, "mixed", "dualNH"), (0, 3, 2, "mixed", "dualNH")])
+def test_particle_sharded_mailbox_exchange_on_one_gpu(variant, chains, nranks, sysname, mode):
     """The mailbox exchange (tgnh_exchange_*: the KE all-reduce done by the integrator's own kernels with stores into
     every peer's mailbox) with the 'ranks' as handles on this one GPU, each on its own stream, mailboxes attached by
     pointer: every rank's rescale launch spins until all ranks' sum launches have delivered.  Trajectory = the
@@ -555,17 +556,21 @@ def test_particle_sharded_mailbox_exchange_on_one_gpu(variant, chains, nranks, s
     time out; one process per GPU has no such coupling.)"""
     from openmm_drudenose_amd.system import shard_bounds
     s, g, ng = synth.mixed(400, 30) if sysname == "mixed" else SYSTEMS[sysname]()
+    if mode == "dualNH":
+        g, ng = np.zeros_like(g), 1
     it = integ(chains=chains, hardwall=0.02)
-    bind_groups(it, g, ng)
-    ref = HipContext(s, it, mode="TGNH", precision="double", flags=variant)
+    if mode == "TGNH":
+        bind_groups(it, g, ng)
+    ref = HipContext(s, it, mode=mode, precision="double", flags=variant)
     torch = ref.torch
     b = shard_bounds(s, nranks)
     parts, terms, streams = [], [], []
     for r in range(nranks):
         loc, lg = s.slice_molecules(b[r], b[r + 1]), g[b[r]:b[r + 1]]
         itr = integ(chains=chains, hardwall=0.02)
-        bind_groups(itr, lg, ng)
-        parts.append(HipContext(loc, itr, mode="TGNH", precision="double", flags=variant))
+        if mode == "TGNH":
+            bind_groups(itr, lg, ng)
+        parts.append(HipContext(loc, itr, mode=mode, precision="double", flags=variant))
         terms.append(parts[-1].local_dof_terms())
         streams.append(torch.cuda.Stream(priority=-r))       # normal / high priority: two different hardware queues
     total = sum(terms)
