@@ -389,15 +389,12 @@ struct Chain1Regs { double eta, etaDot0, etaDot1, etaDotDot, etaMass, nkbt, ke; 
 //           the arithmetic of the TGNH ones (SURVEY A9's bridge identity), so they take the same code.
 struct Chain1Map { int eta, ed0, ed1, edd, mass; bool used, guard; };
 __device__ __forceinline__ Chain1Map chain1_map(const ChainLayout& L, const int itg) {
-    Chain1Map m;
-    if (L.mode == TGNH_MODE_TGNH) {
-        m.eta = itg; m.ed0 = 2 * itg; m.ed1 = 2 * itg + 1; m.edd = itg; m.mass = itg;
-        m.used = true; m.guard = itg != L.NT - 1;                     // etaMass > 0 guard: real thermostats only (Cu :561 vs :605)
-    } else {
-        const int t = itg >> 1;
-        m.eta = t; m.ed0 = t; m.ed1 = 2 + t; m.edd = t; m.mass = t;
-        m.used = itg != 1; m.guard = false;                           // Ref :471-472 divides unconditionally
-    }
+    Chain1Map m;                                                  // branch-free: the coefficients are the layout's
+    const int t = itg >> L.c1_shift;
+    m.eta = t; m.edd = t; m.mass = t;
+    m.ed0 = t * L.c1_mul; m.ed1 = m.ed0 + L.c1_add;
+    m.used = itg != L.c1_unused;
+    m.guard = itg < L.c1_guard_below;                             // etaMass > 0 guard: TGNH's real thermostats (Cu :561 vs :605, Ref :471)
     return m;
 }
 

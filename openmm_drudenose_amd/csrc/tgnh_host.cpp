@@ -341,11 +341,13 @@ static void make_layout(tgnh_context* c) {
         else { L.numTempGroup = 1; L.idxMaxNHChains = C; L.iNumNHChains = C + 1; }
         const int n = L.use_drude_chains ? 2 * C : C + 1;
         L.len_eta = n; L.len_etaDotDot = n; L.len_etaMass = n; L.len_etaDot = n + 2;          // Ref :216-217
+        L.c1_shift = 1; L.c1_mul = 1; L.c1_add = 2; L.c1_unused = 1; L.c1_guard_below = 0;
     } else {
         L.G = d.num_groups; L.NT = L.G + 2;
         L.len_eta = L.NT * L.C; L.len_etaDotDot = L.NT * L.C; L.len_etaMass = L.NT * L.C;     // Cu :94-97
         L.len_etaDot = L.NT * (L.C + 1);
         L.numTempGroup = L.idxMaxNHChains = L.iNumNHChains = 0;
+        L.c1_shift = 0; L.c1_mul = 2; L.c1_add = 1; L.c1_unused = -1; L.c1_guard_below = L.NT - 1;
     }
     int o = 0;
     L.off_eta = o; o += L.len_eta;

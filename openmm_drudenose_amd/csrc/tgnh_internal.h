@@ -74,6 +74,10 @@ struct ChainLayout {
     int total;
     // dualNH bookkeeping (Ref :139-154)
     int numTempGroup, idxMaxNHChains, iNumNHChains;
+    // one-link chains (Chain1Map): thermostat lane itg keeps link 0 at (itg >> c1_shift) * c1_mul of etaDot, its dummy
+    // c1_add further on, eta / etaDotDot / etaMass at itg >> c1_shift; lane c1_unused carries no thermostat; lanes
+    // below c1_guard_below have the etaMass > 0 guard.  TGNH: 0, 2, 1, -1, NT-1.  dualNH (useDrudeNHChains): 1, 1, 2, 1, 0.
+    int c1_shift, c1_mul, c1_add, c1_unused, c1_guard_below;
 };
 
 // Mailbox exchange of the per-thermostat kinetic-energy sums between the ranks of a sharded run (one GPU each),
