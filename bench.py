@@ -369,6 +369,15 @@ def main():
             extra[f"{prec}/{var}"] = {"steps_per_s": round(args.steps / d2, 2), "ms_per_step": round(d2 / args.steps * 1e3, 4),
                                      "kernels": r2}
             c2.close()
+        if args.mode == "TGNH":                  # the other semantic mode (platforms/reference's algorithm), same workload
+            import copy
+            a2 = copy.copy(args)
+            a2.mode = "dualNH"
+            c2 = build_context(a2, system, group, ngroups, rank, world, args.precision, args.variant)
+            d2 = timed_run(c2, args.steps, args.warmup, world)
+            extra[f"dualNH/{args.precision}/{args.variant}"] = {"steps_per_s": round(args.steps / d2, 2),
+                                                                 "ms_per_step": round(d2 / args.steps * 1e3, 4), "kernels": kernel_table(c2)}
+            c2.close()
 
     out = None
     if rank == 0:
