@@ -579,6 +579,72 @@ __device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs&
     st_out[L.off_etaDot + m.ed1] = r.etaDot1;
 }
 
+// dualNH, one link, useDrudeNHChains = false (the C++ default).  Ref :139-154 then leaves numTempGroup = 1, so the
+// descending loop (Ref :476-481) damps link i with etaDot[i+1]: the Drude thermostat (vector index 1) with the first
+// dummy, the REAL thermostat (index 0) with the Drude thermostat's etaDot -- the value just updated in the same
+// sub-step -- while the ascending loop (Ref :494-503, stride 2 hard-coded) damps both with their dummies.  Same
+// storage as the self-consistent layout (Chain1Map); lanes 0 (real) and 2 (Drude) of one wavefront, one shuffle per
+// sub-step carries the coupling; lane 1 is the unused middle slot.  The arithmetic is run_dualnh<1>'s.
+__device__ __forceinline__ void chain1q_run(const ChainArgs& a, const Chain1Regs& r, double* st_out, const bool write,
+                                            double* s_scale, const int itg) {
+    const ChainLayout& L = a.L;
+    const Chain1Map m = chain1_map(L, itg);
+    const bool drude = itg == 2;
+    const double dtc = a.dt / a.S;                                   // Ref :432-435
+    const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
+    double ke = r.ke;
+    if (write) st_out[L.off_ke + itg] = ke;
+    if (!m.used) {
+        if (s_scale) s_scale[itg] = 1.0;
+        if (write) {
+            st_out[L.off_scale_a + itg] = 1.0; st_out[L.off_scale_b + itg] = 1.0; st_out[L.off_scale + itg] = 1.0;
+            st_out[L.off_ke_post + itg] = 0.0;
+        }
+        return;
+    }
+    const double invQ = 1.0 / r.etaMass;                             // Ref :471-472 divides unconditionally
+    const double dummy2 = __shfl(r.etaDot1, 0, 64);                  // etaDot[2]: the real lane's "link 1"
+    const double efD1 = chain_exp<false>(-dtc8 * dummy2);            // Drude, descending loop: exp(-dtc8 etaDot[1+1])
+    const double ef2 = chain_exp<false>(-dtc8 * r.etaDot1);          // ascending loop: exp(-dtc8 etaDot[i+2]), i = 0 / 1
+    double ed = r.etaDot0, edd = r.etaDotDot, et = r.eta;
+    const int reps = a.chain_twice ? 2 : 1;
+    double total = 1.0;
+    for (int rep = 0; rep < reps; rep++) {
+        double scale = 1.0;
+        edd = (ke - r.nkbt) * invQ;                                  // Ref :471-472
+        for (int iter = 0; iter < a.S; iter++) {
+            double t1 = ed * efD1;                                   // Ref :476-481, i = 1 (Drude) first ...
+            t1 = fma(edd, dtc4, t1);
+            t1 *= efD1;
+            const double efr = chain_exp<false>(-dtc8 * __shfl(t1, 2, 64));   // ... then i = 0 with the Drude etaDot just formed
+            double t0 = ed * efr;
+            t0 = fma(edd, dtc4, t0);
+            t0 *= efr;
+            ed = drude ? t1 : t0;
+            const double e = chain_exp<false>(-dtc2 * ed);           // Ref :483-486
+            scale *= e; ke *= e * e;
+            et = fma(dtc2, ed, et);                                  // Ref :487-489
+            edd = (ke - r.nkbt) * invQ;                              // Ref :491-492
+            ed *= ef2;                                               // Ref :494-503
+            ed = fma(edd, dtc4, ed);
+            ed *= ef2;
+        }
+        if (write) {
+            if (rep == 0) { st_out[L.off_scale_a + itg] = scale; st_out[L.off_ke_post + itg] = ke; }
+            else st_out[L.off_scale_b + itg] = scale;
+        }
+        total *= scale;
+    }
+    if (s_scale) s_scale[itg] = total;
+    if (!write) return;
+    if (reps == 1) st_out[L.off_scale_b + itg] = 1.0;
+    st_out[L.off_scale + itg] = total;
+    st_out[L.off_eta + m.eta] = et;
+    st_out[L.off_etaDotDot + m.edd] = edd;
+    st_out[L.off_etaDot + m.ed0] = ed;
+    st_out[L.off_etaDot + m.ed1] = r.etaDot1;
+}
+
 // The Reference platform's coupled real/Drude chain on its interleaved vectors.  Ref :467-504.
 // LEN = compile-time bound of the vectors (2*CC+2), 0 = dynamic (LDS).
 template <int CC>

@@ -342,12 +342,14 @@ static void make_layout(tgnh_context* c) {
         const int n = L.use_drude_chains ? 2 * C : C + 1;
         L.len_eta = n; L.len_etaDotDot = n; L.len_etaMass = n; L.len_etaDot = n + 2;          // Ref :216-217
         L.c1_shift = 1; L.c1_mul = 1; L.c1_add = 2; L.c1_unused = 1; L.c1_guard_below = 0;
+        L.c1_quirk = L.use_drude_chains ? 0 : 1;
     } else {
         L.G = d.num_groups; L.NT = L.G + 2;
         L.len_eta = L.NT * L.C; L.len_etaDotDot = L.NT * L.C; L.len_etaMass = L.NT * L.C;     // Cu :94-97
         L.len_etaDot = L.NT * (L.C + 1);
         L.numTempGroup = L.idxMaxNHChains = L.iNumNHChains = 0;
         L.c1_shift = 0; L.c1_mul = 2; L.c1_add = 1; L.c1_unused = -1; L.c1_guard_below = L.NT - 1;
+        L.c1_quirk = 0;
     }
     int o = 0;
     L.off_eta = o; o += L.len_eta;
@@ -477,8 +479,9 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         const bool want = e ? e[0] != '0' : true;
         const char* e3 = getenv("TGNH_ALTERNATE_SWEEPS");
         c->alternate_sweeps = !(e3 && e3[0] == '0');
-        // dualNH qualifies with useDrudeNHChains: its real and Drude chains are then independent (Chain1Map)
-        c->inline_chain = c->L.C == 1 && want && (c->L.mode == TGNH_MODE_TGNH || c->L.numTempGroup == 2);
+        // dualNH qualifies too: with useDrudeNHChains its real and Drude chains are independent (Chain1Map), without
+        // them coupled through one shuffle per sub-step (chain1q_run)
+        c->inline_chain = c->L.C == 1 && want;
     }
     auto alloc = [&]() -> tgnh_status {
         if (host_only) return TGNH_OK;

@@ -78,6 +78,7 @@ struct ChainLayout {
     // c1_add further on, eta / etaDotDot / etaMass at itg >> c1_shift; lane c1_unused carries no thermostat; lanes
     // below c1_guard_below have the etaMass > 0 guard.  TGNH: 0, 2, 1, -1, NT-1.  dualNH (useDrudeNHChains): 1, 1, 2, 1, 0.
     int c1_shift, c1_mul, c1_add, c1_unused, c1_guard_below;
+    int c1_quirk;      // dualNH without useDrudeNHChains: the real chain is damped by the Drude thermostat (chain1q_run)
 };
 
 // Mailbox exchange of the per-thermostat kinetic-energy sums between the ranks of a sharded run (one GPU each),

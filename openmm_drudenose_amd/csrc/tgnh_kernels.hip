@@ -255,10 +255,13 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     for (int i = 0; i < NT; i++) s += a.x_wait ? s_scale[i] : a.st_in[L.off_ke_red + i];
                     a.st_out[L.off_kesum] = 0.5 * s;
                 }
-                if (itg < NT) chain1_run(a.chain, creg, a.st_out, write, s_scale, itg);
+                if (itg < NT) {
+                    if (L.c1_quirk) chain1q_run(a.chain, creg, a.st_out, write, s_scale, itg);
+                    else chain1_run(a.chain, creg, a.st_out, write, s_scale, itg);
+                }
                 TRACE(14);
                 if (have_tile) load_tile(blockIdx.x, cur);
-            }   // (dualNH without useDrudeNHChains keeps the separate chain launch: its coupled vectors would cost this kernel ~50 VGPRs)
+            }
         } else if (tid < NT) {
             s_scale[tid] = a.scale[tid];
         }
@@ -723,9 +726,14 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
             for (int i = 0; i < NT; i++) s += s_ke[i];
             st[L.off_kesum] = 0.5 * s;
         }
-    } else if (L.C == 1 && L.numTempGroup == 2) {
-        // one link, self-consistent layout: two independent one-link chains, the code of the TGNH ones (Chain1Map)
-        if (tid < 3) { Chain1Regs r = chain1_load(a, a.st, tid); r.ke = s_ke[tid]; chain1_run(a, r, a.st, true, nullptr, tid); }
+    } else if (L.C == 1) {
+        // one link: with useDrudeNHChains two independent one-link chains, the code of the TGNH ones (Chain1Map);
+        // without, the same two lanes coupled by one shuffle per sub-step (chain1q_run)
+        if (tid < 3) {
+            Chain1Regs r = chain1_load(a, a.st, tid); r.ke = s_ke[tid];
+            if (L.c1_quirk) chain1q_run(a, r, a.st, true, nullptr, tid);
+            else chain1_run(a, r, a.st, true, nullptr, tid);
+        }
         if (tid == 64) st[L.off_kesum] = 0.5 * (s_ke[0] + s_ke[2]);                  // Ref :586-588 (cached KE)
     } else if (tid == 0) {
         switch (L.C) {

@@ -357,6 +357,24 @@ def test_extended_energy_is_conserved(mode, flags, chains, sysname):
     assert 2.5 < worst[0] / worst[1] < 7.0
 
 
+@pytest.mark.parametrize("flags", [FLAG_MERGE_SCALE_KE, FLAG_DEFER_SCALE])
+def test_one_link_dualnh_without_drude_chains_all_variants(flags):
+    """The C++ default (useDrudeNHChains = false) with one link: the real chain is damped by the Drude thermostat's
+    etaDot (Ref :476-481 with numTempGroup = 1).  That coupling runs inside the rescale launch (chain1q_run, one
+    shuffle per sub-step); the pass-structure variants and a hipGraph replay must agree with the plain, eager run,
+    which test_100_step_parity checks against the oracle."""
+    ref = make("mixed", "dualNH", "double", chains=1, drude_chains=False, hardwall=0.02)
+    alt = make("mixed", "dualNH", "double", flags=flags, chains=1, drude_chains=False, hardwall=0.02)
+    ref[4].step(40)
+    alt[4].step(20)
+    replay = alt[4].capture_steps(5)
+    for _ in range(4):
+        replay()
+    assert rel_err(alt[4].getPositions(), ref[4].getPositions()) < 1e-11
+    assert rel_err(alt[4].getVelocities(), ref[4].getVelocities()) < 1e-10
+    ref[4].close(); alt[4].close()
+
+
 @pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
 @pytest.mark.parametrize("precision", ["mixed", "double"])
 def test_100_step_parity_deferred_rescale(mode, precision):
