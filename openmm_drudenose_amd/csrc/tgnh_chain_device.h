@@ -466,6 +466,32 @@ __device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT,
     return s;
 }
 
+// Fixed-order sum of a FEW partial rows by one wavefront (every work-group computes the same bits).  The rows are
+// read as one flat array: with W = the largest multiple of NT <= 64, lane l < W adds the elements l, l+W, l+2W, ...
+// -- all of column l % NT -- into a single accumulator (independent loads), likewise the big-molecule rows at
+// GRID_CAP; then one 64-lane butterfly per thermostat over the lanes of its column.  Returns this lane's thermostat
+// sum (lane itg) and sum_b KE_b in thermostat order.
+__device__ __forceinline__ void chain_sum_rows(const ChainArgs& a, const int lane, double* mine, double* kesum) {
+    const int NT = a.L.NT;
+    const int W = 64 - 64 % NT;
+    const int n = a.nparts * NT, nb = a.nbig * NT;
+    const double* big = a.partials + (size_t)GRID_CAP * NT;
+    double acc = 0.0;
+    if (lane < W) {
+#pragma unroll 8
+        for (int f = lane; f < n; f += W) acc += a.partials[f];
+        for (int f = lane; f < nb; f += W) acc += big[f];
+    }
+    const int col = lane < W ? lane % NT : -1;
+    double m = 0.0, s = 0.0;
+    for (int b = 0; b < NT; b++) {
+        const double t = wave_sum(col == b ? acc : 0.0);
+        m = lane == b ? t : m;
+        s += t;
+    }
+    *mine = m; *kesum = s;
+}
+
 __device__ __forceinline__ Chain1Regs chain1_load(const ChainArgs& a, const double* st_in, const int itg) {
     const ChainLayout& L = a.L;
     const Chain1Map m = chain1_map(L, itg);

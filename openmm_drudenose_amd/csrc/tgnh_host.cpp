@@ -740,6 +740,7 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
         a.chain_on = 1;
         a.chain = chain_args(h);
         a.chain.chain_twice = h->chain_pending_twice ? 1 : 0;
+        a.sum_rows = h->sum_pending ? 1 : 0;
         a.x_wait = h->xwait_pending ? 1 : 0;
         a.st_in = h->d_state;
         a.st_out = h->d_stage;
@@ -749,6 +750,11 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
     size_t lds = tile_lds_bytes(h->d.precision, ops, a.hardwall != 0, a.use_com != 0);
     if ((ops & OP_KE) && h->gb == 0) lds += sizeof(double) * (TBLOCK / 64) * h->L.G;   // per-wave group bins
     const int grid = grid_for(h, ops, a.hardwall != 0, lds);
+    if ((ops & OP_KE) && h->stage_pending && !inline_chain) {      // commit the staged thermostat block on the way
+        a.commit_len = h->L.total; a.commit_src = h->d_stage; a.commit_dst = h->d_state;
+        a.commit_skip = h->L.off_ke_red; a.commit_skip_n = h->L.NT;
+        h->stage_pending = false;
+    }
     if (ops & OP_KE) {
         h->ke_parts = grid;
         if (h->num_big && a.use_com) {
@@ -762,7 +768,7 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
         Timed t(h, s, kid);
         HIP_OK(launch_tile(h->d.precision, ops, h->gb, a, grid, lds, s));
     }
-    if (inline_chain) { h->chain_pending = false; h->xwait_pending = false; h->stage_pending = true; }   // d_stage now holds the advanced thermostat
+    if (inline_chain) { h->chain_pending = false; h->sum_pending = false; h->xwait_pending = false; h->stage_pending = true; }   // d_stage now holds the advanced thermostat
     if (h->alternate_sweeps) h->sweep_reverse ^= 1;      // the next streaming launch starts where this one ends
     return TGNH_OK;
 }
@@ -806,6 +812,15 @@ static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
         }
         return TGNH_OK;
     }
+    if (h->inline_chain && !h->allreduce && h->L.NT <= CHAIN_INLINE_SUM_NT &&
+        h->ke_parts + h->num_big <= CHAIN_INLINE_SUM_ROWS && !(h->d.flags & TGNH_FLAG_MERGE_SCALE_KE)) {
+        // A small system (few partial rows): nothing to launch -- the next rescale launch sums the rows and runs the
+        // chain in its prologue (3 launches per step instead of 4 where launches are all a step costs).  With many
+        // rows that read is a chain of L2 misses on the critical path and the separate launch is cheaper.  (Not with
+        // MERGE_SCALE_KE: its rescale launch writes new rows while late work-groups could still be reading the old.)
+        h->chain_pending = true; h->sum_pending = true; h->chain_pending_twice = twice;
+        return TGNH_OK;
+    }
     if (h->inline_chain) {           // sum (and all-reduce) now, the chain itself inside the next rescale launch
         a.do_sum = 1; a.do_chain = 0;
         { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
@@ -833,10 +848,10 @@ static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
 static tgnh_status materialize_chain(tgnh_handle h, hipStream_t s) {
     if (!h->chain_pending) return commit_stage(h, s);
     ChainArgs a = chain_args(h);
-    a.do_sum = 0; a.do_chain = 1; a.chain_twice = h->chain_pending_twice ? 1 : 0;
+    a.do_sum = h->sum_pending ? 1 : 0; a.do_chain = 1; a.chain_twice = h->chain_pending_twice ? 1 : 0;
     a.x_wait = h->xwait_pending ? 1 : 0;
     { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
-    h->chain_pending = false; h->xwait_pending = false;
+    h->chain_pending = false; h->sum_pending = false; h->xwait_pending = false;
     return TGNH_OK;
 }
 

@@ -110,6 +110,9 @@ struct XchgArgs {
     unsigned int* status;       // the handle's status word (bit 2: exchange time-out)
 };
 
+constexpr int CHAIN_INLINE_SUM_NT = 10;     // thermostats (G <= 8) ...
+constexpr int CHAIN_INLINE_SUM_ROWS = 256;  // ... and partial rows up to which a rescale launch sums the rows itself
+
 struct ChainArgs {
     ChainLayout L;
     XchgArgs x;
@@ -155,6 +158,12 @@ struct TileArgs {
     // energies itself; work-group 0 writes the advanced thermostat block to a staging copy (work-groups of this
     // launch may start after work-group 0 has finished, so st_in must stay untouched); the next chain_kernel commits it
     int chain_on;
+    int sum_rows;              // few partial rows (a small system): the chain wavefront sums them itself -- no chain launch at all
+    // a staged thermostat block to commit (work-group 0, first thing): set on KE launches, which always lie between
+    // the rescale launch that staged it and the next one that reads st_in; [skip, skip + n) = the summed KE, newer in dst
+    int commit_len, commit_skip, commit_skip_n;
+    const double* commit_src;
+    double* commit_dst;
     int x_wait;                // the chain wavefront takes the kinetic energies from the mailbox exchange
     const double* st_in;
     double* st_out;
@@ -231,6 +240,7 @@ struct tgnh_context {
     bool stage_pending = false;       // d_stage is newer than d_state; the next chain_kernel launch commits it
     int sweep_reverse = 0;            // direction of the next streaming launch (alternates)
     bool alternate_sweeps = true;
+    bool sum_pending = false;         // with chain_pending: the partial rows are not summed yet either (the rescale launch does both)
     bool chain_pending = false, chain_pending_twice = false;   // summed KE waits for the next rescale launch to run the chain
     bool inline_chain = false;        // numNHChains == 1: the chain runs inside the rescale launch
     uint32_t* d_status = nullptr;

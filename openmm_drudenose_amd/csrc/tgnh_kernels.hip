@@ -211,6 +211,10 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
 
     TileIn cur, nxt;
     TRACE(0);
+    if (a.commit_len > 0 && blockIdx.x == 0) {            // take over the thermostat block an in-kernel chain staged
+        for (int i = tid; i < a.commit_len; i += TBLOCK)
+            if (i < a.commit_skip || i >= a.commit_skip + a.commit_skip_n) a.commit_dst[i] = a.commit_src[i];
+    }
     // ---- scale factors.  With a one-link chain the Nose-Hoover update itself runs here (A5): every work-group
     // computes the same factors from the same summed kinetic energies (fp64, deterministic); work-group 0 alone
     // writes the advanced thermostat block -- to a staging copy, because work-groups of this launch may start after
@@ -250,7 +254,13 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     if (itg < NT) s_scale[itg] = tot;                // parked for the KESum below (same wavefront: in order)
                     if (write && itg < NT) a.chain.st[L.off_ke_red + itg] = tot;   // nobody reads it there in this launch
                 }
-                if (write && itg == 63) {                            // Cu :493-497
+                if (a.sum_rows) {                                    // a small system: no chain launch, the rows are summed here
+                    double mine, ks;
+                    chain_sum_rows(a.chain, itg, &mine, &ks);
+                    creg.ke = mine;
+                    if (write && itg < NT) a.chain.st[L.off_ke_red + itg] = mine;   // nobody reads it there in this launch
+                    if (write && itg == 63) a.st_out[L.off_kesum] = 0.5 * ks;       // Cu :493-497
+                } else if (write && itg == 63) {                     // Cu :493-497
                     double s = 0.0;
                     for (int i = 0; i < NT; i++) s += a.x_wait ? s_scale[i] : a.st_in[L.off_ke_red + i];
                     a.st_out[L.off_kesum] = 0.5 * s;
