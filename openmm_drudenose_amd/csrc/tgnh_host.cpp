@@ -477,6 +477,7 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         // an L2-missing read of a dozen dependent batches, 7-9 us on the critical path against a 6 us launch.)
         const char* e = getenv("TGNH_INLINE_CHAIN");
         const bool want = e ? e[0] != '0' : true;
+        if (const char* e4 = getenv("TGNH_INLINE_SUM_ROWS")) c->inline_sum_rows = atoi(e4);   // tuning: 0 = never
         const char* e3 = getenv("TGNH_ALTERNATE_SWEEPS");
         c->alternate_sweeps = !(e3 && e3[0] == '0');
         // dualNH qualifies too: with useDrudeNHChains its real and Drude chains are independent (Chain1Map), without
@@ -813,7 +814,7 @@ static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
         return TGNH_OK;
     }
     if (h->inline_chain && !h->allreduce && h->L.NT <= CHAIN_INLINE_SUM_NT &&
-        h->ke_parts + h->num_big <= CHAIN_INLINE_SUM_ROWS && !(h->d.flags & TGNH_FLAG_MERGE_SCALE_KE)) {
+        h->ke_parts + h->num_big <= h->inline_sum_rows && !(h->d.flags & TGNH_FLAG_MERGE_SCALE_KE)) {
         // A small system (few partial rows): nothing to launch -- the next rescale launch sums the rows and runs the
         // chain in its prologue (3 launches per step instead of 4 where launches are all a step costs).  With many
         // rows that read is a chain of L2 misses on the critical path and the separate launch is cheaper.  (Not with
