@@ -14,15 +14,17 @@ from helpers import rel_err
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-NSTEPS = 40
+NSTEPS = 120
 
 
-@pytest.mark.parametrize("variant", [FLAG_DEFER_SCALE, 0])
-def test_two_processes_exchange_by_ipc_mailboxes(tmp_path, variant):
+@pytest.mark.parametrize("variant,lag", [(FLAG_DEFER_SCALE, 0.0), (0, 0.0), (FLAG_DEFER_SCALE, 0.03)])
+def test_two_processes_exchange_by_ipc_mailboxes(tmp_path, variant, lag):
+    """lag > 0: rank 1 idles that long after every 50 steps, so rank 0's launches really wait in their spin loops (and
+    run ahead by the one exchange the two mailbox parities allow)."""
     sys.path.insert(0, HERE)
     from xchg_worker import make_integrator
     out = str(tmp_path)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TGNH_XW_LAG=str(lag))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "xchg_worker.py"), str(r), "2", out, str(NSTEPS), str(variant)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     logs = []

@@ -54,7 +54,15 @@ def main():
     publish(os.path.join(out, f"ready{rank}.npy"), np.zeros(1))
     for r in range(world):
         wait_for(os.path.join(out, f"ready{r}.npy"))
-    ctx.step(nsteps)
+    lag = float(os.environ.get("TGNH_XW_LAG", "0"))          # soak runs: odd ranks fall behind by `lag` s every 50 steps
+    if lag > 0:
+        for done in range(0, nsteps, 50):
+            ctx.step(min(50, nsteps - done))
+            if rank % 2:
+                ctx.torch.cuda.synchronize()
+                time.sleep(lag)
+    else:
+        ctx.step(nsteps)
     ctx.torch.cuda.synchronize()
     flags = ctx.check()
     publish(os.path.join(out, f"pos{rank}.npy"), ctx.getPositions())

@@ -7,9 +7,10 @@ import numpy as np
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 steps = sys.argv[1] if len(sys.argv) > 1 else "20000"
 waters = sys.argv[2] if len(sys.argv) > 2 else "20000"
+lag = sys.argv[3] if len(sys.argv) > 3 else "0"          # seconds rank 1 idles every 50 steps (rank 0 waits in its kernels)
 for variant in ("2", "0"):
     out = tempfile.mkdtemp()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TGNH_XW_WATERS=waters, TGNH_XW_PAIRS="500")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TGNH_XW_WATERS=waters, TGNH_XW_PAIRS="500", TGNH_XW_LAG=lag)
     procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "xchg_worker.py"), str(r), "2", out, steps, variant], env=env) for r in range(2)]
     rcs = [p.wait() for p in procs]
     flags = [int(np.load(os.path.join(out, f"flags{r}.npy"))[0]) for r in range(2)]
