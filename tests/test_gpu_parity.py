@@ -748,6 +748,24 @@ def test_config_sizes_parity(name):
 # ---------------------------------------------------------------------------
 # full size (BASELINE.json metric: 1 M Drude pairs): size-independent properties
 # ---------------------------------------------------------------------------
+def test_full_size_steps_against_the_oracle():
+    """The metric configuration itself (1 M Drude pairs = 5 M slots, mixed precision, deferred rescale, hard wall, the
+    bench's integrator settings) against the oracle directly: the oracle manages ~5 steps/s at this size, so a few
+    steps are affordable -- enough to pass through every launch of the step, the in-kernel chain and the row sum
+    over all 1.2 k x 8 partial rows."""
+    s, g, ng = synth.water_box(1_000_000)
+    it = integ(chains=1, hardwall=0.02)
+    bind_groups(it, g, ng)
+    ctx = HipContext(s, it, mode="TGNH", precision="mixed", flags=FLAG_DEFER_SCALE)
+    o = make_oracle(s, g, ng, "TGNH", it)
+    pos_o, vel_o = oracle_run(o, s, 3, x0=ctx.sites())
+    ctx.step(3)
+    ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
+    print(f"5 M slots, 3 steps: pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= TOL and ev <= TOL          # (thermostat variables are not compared: deferred, the chain is half a step ahead)
+    ctx.close()
+
+
 def test_full_size_properties():
     import torch
     s, g, ng = synth.water_box(1_000_000)
