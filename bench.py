@@ -414,6 +414,14 @@ def main():
                          "frac_of_device_copy": round(achieved / copy_gbps, 4)},
             "kernels": rows,
         }
+        # `value` times whole steps, the harness force call-out included (in a real context that slot is OpenMM's
+        # calcForcesAndEnergy).  The integrator's own launches alone (SURVEY 8d reports the force kernel separately):
+        own = sum(v["avg_us"] for k, v in rows.items() if k != "harness force")
+        if own > 0:
+            out["integrator_only"] = {"steps_per_s": round(1e6 / own, 1), "us_per_step": round(own, 2),
+                                      "how": "sum of the average durations of the integrator's own launches (instrumented repeat), force call-out excluded; "
+                                             "derived, not a timed region",
+                                      "vs_model_roofline_steps_per_s": round(HBM_PEAK_GBS * 1e9 / b_step * world, 1)}
         if extra:
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
