@@ -101,6 +101,13 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
                 prev = r;
             }
         }
+        if (com) {      // a molecule of massless sites only: the reference forms v_com = 0 * RECIP(0) = NaN for it (K :86-104) and
+                        // every thermostat follows; refuse it rather than reproduce that
+            std::vector<double> rmass(R, 0.0);
+            for (int i = 0; i < N; i++) rmass[c->resid[i]] += c->mass[i];
+            for (int r : res_order)
+                if (!(rmass[r] > 0.0)) return fail(TGNH_ERR_UNSUPPORTED, "a molecule has no massive particle (its centre-of-mass velocity is undefined)");
+        }
     }
 
     // Molecules longer than a tile ("big": proteins, polymers) cannot have their COM formed in LDS; theirs comes

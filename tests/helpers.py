@@ -79,3 +79,41 @@ def extended_energy(system, normal, pos, vel, x0, nkt, eta, eta_dot, eta_mass, c
         kt = kT_drude if t == len(nkt) - 1 else kT
         th += 0.5 * float((eta_mass[t] * eta_dot[t] ** 2).sum()) + nkt[t] * eta[t, 0] + kt * float(eta[t, 1:].sum())
     return ke + pe + th, ke, th
+
+
+def random_topology(seed):
+    """Ragged test input: molecules of 1-40 slots (every third seed: two longer than a tile), Drude pairs anywhere inside
+    a molecule (Drude before or after its parent, up to 30 slots apart), massless sites, 1-6 temperature groups assigned
+    per molecule, a few constraints inside molecules."""
+    rng = np.random.default_rng(1000 + seed)
+    sizes = rng.integers(1, 41, size=rng.integers(40, 400))
+    if seed % 3 == 0:
+        sizes[rng.integers(0, len(sizes), 2)] = rng.integers(600, 1500, 2)
+    n = int(sizes.sum())
+    resid = np.repeat(np.arange(len(sizes)), sizes).astype(np.int32)
+    first = np.r_[0, np.cumsum(sizes)[:-1]]
+    mass = rng.uniform(1.0, 40.0, n)
+    ngroups = int(rng.integers(1, 7))
+    group = np.repeat(rng.integers(0, ngroups, len(sizes)), sizes).astype(np.int32)
+    pd, pp, used = [], [], np.zeros(n, bool)
+    for f, sz in zip(first, sizes):
+        for _ in range(int(rng.integers(0, max(1, sz // 2) + 1))):
+            a = f + int(rng.integers(0, sz))
+            b = a + int(rng.integers(-30, 31))
+            if b == a or b < f or b >= f + sz or used[a] or used[b]:
+                continue
+            used[a] = used[b] = True
+            pd.append(a); pp.append(b)
+            mass[a] = 0.4
+    free = np.flatnonzero(~used)
+    mass[rng.choice(free, size=min(len(free), n // 20), replace=False)] = 0.0
+    for f, sz in zip(first, sizes):                      # every molecule keeps a massive particle (else v_com is 0/0: rejected)
+        if not mass[f:f + sz].any():
+            mass[f] = 12.0
+    cons = []
+    for f, sz in zip(first, sizes):
+        if sz >= 3 and rng.random() < 0.3:
+            i, j = f + rng.choice(sz, 2, replace=False)
+            if mass[i] > 0 and mass[j] > 0:
+                cons.append((i, j))
+    return mass, pd, pp, resid, group, ngroups, cons, sizes, first, rng

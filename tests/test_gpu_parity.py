@@ -748,6 +748,33 @@ def test_config_sizes_parity(name):
 # ---------------------------------------------------------------------------
 # full size (BASELINE.json metric: 1 M Drude pairs): size-independent properties
 # ---------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["TGNH", "dualNH"])
+@pytest.mark.parametrize("seed", [0, 1, 2, 5])
+def test_random_ragged_topologies_against_the_oracle(seed, mode):
+    """Ragged inputs on the device (tests/helpers.py::random_topology: molecules of 1-40 slots, some longer than a
+    tile, Drudes before or after their parents and up to 30 slots away, massless sites, up to 6 groups): 40 steps
+    against the oracle, deferred rescale, hard wall on."""
+    from helpers import random_topology
+    mass, pd, pp, resid, group, ngroups, cons, sizes, first, rng = random_topology(seed)
+    n = len(mass)
+    pos = rng.uniform(0.0, 3.0, (n, 3))
+    s, g, ng = synth._finish(mass, np.array(pd, np.int32), np.array(pp, np.int32), resid, pos, group, ngroups, rng, 300.0, 1.0,
+                             f"ragged{seed}")
+    it = integ(chains=1 + seed % 3, hardwall=0.02)
+    if mode == "TGNH":
+        bind_groups(it, g, ng)
+    else:
+        g, ng = np.zeros_like(g), 1
+    ctx = HipContext(s, it, mode=mode, precision="double", flags=FLAG_DEFER_SCALE)
+    o = make_oracle(s, g, ng, mode, it)
+    pos_o, vel_o = oracle_run(o, s, 40, x0=ctx.sites())
+    ctx.step(40)
+    ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
+    print(f"ragged seed {seed} {mode}: {n} slots, {len(pd)} pairs, {len(sizes)} molecules, {ng} groups: pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= TOL and ev <= TOL
+    ctx.close()
+
+
 def test_full_size_steps_against_the_oracle():
     """The metric configuration itself (1 M Drude pairs = 5 M slots, mixed precision, deferred rescale, hard wall, the
     bench's integrator settings) against the oracle directly: the oracle manages ~5 steps/s at this size, so a few

@@ -104,6 +104,11 @@ def test_unsupported_topologies_fail_loudly():
     m = s.mass.copy(); m[0] = 0.0                               # massless parent: the reference divides by it
     with pytest.raises(TgnhError, match="massless"):
         HostTopology(type(s)(mass=m, pair_drude=s.pair_drude, pair_parent=s.pair_parent, resid=s.resid), integ())
+    lone = synth.DrudeSystem(mass=np.array([12.0, 1.0, 0.0]), pair_drude=np.zeros(0, np.int32), pair_parent=np.zeros(0, np.int32),
+                             resid=np.array([0, 0, 1], np.int32))                  # molecule 1 = one massless site: v_com = 0/0 in the reference
+    with pytest.raises(TgnhError, match="no massive particle"):
+        HostTopology(lone, integ())
+    HostTopology(lone, integ(com=False))                            # without the COM group nothing divides by that mass
     far = synth.DrudeSystem(mass=np.ones(1300), pair_drude=np.array([1200]), pair_parent=np.array([0]), resid=np.zeros(1300, np.int32))
     with pytest.raises(TgnhError, match="spans more than one"):  # Drude 1200 slots away from its parent
         HostTopology(far, integ())
@@ -165,3 +170,36 @@ def test_up_to_32_temperature_groups():
     s, g, ng = synth.many_groups(100, 8, 33)
     with pytest.raises(TgnhError, match="more than 32 temperature groups"):
         HostTopology(s, integ(group=g, ngroups=ng))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_topologies_tile_and_count_like_the_oracle(seed):
+    """Ragged inputs: molecules of 1-40 slots in random order of size (a few longer than a tile), Drude pairs anywhere
+    inside a molecule (Drude before or after its parent, up to 30 slots apart), massless sites, 1-6 temperature groups
+    assigned per molecule, random constraints inside molecules.  Whatever comes: tiles <= 512 slots that cut neither a
+    pair nor a molecule that fits a tile, packed words that decode to the input, normal-particle list and degrees of
+    freedom equal to the oracle's."""
+    from helpers import random_topology
+    mass, pd, pp, resid, group, ngroups, cons, sizes, first, rng = random_topology(seed)
+    n = len(mass)
+    s = synth.DrudeSystem(mass=mass, pair_drude=np.array(pd, np.int32), pair_parent=np.array(pp, np.int32), resid=resid,
+                          constraints=np.array(cons, np.int32).reshape(-1, 2), has_cm_motion_remover=bool(seed % 2))
+    it = integ(chains=int(rng.integers(1, 5)), group=group, ngroups=ngroups)
+    t = HostTopology(s, it)
+    o = make_oracle(s, group, ngroups, "TGNH", it)
+    assert np.array_equal(t.topology(0), o.normal_particles())
+    assert np.allclose(t.dof()[0], o.dof()[0], rtol=1e-13) and np.allclose(t.dof()[1], o.dof()[1], rtol=1e-13)
+    ts = t.topology(7)
+    assert ts[0] == 0 and ts[-1] == n and np.all(np.diff(ts) > 0) and np.all(np.diff(ts) <= 512)
+    tile_of = np.searchsorted(ts, np.arange(n), side="right") - 1
+    if len(pd):
+        assert np.all(tile_of[s.pair_drude] == tile_of[s.pair_parent])
+    for f, sz in zip(first, sizes):
+        if sz <= 512:
+            assert tile_of[f] == tile_of[f + sz - 1]
+    meta = t.topology(8).view(np.uint32)
+    off = ((meta >> 10) & 2047).astype(np.int64) - 1024
+    assert np.array_equal((np.arange(n) + off)[s.pair_drude], s.pair_parent)
+    assert np.array_equal(((meta >> 2) & 255).astype(np.int32), group)
+    assert np.array_equal(np.flatnonzero((meta & 3) == 1), np.sort(s.pair_drude))
+    assert np.bincount(tile_of, minlength=len(ts) - 1).max() <= 512
