@@ -44,7 +44,16 @@ SYSTEMS = {
     "nacl": lambda: synth.nacl(),
     "il40": lambda: synth.ionic_liquid(40),
     "mixed": lambda: synth.mixed(300, 20),
+    "ragged6": lambda: ragged_system(6),                       # random molecule sizes / pair placements, 4 groups
 }
+
+
+def ragged_system(seed):
+    from helpers import random_topology
+    mass, pd, pp, resid, group, ngroups, cons, sizes, first, rng = random_topology(seed)
+    pos = rng.uniform(0.0, 3.0, (len(mass), 3))
+    return synth._finish(mass, np.array(pd, np.int32), np.array(pp, np.int32), resid, pos, group, ngroups, rng, 300.0, 1.0,
+                         f"ragged{seed}")
 
 
 def make(sysname, mode, precision, flags=0, **kw):
@@ -563,7 +572,8 @@ def test_particle_sharded_hip_path_on_one_gpu():
     (FLAG_DEFER_SCALE, 1, 2, "mixed", "TGNH"), (0, 1, 2, "mixed", "TGNH"), (FLAG_DEFER_SCALE, 3, 2, "mixed", "TGNH"),
     (0, 3, 2, "mixed", "TGNH"), (FLAG_MERGE_SCALE_KE, 1, 2, "mixed", "TGNH"),
     (FLAG_DEFER_SCALE, 1, 2, "groups32", "TGNH"),   # 2 ranks x 34 thermostats = 68 cells: more than one wavefront's worth
-    (FLAG_DEFER_SCALE, 1, 2, "mixed", "dualNH"), (0, 3, 2, "mixed", "dualNH")])
+    (FLAG_DEFER_SCALE, 1, 2, "mixed", "dualNH"), (0, 3, 2, "mixed", "dualNH"),
+    (FLAG_DEFER_SCALE, 1, 2, "ragged6", "TGNH")])    # shards cut at ragged molecule boundaries
 def test_particle_sharded_mailbox_exchange_on_one_gpu(variant, chains, nranks, sysname, mode):
     """The mailbox exchange (tgnh_exchange_*: the KE all-reduce done by the integrator's own kernels with stores into
     every peer's mailbox) with the 'ranks' as handles on this one GPU, each on its own stream, mailboxes attached by
@@ -749,11 +759,11 @@ def test_config_sizes_parity(name):
 # full size (BASELINE.json metric: 1 M Drude pairs): size-independent properties
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["TGNH", "dualNH"])
-@pytest.mark.parametrize("seed", [0, 1, 2, 5])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_random_ragged_topologies_against_the_oracle(seed, mode):
     """Ragged inputs on the device (tests/helpers.py::random_topology: molecules of 1-40 slots, some longer than a
     tile, Drudes before or after their parents and up to 30 slots away, massless sites, up to 6 groups): 40 steps
-    against the oracle, deferred rescale, hard wall on."""
+    against the oracle, hard wall on; pass structure, precision and chain length vary with the seed."""
     from helpers import random_topology
     mass, pd, pp, resid, group, ngroups, cons, sizes, first, rng = random_topology(seed)
     n = len(mass)
@@ -765,7 +775,8 @@ def test_random_ragged_topologies_against_the_oracle(seed, mode):
         bind_groups(it, g, ng)
     else:
         g, ng = np.zeros_like(g), 1
-    ctx = HipContext(s, it, mode=mode, precision="double", flags=FLAG_DEFER_SCALE)
+    flags = (FLAG_DEFER_SCALE, 0, FLAG_MERGE_SCALE_KE)[seed % 3]          # every pass structure, both precisions that are gated
+    ctx = HipContext(s, it, mode=mode, precision=("double", "mixed")[seed % 2], flags=flags)
     o = make_oracle(s, g, ng, mode, it)
     pos_o, vel_o = oracle_run(o, s, 40, x0=ctx.sites())
     ctx.step(40)
