@@ -117,3 +117,32 @@ def random_topology(seed):
             if mass[i] > 0 and mass[j] > 0:
                 cons.append((i, j))
     return mass, pd, pp, resid, group, ngroups, cons, sizes, first, rng
+
+
+def random_clusters(rng, mass, pd, pp, sizes, first, pos):
+    """Constraint clusters for a random_topology: in about half of the molecules, 2-4 massive atoms outside Drude pairs are
+    pulled to within ~0.1 nm of one another and held at those distances -- all pairs (a rigid body, up to 3 atoms) or the bonds from
+    the first atom only.  -> (cluster_atoms [K,4], cluster_dist [K,6]) in DrudeSystem's canonical pair order."""
+    PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))
+    in_pair = np.zeros(len(mass), bool)
+    in_pair[pd] = True
+    in_pair[pp] = True
+    atoms, dist = [], []
+    for f, sz in zip(first, sizes):
+        cand = [i for i in range(f, f + sz) if mass[i] > 0 and not in_pair[i]]
+        if len(cand) < 2 or rng.random() < 0.5:
+            continue
+        c = int(rng.integers(2, min(4, len(cand)) + 1))
+        pick = rng.choice(cand, c, replace=False)
+        for k in range(1, c):
+            pos[pick[k]] = pos[pick[0]] + rng.normal(0.0, 0.06, 3) + np.array([0.08, 0.0, 0.0])
+        rigid = c <= 3 and rng.random() < 0.5            # (a random rigid tetrahedron can take SHAKE > 500 sweeps at 1e-10)
+        a = [-1] * 4
+        a[:c] = [int(x) for x in pick]
+        d = [0.0] * 6
+        for k, (i, j) in enumerate(PAIRS):
+            if j < c and (rigid or i == 0):
+                d[k] = float(np.linalg.norm(pos[pick[i]] - pos[pick[j]]))
+        atoms.append(a)
+        dist.append(d)
+    return np.array(atoms, np.int32).reshape(-1, 4), np.array(dist, np.float64).reshape(-1, 6)

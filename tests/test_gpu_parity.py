@@ -786,6 +786,40 @@ def test_random_ragged_topologies_against_the_oracle(seed, mode):
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["TGNH", "dualNH"])
+@pytest.mark.parametrize("seed", [1, 2, 4, 7])
+def test_random_constraint_clusters_against_the_oracle(seed, mode):
+    """The split (constrained) step on ragged topologies with random constraint clusters of 2-4 atoms (rigid or
+    bonds from one atom; tests/helpers.py::random_clusters): SHAKE on posDelta, the velocity stage (TGNH), dof
+    reduced per group -- 40 steps against the oracle's constrained loop."""
+    from helpers import random_topology, random_clusters
+    mass, pd, pp, resid, group, ngroups, cons, sizes, first, rng = random_topology(seed)
+    pos = rng.uniform(0.0, 3.0, (len(mass), 3))
+    ca, cd = random_clusters(rng, mass, pd, pp, sizes, first, pos)
+    s, g, ng = synth._finish(mass, np.array(pd, np.int32), np.array(pp, np.int32), resid, pos, group, ngroups, rng, 300.0, 1.0,
+                             f"clusters{seed}")
+    s.set_clusters(ca, cd)
+    it = integ(chains=1 + seed % 2, hardwall=0.02)
+    it.setConstraintTolerance(1e-10)
+    if mode == "TGNH":
+        bind_groups(it, g, ng)
+    else:
+        g, ng = np.zeros_like(g), 1
+    ctx = HipContext(s, it, mode=mode, precision="double")
+    assert ctx.constrained and len(ca) > 10
+    o = make_oracle(s, g, ng, mode, it)
+    assert np.allclose(ctx.dof()[0], to_internal(o.dof()[0], mode), rtol=1e-14)
+    pos_o, vel_o, x0 = s.positions.copy(), s.velocities.copy(), ctx.sites()
+    f = o.harness_force(pos_o, x0, synth.K_DRUDE, synth.K_TETHER)
+    o.run_harness_constrained(pos_o, vel_o, f, x0, synth.K_DRUDE, synth.K_TETHER, 1e-10, 40)
+    ctx.step(40)
+    assert ctx.check() == 0
+    ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
+    print(f"clusters seed {seed} {mode}: {len(ca)} clusters, {len(s.constraints)} constraints: pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= TOL and ev <= TOL
+    ctx.close()
+
+
 def test_full_size_steps_against_the_oracle():
     """The metric configuration itself (1 M Drude pairs = 5 M slots, mixed precision, deferred rescale, hard wall, the
     bench's integrator settings) against the oracle directly: the oracle manages ~5 steps/s at this size, so a few
