@@ -682,13 +682,17 @@ def test_against_committed_regression_vectors():
         ctx.close()
 
 
-def test_thermostat_state_checkpoint_roundtrip():
-    s, g, ng, it, a = make("il40", "TGNH", "double")
+@pytest.mark.parametrize("mode,chains,flags", [("TGNH", 3, 0), ("TGNH", 1, 0), ("dualNH", 1, 0), ("TGNH", 1, FLAG_MERGE_SCALE_KE)])
+def test_thermostat_state_checkpoint_roundtrip(mode, chains, flags):
+    """Save positions, velocities and the thermostat variables, restore them into a fresh context, continue: bitwise the
+    same trajectory.  chains = 1: the saved state has to come out of (and go back into) the in-kernel chain's staged
+    block."""
+    s, g, ng, it, a = make("il40", mode, "double", chains=chains, flags=flags)
     a.step(20)
     saved = [a.thermostat_state(w) for w in range(3)]
     pos, vel = a.getPositions(), a.getVelocities()
     a.step(20)
-    _, _, _, _, b = make("il40", "TGNH", "double")
+    _, _, _, _, b = make("il40", mode, "double", chains=chains, flags=flags)
     b.setPositions(pos); b.setVelocities(vel); b.compute_forces()
     for w in range(3):
         b.set_thermostat_state(w, saved[w])
