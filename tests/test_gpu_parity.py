@@ -715,9 +715,10 @@ def test_kinetic_energy_query(mode):
     ctx.close()
 
 
-def test_setters_take_effect_mid_run():
+@pytest.mark.parametrize("chains", [1, 3])
+def test_setters_take_effect_mid_run(chains):
     """Step size and drudeStepsPerRealStep are re-read every step (Cu :292, :437)."""
-    s, g, ng, it, ctx = make("water27", "TGNH", "double")
+    s, g, ng, it, ctx = make("water27", "TGNH", "double", chains=chains)
     o = make_oracle(s, g, ng, "TGNH", it)
     pos, vel, x0 = s.positions.copy(), s.velocities.copy(), ctx.sites()
     f = o.harness_force(pos, x0, synth.K_DRUDE, synth.K_TETHER)
