@@ -485,6 +485,10 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         const char* e = getenv("TGNH_INLINE_CHAIN");
         const bool want = e ? e[0] != '0' : true;
         if (const char* e4 = getenv("TGNH_INLINE_SUM_ROWS")) c->inline_sum_rows = atoi(e4);   // tuning: 0 = never
+        // ... up to 2 M slots: beyond, the launches are bandwidth-bound, the gain shrinks to 0.7 % and the row read would
+        // only lengthen the dominant launch (its bandwidth figure is what DESIGN.md section 4 reports)
+        c->inline_sum_all = d->num_particles < 2000000;
+        if (const char* e5 = getenv("TGNH_INLINE_SUM_ALL")) c->inline_sum_all = e5[0] != '0';
         const char* e3 = getenv("TGNH_ALTERNATE_SWEEPS");
         c->alternate_sweeps = !(e3 && e3[0] == '0');
         // dualNH qualifies too: with useDrudeNHChains its real and Drude chains are independent (Chain1Map), without
@@ -748,7 +752,7 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
         a.chain_on = 1;
         a.chain = chain_args(h);
         a.chain.chain_twice = h->chain_pending_twice ? 1 : 0;
-        a.sum_rows = h->sum_pending ? 1 : 0;
+        a.sum_rows = h->sum_pending ? (h->ke_parts + h->num_big <= h->inline_sum_rows ? 1 : 2) : 0;
         a.x_wait = h->xwait_pending ? 1 : 0;
         a.st_in = h->d_state;
         a.st_out = h->d_stage;
@@ -821,10 +825,13 @@ static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
         return TGNH_OK;
     }
     if (h->inline_chain && !h->allreduce && h->L.NT <= CHAIN_INLINE_SUM_NT &&
-        h->ke_parts + h->num_big <= h->inline_sum_rows && !(h->d.flags & TGNH_FLAG_MERGE_SCALE_KE)) {
-        // A small system (few partial rows): nothing to launch -- the next rescale launch sums the rows and runs the
-        // chain in its prologue (3 launches per step instead of 4 where launches are all a step costs).  With many
-        // rows that read is a chain of L2 misses on the critical path and the separate launch is cheaper.  (Not with
+        (h->ke_parts + h->num_big <= h->inline_sum_rows || h->inline_sum_all) && !(h->d.flags & TGNH_FLAG_MERGE_SCALE_KE)) {
+        // Unsharded, one-link chains, G <= 8: nothing to launch -- the next rescale launch sums the partial rows and
+        // runs the chain in its prologue (3 launches per step).  Up to 256 rows its chain wavefront reads them alone
+        // (one batch of loads); more rows are read by all four wavefronts, a quarter each, ahead of their tile
+        // loads (read by one wavefront they were a chain of L2 misses on the critical path, +7-9 us) -- that up to 2 M
+        // slots (inline_sum_all).  +4 % steps/s at 625 k slots, +7-17 % for small systems
+        // (profiles/r01_tuning_sweep.log).  (Not with
         // MERGE_SCALE_KE: its rescale launch writes new rows while late work-groups could still be reading the old.)
         h->chain_pending = true; h->sum_pending = true; h->chain_pending_twice = twice;
         return TGNH_OK;

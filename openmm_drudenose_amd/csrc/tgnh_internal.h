@@ -241,6 +241,7 @@ struct tgnh_context {
     int sweep_reverse = 0;            // direction of the next streaming launch (alternates)
     bool alternate_sweeps = true;
     int inline_sum_rows = tgnh::CHAIN_INLINE_SUM_ROWS;
+    bool inline_sum_all = false;      // more rows than that (and < 2 M slots): all four wavefronts of the rescale launch sum them (sum_rows = 2)
     bool sum_pending = false;         // with chain_pending: the partial rows are not summed yet either (the rescale launch does both)
     bool chain_pending = false, chain_pending_twice = false;   // summed KE waits for the next rescale launch to run the chain
     bool inline_chain = false;        // numNHChains == 1: the chain runs inside the rescale launch

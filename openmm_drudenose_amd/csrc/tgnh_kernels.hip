@@ -228,7 +228,38 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
     mixed s_com = 1, s_drude = 1;
     const bool chain_wave = DO_SCALE && a.chain_on && tid < 64;
     const bool have_tile = (int)blockIdx.x < a.num_tiles;
+    // sum_rows == 2 (many partial rows, no chain launch): ALL four wavefronts read a quarter of the rows each, in
+    // batches of 16 loads issued ahead of the tile loads, so the row read costs one or two memory latencies that the
+    // tile loads overlap -- read by the chain wavefront alone it was a chain of L2 misses on the critical path.
+    // Flat view of the rows as in chain_sum_rows: lane l < W of wavefront w starts at element w W + l, stride 4 W.
+    double racc = 0.0;
+    int rcol = -1;
+    __shared__ double s_part[TBLOCK / 64][CHAIN_INLINE_SUM_NT];
+    if (DO_SCALE && a.chain_on && a.sum_rows == 2) {
+        const int NT = G + 2, W = 64 - 64 % NT, lane = tid & 63;
+        if (lane < W) {
+            rcol = lane % NT;
+            const int n = a.chain.nparts * NT, stride = (TBLOCK / 64) * W;
+            for (int f0 = (tid >> 6) * W + lane; f0 < n; f0 += 16 * stride) {
+                double v[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) { const int f = f0 + k * stride; v[k] = f < n ? a.chain.partials[f] : 0.0; }
+#pragma unroll
+                for (int k = 0; k < 16; k++) racc += v[k];
+            }
+            const double* big = a.chain.partials + (size_t)GRID_CAP * NT;
+            for (int f = (tid >> 6) * W + lane; f < a.chain.nbig * NT; f += stride) racc += big[f];
+        }
+    }
     if (!chain_wave && have_tile) load_tile(blockIdx.x, cur);
+    if (DO_SCALE && a.chain_on && a.sum_rows == 2) {
+        const int NT = G + 2;
+        for (int b = 0; b < NT; b++) {
+            const double tb = wave_sum(rcol == b ? racc : 0.0);
+            if ((tid & 63) == 0) s_part[tid >> 6][b] = tb;
+        }
+        __syncthreads();
+    }
     TRACE(1);
     int trace_tile = 0; (void)trace_tile;
 #ifdef TGNH_TRACE
@@ -254,9 +285,19 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     if (itg < NT) s_scale[itg] = tot;                // parked for the KESum below (same wavefront: in order)
                     if (write && itg < NT) a.chain.st[L.off_ke_red + itg] = tot;   // nobody reads it there in this launch
                 }
-                if (a.sum_rows) {                                    // a small system: no chain launch, the rows are summed here
-                    double mine, ks;
-                    chain_sum_rows(a.chain, itg, &mine, &ks);
+                if (a.sum_rows) {                                    // no chain launch: the rows are summed in this launch
+                    double mine = 0.0, ks = 0.0;
+                    if (a.sum_rows == 2) {                           // the four wavefronts' quarters, in wavefront order
+                        for (int b = 0; b < NT; b++) {
+                            double tb = 0.0;
+#pragma unroll
+                            for (int w = 0; w < TBLOCK / 64; w++) tb += s_part[w][b];
+                            mine = itg == b ? tb : mine;
+                            ks += tb;
+                        }
+                    } else {
+                        chain_sum_rows(a.chain, itg, &mine, &ks);      // a handful of rows: this wavefront alone
+                    }
                     creg.ke = mine;
                     if (write && itg < NT) a.chain.st[L.off_ke_red + itg] = mine;   // nobody reads it there in this launch
                     if (write && itg == 63) a.st_out[L.off_kesum] = 0.5 * ks;       // Cu :493-497
