@@ -7,9 +7,14 @@ SWM4-NDP water box of 1,000,000 molecules (5,000,000 particle slots, 1,000,000 D
 state resident in HBM.  The force call-out (OpenMM's calcForcesAndEnergy in a real context) is
 the harness spring kernel and is INSIDE the timed region.  N > 1 shards whole molecules over the
 ranks (strong scaling: the 1 M-pair system is fixed) with one all-reduce of the per-thermostat
-kinetic-energy sums per thermostat half step: RCCL through torch.distributed, or -- after a short
-run on a small box has shown both to agree on this node -- the library's mailbox exchange (stores
-into every peer's mailbox over xGMI, waited for inside the rescale launch; --exchange).
+kinetic-energy sums per thermostat half step.  The headline value of a sharded run uses RCCL
+(torch.distributed all_reduce on the library's device buffer, captured into the step's hipGraph), as
+BASELINE.json's north_star names it; the library's mailbox exchange (stores into every peer's mailbox
+over xGMI, waited for inside the rescale launch) is measured right after it and reported beside it as
+`extra.mailbox`, together with its validation verdict against the RCCL run.
+
+`python bench.py --gpus N` from a plain shell starts its own N ranks (one per GPU) through
+torch.distributed.run before anything touches a GPU; under a launcher (WORLD_SIZE set) it is one of the ranks.
 
 Prints ONE JSON line on rank 0.
 """
@@ -41,9 +46,9 @@ def parse():
     p.add_argument("--molecules", type=int, default=1_000_000, help="SWM4 molecules = Drude pairs (metric: 1,000,000)")
     p.add_argument("--precision", default="mixed", choices=["single", "mixed", "double"])
     p.add_argument("--mode", default="TGNH", choices=["TGNH", "dualNH"])
-    p.add_argument("--variant", default="defer", choices=["plain", "merge", "defer"],
-                   help="defer (default) = end-of-step rescale folded into the next step's first pass; "
-                        "plain = the reference's pass structure; merge = rescale fused with the next KE pass (DESIGN.md)")
+    p.add_argument("--variant", default="defer", choices=["plain", "defer"],
+                   help="defer (default) = end-of-step rescale and second half kick folded into the next step's first pass; "
+                        "plain = the reference's pass structure (what the OpenMM glue runs) (DESIGN.md)")
     p.add_argument("--chains", type=int, default=1)
     p.add_argument("--drude-steps", type=int, default=20, help="drudeStepsPerRealStep (reference default 20)")
     p.add_argument("--hardwall", type=float, default=0.02, help="maxDrudeDistance nm (example/nacl_tg.py:22); 0 = off")
@@ -51,9 +56,11 @@ def parse():
     p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                    help="replay the step loop from a hipGraph (auto: on when sharded over >1 GPU, where launches are short)")
     p.add_argument("--graph-steps", type=int, default=10, help="time steps per captured graph")
-    p.add_argument("--exchange", default="auto", choices=["auto", "mailbox", "rccl"],
-                   help="KE all-reduce of a sharded run: rccl = torch.distributed all_reduce; mailbox = tgnh_exchange_* "
-                        "(stores over xGMI); auto = mailbox if a validation run on a small box agrees with rccl on every rank")
+    p.add_argument("--exchange", default="rccl", choices=["rccl", "mailbox"],
+                   help="KE all-reduce of the HEADLINE sharded run: rccl = torch.distributed all_reduce (north_star); "
+                        "mailbox = tgnh_exchange_* (stores over xGMI).  The other one is measured as an extra leg")
+    p.add_argument("--dry-launch", action="store_true",
+                   help="launcher check only: the ranks rendezvous (gloo), count themselves and rank 0 prints the count; no GPU work")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the extra single-precision / variant legs")
     return p.parse_args()
@@ -63,11 +70,11 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
     import torch
     import torch.distributed as dist
     from openmm_drudenose_amd import DrudeTGNHIntegrator, HipContext
-    from openmm_drudenose_amd.drudetgnhplugin import FLAG_MERGE_SCALE_KE, FLAG_DEFER_SCALE
+    from openmm_drudenose_amd.drudetgnhplugin import FLAG_DEFER_SCALE
     from openmm_drudenose_amd.system import shard_bounds
     it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, args.drude_steps, args.chains, True, True)
     it.setMaxDrudeDistance(args.hardwall)
-    flags = {"plain": 0, "merge": FLAG_MERGE_SCALE_KE, "defer": FLAG_DEFER_SCALE}[variant]
+    flags = {"plain": 0, "defer": FLAG_DEFER_SCALE}[variant]
     local, lgroup = system, group
     if world > 1:
         b = shard_bounds(system, world)
@@ -142,7 +149,7 @@ def validate_mailbox(args, rank, world):
         ctx.step(60)
         torch.cuda.synchronize()
         eta = torch.from_numpy(np.concatenate([ctx.thermostat_state(0), ctx.thermostat_state(1)])).to(CDEV)
-        flags = ctx.check()
+        flags = ctx.status_flags()
         if which == "mailbox":
             every = [torch.empty_like(eta) for _ in range(world)]
             dist.all_gather(every, eta)
@@ -162,9 +169,13 @@ def validate_mailbox(args, rank, world):
 
 def timed_run(ctx, steps, warmup, world, graph_steps=0):
     """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize pairs; max over ranks.
-    graph_steps > 0: the steps are replays of a hipGraph holding graph_steps steps (+ an eager remainder)."""
+    graph_steps > 0: the steps are replays of a hipGraph holding graph_steps steps (+ an eager remainder).
+    Leaves ctx.leg = what the JSON line reports for this leg, including the sum of the per-kernel times of one step
+    (instrumented repeat) and a `suspect` mark when the timed region was more than 1.3x that sum."""
     import torch
     import torch.distributed as dist
+    ctx.timing(True)               # creates the HIP-event pool now, outside the timed region
+    ctx.timing(False)
     ctx.step(warmup)
     torch.cuda.synchronize()
     replay = None
@@ -196,6 +207,7 @@ def timed_run(ctx, steps, warmup, world, graph_steps=0):
         for _ in range(steps // graph_steps):
             replay()
         ctx.step(steps % graph_steps)
+    t_enq = time.perf_counter() - t0                   # host time to enqueue the region (eager: launch-bound if close to dt)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -210,17 +222,27 @@ def timed_run(ctx, steps, warmup, world, graph_steps=0):
         dom = ctx.timing_read(0)                       # (total ms, launches) of the dominant kernel inside the timed region
     # full per-kernel table: an instrumented repeat of the same steps right after the timed region (event records
     # around all kernels cost ~20 us per step, which is why they are not inside it)
+    nrep = max(1, min(steps, 200))
     ctx.timing(True)
-    ctx.step(min(steps, 200))
+    ctx.step(nrep)
     torch.cuda.synchronize()
     ctx.timing(False)
     ctx.dominant_in_timed_region = dom
+    rows = kernel_table(ctx)
+    sum_us = sum(v["avg_us"] * v["launches"] for v in rows.values()) / nrep
+    ms = dt / steps * 1e3
+    ctx.leg = {"steps_per_s": round(steps / dt, 2), "ms_per_step": round(ms, 4),
+               "sum_kernels_us_per_step": round(sum_us, 2), "host_enqueue_ms": round(t_enq * 1e3, 3),
+               "suspect": bool(sum_us > 0 and ms * 1e3 > 1.3 * sum_us), "kernels": rows}
+    if dom and dom[1]:
+        ctx.leg["dominant_in_timed_region"] = {"avg_us": round(dom[0] / dom[1] * 1e3, 3), "launches": dom[1]}
     return dt
 
 
 def device_copy_gbps():
     """Achievable HBM bandwidth of THIS device: a 1 GiB float4-style device-to-device copy (read + write bytes / time).
-    MI355X boxes differ by ~10 % on streaming kernels; this puts the roofline fraction next to what a copy reaches."""
+    MI355X boxes differ by ~10 % on streaming kernels; this puts the roofline fraction next to what a copy reaches.
+    Runs after every timed leg (its 2 GiB go through torch's caching allocator)."""
     import torch
     n = 256 * 1024 * 1024
     a = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
@@ -250,48 +272,132 @@ def kernel_table(ctx):
     return rows
 
 
-def pmc_traffic(precision, slots):
+def csrc_sha():
+    """Hash of the kernel sources the loaded library was built from (profiles are stamped with the same hash)."""
+    from openmm_drudenose_amd import build as hip_build
+    return hip_build.source_sha()
+
+
+def pmc_traffic(precision, slots, variant):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    --pmc WRITE_SIZE in separate runs, gfx950 correction applied; profiles/r01_pmc_traffic.json).  PMC counters
-    cannot be collected from inside this process, so the figure is the profiled one for the same workload,
-    or None when the workload differs."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    --pmc WRITE_SIZE in separate runs, gfx950 correction applied; tools/profile_round.py writes
+    profiles/r02_pmc_traffic.json and stamps it with the hash of csrc/).  PMC counters cannot be collected from
+    inside this process, so the figure is the profiled one -- quoted only when it was taken from THIS binary
+    (same source hash), the same workload and the same step variant; otherwise None."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         d = json.load(open(path))
-        if d.get("slots") != slots:
-            return None
-        return d["kernels"][f"tile<{precision},rescale+kick+drift>"]["hbm_bytes_per_launch"]
+        if d.get("slots") != slots or d.get("csrc_sha") != csrc_sha() or d.get("variant") != variant:
+            return None, path
+        return d["kernels"][f"tile<{precision},rescale+kick+drift>"]["hbm_bytes_per_launch"], path
     except Exception:
-        return None
+        return None, path
 
 
 def cpu_baseline(args, system, group, ngroups):
     """The CPU oracle (the restatement of the reference's algorithm, 1 thread -- the reference platform is
-    single-threaded scalar code) on the same system, same mode, same harness force; a bounded number of steps."""
+    single-threaded scalar code) on the same system and harness force, a bounded number of steps: in dualNH mode
+    (platforms/reference's algorithm: the stated baseline, `value`) and in TGNH mode (platforms/cuda's algorithm, the
+    one the GPU headline runs)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from openmm_drudenose_amd import synth
     from oracle import Oracle, MODE_TGNH, MODE_DUALNH
-    mode = MODE_TGNH if args.mode == "TGNH" else MODE_DUALNH
-    g = group if args.mode == "TGNH" else np.zeros_like(group)
-    o = Oracle(system, g, ngroups if args.mode == "TGNH" else 1, mode, 300.0, 0.1, 1.0, 0.005, 0.001, args.drude_steps, args.chains,
-               True, True, args.hardwall)
-    pos, vel, x0 = system.positions.copy(), system.velocities.copy(), system.positions.copy()
-    f = o.harness_force(pos, x0, synth.K_DRUDE, synth.K_TETHER)
-    t0 = time.perf_counter()
-    o.run_harness(pos, vel, f, x0, synth.K_DRUDE, synth.K_TETHER, 2)
-    per = (time.perf_counter() - t0) / 2
-    n = int(max(3, min(200, args.cpu_seconds / max(per, 1e-6))))
-    t0 = time.perf_counter()
-    o.run_harness(pos, vel, f, x0, synth.K_DRUDE, synth.K_TETHER, n)
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 4), "unit": "steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} steps of the same {system.num_pairs}-pair system ({system.num_particles} slots), "
-                      f"oracle/tgnh_oracle.c {args.mode} mode, fp64, gcc -O2, harness force included",
+
+    def one(mode_name, budget):
+        mode = MODE_TGNH if mode_name == "TGNH" else MODE_DUALNH
+        g = group if mode_name == "TGNH" else np.zeros_like(group)
+        o = Oracle(system, g, ngroups if mode_name == "TGNH" else 1, mode, 300.0, 0.1, 1.0, 0.005, 0.001, args.drude_steps,
+                   args.chains, True, True, args.hardwall)
+        pos, vel, x0 = system.positions.copy(), system.velocities.copy(), system.positions.copy()
+        f = o.harness_force(pos, x0, synth.K_DRUDE, synth.K_TETHER)
+        t0 = time.perf_counter()
+        o.run_harness(pos, vel, f, x0, synth.K_DRUDE, synth.K_TETHER, 2)
+        per = (time.perf_counter() - t0) / 2
+        n = int(max(3, min(200, budget / max(per, 1e-6))))
+        t0 = time.perf_counter()
+        o.run_harness(pos, vel, f, x0, synth.K_DRUDE, synth.K_TETHER, n)
+        return n, n / (time.perf_counter() - t0)
+
+    nd, vd = one("dualNH", args.cpu_seconds / 2)
+    nt, vt = one("TGNH", args.cpu_seconds / 2)
+    return {"value": round(vd, 4), "unit": "steps/s", "cores": 1, "kind": "port",
+            "dualnh": round(vd, 4), "tgnh": round(vt, 4),
+            "sample": f"{nd} steps (dualNH = platforms/reference's algorithm, `value`) and {nt} steps (TGNH = platforms/cuda's "
+                      f"algorithm) of the same {system.num_pairs}-pair system ({system.num_particles} slots), "
+                      f"oracle/tgnh_oracle.c, fp64, gcc -O2, 1 thread, harness force included",
             "host_cpus": os.cpu_count()}
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`bench.py --gpus N` from a plain shell: start N fresh ranks (one per GPU) under torch.distributed.run, relay the
+    one JSON line of rank 0 and exit with the launcher's code.  This process never touches a GPU (and has not imported
+    torch), so the ranks are ordinary children -- nothing that has initialised HIP is re-executed."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    print("[bench] self-launch: " + " ".join(cmd), file=sys.stderr)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        print(f"[bench] the {args.gpus}-rank run failed (exit code {p.returncode}, {len(lines)} JSON lines)", file=sys.stderr)
+        raise SystemExit(p.returncode or 1)
+    print(lines[-1], flush=True)
+    raise SystemExit(0)
+
+
+def dry_launch(args, world, rank):
+    """Launcher check (CPU, gloo): the ranks meet, count themselves, rank 0 prints the count."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    dist.init_process_group("gloo")
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    met = int(t.item())
+    ok = met == args.gpus == dist.get_world_size()
+    if rank == 0:
+        print(json.dumps({"launcher_check": ok, "n_gpus": dist.get_world_size(), "ranks_met": met, "gpus_asked": args.gpus}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    raise SystemExit(0 if ok else 3)
+
+
+def step_model_bytes(num_slots, precision, variant):
+    """SURVEY 8d state-array model of one step for the pass structure actually run: plain = the reference's passes
+    (7V + 2F + 2X); defer = rescale+kick+drift (2V + F + 2X) and kick+KE without a velocity write (V + F)."""
+    V = 16 if precision == "single" else 32
+    X = 16 if precision == "single" else 32
+    F = 24
+    per = {"plain": 7 * V + 2 * F + 2 * X, "defer": 3 * V + 2 * F + 2 * X}[variant]
+    return num_slots * per
 
 
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        self_launch(args, sys.argv[1:])                # does not return
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dry_launch:
+        dry_launch(args, world, rank)
     # Exactly ONE line may reach stdout (the JSON).  Libraries print there too (RCCL writes its version banner to
     # stdout at communicator creation), so fd 1 is pointed at stderr for the whole run and the JSON goes to a
     # private duplicate of the original stdout.
@@ -300,17 +406,13 @@ def main():
     os.dup2(2, 1)
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     local_rank = int(os.environ.get("TGNH_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
     # TGNH_FORCE_DIST=1 exercises the sharded code path (process group, dof all-reduce, KE all-reduce hook) on one rank
     use_dist = world > 1 or os.environ.get("TGNH_FORCE_DIST") == "1"
+    ranks_met = 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -320,31 +422,43 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(BACKEND)
+        t = torch.ones(1, dtype=torch.int64, device=CDEV)
+        dist.all_reduce(t)                              # the ranks that actually met, counted over the collective itself
+        ranks_met = int(t.item())
+        if ranks_met != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but {ranks_met} ranks met in the process group")
 
     from openmm_drudenose_amd import synth, _lib
     system, group, ngroups = synth.water_box(args.molecules)
 
     use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
-    want_mailbox = use_dist and args.exchange != "rccl"
-    if want_mailbox and args.exchange == "auto":
-        want_mailbox = validate_mailbox(args, rank, world)
-        if rank == 0:
-            print(f"[bench] mailbox exchange validated against rccl: {want_mailbox}", file=sys.stderr)
-    while True:
+    gsteps = args.graph_steps if use_graph else 0
+
+    def run_leg(exchange):
+        """one timed run of the main configuration with the given exchange -> (ctx, seconds) ; ctx still open"""
         ctx = build_context(args, system, group, ngroups, rank, world, args.precision, args.variant)
-        if want_mailbox:
-            attach_mailbox(ctx, rank, world)
-        dt = timed_run(ctx, args.steps, args.warmup, world, args.graph_steps if use_graph else 0)
-        if ctx.exchange == "mailbox" and not all_ranks_agree((ctx.check() & 4) == 0):
-            # a wait timed out during the measurement: that number means nothing -- measure again over RCCL
-            print(f"[bench] rank {rank}: mailbox exchange timed out in the timed run; repeating with rccl", file=sys.stderr)
+        if exchange == "mailbox" and not attach_mailbox(ctx, rank, world):
             close_sharded(ctx)
-            want_mailbox = False
-            continue
-        break
+            return None, None
+        dt = timed_run(ctx, args.steps, args.warmup, world, gsteps)
+        return ctx, dt
+
+    headline_exchange = args.exchange if use_dist else None
+    mailbox_info = None
+    if headline_exchange == "mailbox":
+        ok = validate_mailbox(args, rank, world)
+        mailbox_info = {"validated_against_rccl": ok}
+        if not ok:
+            raise SystemExit("bench.py: --exchange mailbox, but the mailbox exchange did not validate against rccl on this node")
+    ctx, dt = run_leg(headline_exchange)
+    if ctx is None:
+        raise SystemExit("bench.py: the mailbox exchange could not be attached")
+    if ctx.exchange == "mailbox" and not all_ranks_agree((ctx.status_flags() & 4) == 0):
+        raise SystemExit("bench.py: the mailbox exchange timed out inside the timed run")
     graph_used = ctx.graph_used
     exchange_used = ctx.exchange
-    rows = kernel_table(ctx)
+    leg = ctx.leg
+    rows = leg["kernels"]
     assert ctx.check() == 0
     # dominant kernel: the fused rescale + half kick + drift (+ hard wall) pass
     bytes_dom = ctx.algorithmic_bytes(_lib.KID_SKD)
@@ -357,33 +471,49 @@ def main():
     local_slots = ctx.n
     close_sharded(ctx)
 
-    copy_gbps = device_copy_gbps() if rank == 0 else None
     extra = {}
+    if use_dist and world > 1 and not args.no_extra:
+        # the other exchange, same system, same steps: the mailbox exchange beside an RCCL headline (or the reverse)
+        other = "mailbox" if headline_exchange == "rccl" else "rccl"
+        info = {}
+        ok = True
+        if other == "mailbox":
+            ok = validate_mailbox(args, rank, world)
+            info["validated_against_rccl"] = ok
+        if ok:
+            c2, d2 = run_leg(other)
+            if c2 is not None:
+                timed_out = other == "mailbox" and not all_ranks_agree((c2.status_flags() & 4) == 0)
+                info.update({"steps_per_s": None if timed_out else round(args.steps / d2, 3),
+                             "ms_per_step": round(d2 / args.steps * 1e3, 5), "hipgraph": c2.graph_used,
+                             "timed_out": timed_out, "sum_kernels_us_per_step": c2.leg["sum_kernels_us_per_step"]})
+                close_sharded(c2)
+            else:
+                info["attached"] = False
+        extra[other] = info
+    if mailbox_info:
+        extra["mailbox"] = dict(extra.get("mailbox", {}), **mailbox_info)
     if world == 1 and not args.no_extra:
         for prec, var in ((args.precision, "plain"), ("single", "defer")):
             if (prec, var) == (args.precision, args.variant):
                 continue
             c2 = build_context(args, system, group, ngroups, rank, world, prec, var)
-            d2 = timed_run(c2, args.steps, args.warmup, world)
-            r2 = kernel_table(c2)
-            extra[f"{prec}/{var}"] = {"steps_per_s": round(args.steps / d2, 2), "ms_per_step": round(d2 / args.steps * 1e3, 4),
-                                     "kernels": r2}
+            timed_run(c2, args.steps, args.warmup, world)
+            extra[f"{prec}/{var}"] = c2.leg
             c2.close()
         if args.mode == "TGNH":                  # the other semantic mode (platforms/reference's algorithm), same workload
             import copy
             a2 = copy.copy(args)
             a2.mode = "dualNH"
             c2 = build_context(a2, system, group, ngroups, rank, world, args.precision, args.variant)
-            d2 = timed_run(c2, args.steps, args.warmup, world)
-            extra[f"dualNH/{args.precision}/{args.variant}"] = {"steps_per_s": round(args.steps / d2, 2),
-                                                                 "ms_per_step": round(d2 / args.steps * 1e3, 4), "kernels": kernel_table(c2)}
+            timed_run(c2, args.steps, args.warmup, world)
+            extra[f"dualNH/{args.precision}/{args.variant}"] = c2.leg
             c2.close()
+    copy_gbps = device_copy_gbps() if rank == 0 else None
 
-    out = None
     if rank == 0:
-        V = 16 if args.precision == "single" else 32
-        X = 16 if args.precision == "single" else 32
-        b_step = system.num_particles * (7 * V + 2 * 24 + 2 * X)
+        b_step = step_model_bytes(system.num_particles, args.precision, args.variant)
+        traffic, traffic_path = pmc_traffic(args.precision, local_slots, args.variant) if world == 1 else (None, None)
         out = {
             "metric": "integrator steps/sec at 1M Drude pairs",
             "value": round(args.steps / dt, 3), "unit": "steps/s",
@@ -398,16 +528,19 @@ def main():
                             f"{args.mode} mode, {args.precision} precision, numNHChains={args.chains}, hard wall "
                             f"{args.hardwall} nm, harness force call-out inside the timed region",
                 "precision": args.precision, "variant": args.variant, "hipgraph": graph_used,
-                "parallelism": f"particle-sharded x{world} (whole molecules), KE all-reduce per thermostat half step",
-                "exchange": exchange_used,
+                "parallelism": f"particle-sharded x{world} (whole molecules), one KE all-reduce per step",
+                "exchange": exchange_used, "rccl_ranks": ranks_met if use_dist else None,
                 "slots_per_gpu": local_slots,
                 "model_bytes_per_step": b_step,
                 "step_GBps_vs_model": round(b_step / (dt / args.steps) / 1e9 / world, 1),
+                "sum_kernels_us_per_step": leg["sum_kernels_us_per_step"], "suspect": leg["suspect"],
+                "csrc_sha": csrc_sha(),
             },
             "roofline": {"bound": "hbm", "kernel": "tile_kernel<scale+kick+drift>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(args.precision, local_slots) if world == 1 else None,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes, bytes per launch)",
+                         "traffic": traffic,
+                         "traffic_source": f"{os.path.relpath(traffic_path, ROOT)} (separate rocprofv3 --pmc passes, bytes per launch; "
+                                           "null unless taken from this binary, workload and variant)" if traffic_path else None,
                          "algorithmic_bytes_per_launch": bytes_dom, "avg_launch_us": dom["avg_us"],
                          "launches_timed": dom["launches"], "timing": dom["where"],
                          "device_copy_GBps": round(copy_gbps, 1),
@@ -416,10 +549,10 @@ def main():
         }
         # `value` times whole steps, the harness force call-out included (in a real context that slot is OpenMM's
         # calcForcesAndEnergy).  The integrator's own launches alone (SURVEY 8d reports the force kernel separately):
-        own = sum(v["avg_us"] for k, v in rows.items() if k != "harness force")
+        own = sum(v["avg_us"] * v["launches"] for k, v in rows.items() if k != "harness force") / max(1, rows.get("scale+kick+drift", {}).get("launches", 1))
         if own > 0:
             out["integrator_only"] = {"steps_per_s": round(1e6 / own, 1), "us_per_step": round(own, 2),
-                                      "how": "sum of the average durations of the integrator's own launches (instrumented repeat), force call-out excluded; "
+                                      "how": "sum of the durations of the integrator's own launches per step (instrumented repeat), force call-out excluded; "
                                              "derived, not a timed region",
                                       "vs_model_roofline_steps_per_s": round(HBM_PEAK_GBS * 1e9 / b_step * world, 1)}
         if extra:

@@ -56,8 +56,10 @@ enum { TGNH_PREC_SINGLE = 0,      /* float4 posq, float4 velm */
        TGNH_PREC_DOUBLE = 2 };    /* double4 posq, double4 velm */
 
 /* flags for tgnh_desc.flags */
-enum { TGNH_FLAG_MERGE_SCALE_KE = 1,   /* fuse the end-of-step rescale with the next step's KE pass */
-       TGNH_FLAG_DEFER_SCALE = 2 };    /* apply the end-of-step rescale lazily */
+enum { TGNH_FLAG_DEFER_SCALE = 2 };    /* the end-of-step rescale AND the second half kick are left pending and folded
+                                        * into the next step's first pass: between tgnh_step_end and the next
+                                        * tgnh_step_begin velm lags and the force buffer must stay as it is; tgnh_flush
+                                        * makes velm the reference's end-of-step state.  (1 is reserved.) */
 
 typedef struct tgnh_desc {
     uint32_t struct_size;         /* sizeof(tgnh_desc), ABI check */
@@ -158,12 +160,14 @@ tgnh_status tgnh_step_begin_kick(tgnh_handle h, void* stream);
 tgnh_status tgnh_step_begin_move(tgnh_handle h, void* stream);
 tgnh_status tgnh_step_end_kick(tgnh_handle h, void* stream);
 tgnh_status tgnh_step_end_thermo(tgnh_handle h, void* stream);
-/* Apply any rescale still pending (TGNH_FLAG_DEFER_SCALE) so velm is the
+/* Apply the half kick and rescale still pending (TGNH_FLAG_DEFER_SCALE) so velm is the
  * reference's end-of-step state; call before anything else reads velm. */
 tgnh_status tgnh_flush(tgnh_handle h, void* stream);
 /* A caller that captured `nsteps` steps into a hipGraph and replays it tells the handle here: the host-side
  * clock and step count advance only when the step functions are called, not when a graph is replayed. */
 tgnh_status tgnh_note_replayed_steps(tgnh_handle h, int nsteps);
+/* Restore the clock of a checkpointed run (time, stepCount: ReferenceDrudeTGNHKernels.cpp:413-414, CudaDrudeTGNHKernels.cpp:405-406). */
+tgnh_status tgnh_set_time(tgnh_handle h, double time, int64_t step_count);
 /* Velocities were changed behind the integrator's back (setVelocities, CMMotionRemover,
  * barostat): cached kinetic energies are stale.  DrudeTGNHIntegrator.cpp:166-170 */
 tgnh_status tgnh_state_changed(tgnh_handle h);
@@ -178,7 +182,12 @@ tgnh_status tgnh_get_kinetic_energy(tgnh_handle h, int ke_sum_valid, void* strea
 tgnh_status tgnh_get_num_thermostats(tgnh_handle h, int* count);               /* NT: TGNH G+2 = [groups.., COM, Drude]; DUALNH 3 = [real, unused, Drude] */
 tgnh_status tgnh_get_last_kinetic_energies(tgnh_handle h, void* stream, double* ke);   /* no 1/2; before the chain */
 tgnh_status tgnh_get_last_scale_factors(tgnh_handle h, void* stream, double* scale);
-tgnh_status tgnh_get_status_flags(tgnh_handle h, void* stream, uint32_t* flags);   /* bit0: Drude beyond 2x hard wall; bit1: harness SHAKE did not converge */
+/* bit0: a Drude beyond 2x the hard wall; bit1: the harness SHAKE did not converge; bit2: a mailbox exchange timed out.
+ * *flags is always filled in.  bit2 -- and bit0 in DUALNH mode, where the Reference platform throws
+ * (ReferenceDrudeTGNHKernels.cpp:311-312) -- are FAILURES and sticky: once the host has seen one (here, at any other
+ * tgnh_get_*, at tgnh_exchange_detach, or through the read-back the library enqueues behind every 64th step) every later
+ * tgnh_step_*, tgnh_flush and tgnh_get_* returns TGNH_ERR_STATE / TGNH_ERR_HARDWALL with the message in tgnh_last_error(). */
+tgnh_status tgnh_get_status_flags(tgnh_handle h, void* stream, uint32_t* flags);
 tgnh_status tgnh_get_time(tgnh_handle h, double* time, int64_t* step_count);
 tgnh_status tgnh_get_dof(tgnh_handle h, double* dof, double* nkt);
 

@@ -9,7 +9,7 @@ TGNH_OK = 0
 ERR_ARG, ERR_GROUP_MISMATCH, ERR_HARDWALL, ERR_UNSUPPORTED, ERR_HIP, ERR_STATE = -1, -2, -3, -4, -5, -6
 MODE_DUALNH, MODE_TGNH = 0, 1
 PREC_SINGLE, PREC_MIXED, PREC_DOUBLE = 0, 1, 2
-FLAG_MERGE_SCALE_KE, FLAG_DEFER_SCALE = 1, 2
+FLAG_DEFER_SCALE = 2
 KID_SKD, KID_KICK_KE, KID_SCALE, KID_KE, KID_CHAIN, KID_FORCE, KID_OTHER = range(7)
 KERNEL_NAMES = {KID_SKD: "scale+kick+drift", KID_KICK_KE: "kick+KE", KID_SCALE: "rescale", KID_KE: "KE",
                 KID_CHAIN: "chain", KID_FORCE: "harness force", KID_OTHER: "other"}
@@ -62,6 +62,7 @@ SIGNATURES = {
     "tgnh_flush": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_state_changed": (C.c_int, [C.c_void_p]),
     "tgnh_note_replayed_steps": (C.c_int, [C.c_void_p, C.c_int]),
+    "tgnh_set_time": (C.c_int, [C.c_void_p, C.c_double, C.c_int64]),
     "tgnh_get_kinetic_energy": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, c_f64p]),
     "tgnh_get_num_thermostats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "tgnh_get_last_kinetic_energies": (C.c_int, [C.c_void_p, C.c_void_p, c_f64p]),

@@ -13,8 +13,22 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdrudetgnh_hip.so")
 SOURCES = ["tgnh_host.cpp", "tgnh_kernels.hip", "tgnh_harness.hip"]
-HEADERS = ["tgnh_internal.h", os.path.join("..", "..", "include", "drude_tgnh.h")]
+HEADERS = ["tgnh_internal.h", "tgnh_chain_device.h", os.path.join("..", "..", "include", "drude_tgnh.h")]
 ARCH = "gfx950"
+
+
+def source_sha():
+    """sha1 over the sources the library is built from, in a fixed order: what profiles/ and bench.py stamp their
+    numbers with, so a profile is only ever quoted for the binary it was taken from."""
+    import hashlib
+    h = hashlib.sha1()
+    for name in sorted(os.listdir(CSRC)):
+        path = os.path.join(CSRC, name)
+        if os.path.isfile(path) and name.endswith((".cpp", ".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(path, "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "drude_tgnh.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _stale():

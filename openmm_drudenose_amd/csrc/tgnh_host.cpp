@@ -37,6 +37,11 @@ static tgnh_status fail(tgnh_status code, const std::string& msg) {
         if (!(h)) return fail(TGNH_ERR_ARG, "null handle");        \
     } while (0)
 
+static void note_status(tgnh_handle h, uint32_t flags);
+static tgnh_status entry(tgnh_handle h, bool need_bufs);
+static tgnh_status flush_impl(tgnh_handle h, hipStream_t s);
+static tgnh_status settle_kick(tgnh_handle h, hipStream_t s);
+
 // ---------------------------------------------------------------------------
 // A1: topology + tiles
 // ---------------------------------------------------------------------------
@@ -146,7 +151,9 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
         for (int i = 0; i < N; i++) res_starts_before[i + 1] = res_starts_before[i] + is_start[i];
     }
     int align = 1;
+#ifdef TGNH_TUNING
     if (const char* e = getenv("TGNH_TILE_ALIGN")) { align = atoi(e); if (align < 1) align = 1; }
+#endif
     c->tile_start.clear(); c->tile_res.clear();
     // residues overlapping [start, e): those starting inside, plus one that started before `start`
     auto entries_in = [&](int start, int e) {
@@ -155,7 +162,9 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
         return n;
     };
     int cap = TILE_SLOTS;
+#ifdef TGNH_TUNING
     if (const char* e = getenv("TGNH_TILE_CAP")) { int v = atoi(e); if (v >= 64 && v <= TILE_SLOTS) cap = v; }
+#endif
     int start = 0;
     while (start < N) {
         int end = std::min(start + cap, N);
@@ -331,7 +340,7 @@ static tgnh_status finalize_thermostat(tgnh_context* c) {
         HIP_OK(hipMemcpy(c->d_stage, st.data(), sizeof(double) * L.total, hipMemcpyHostToDevice));
     }
     c->chain_pending = false; c->stage_pending = false;
-    c->ke_valid = false; c->scale_pending = false; c->first_half_done = false;
+    c->scale_pending = false; c->kick_pending = false; c->first_half_done = false;
     return TGNH_OK;
 }
 
@@ -401,6 +410,8 @@ static void free_device(tgnh_context* c) {
     if (c->d_stage) (void)hipFree(c->d_stage);
     exchange_release(c);
     if (c->d_status) (void)hipFree(c->d_status);
+    if (c->h_status_seen) (void)hipHostFree(c->h_status_seen);
+    c->h_status_seen = nullptr;
     if (c->d_scalar) (void)hipFree(c->d_scalar);
     if (c->d_cl_atoms) (void)hipFree(c->d_cl_atoms);
     if (c->d_cl_dist) (void)hipFree(c->d_cl_dist);
@@ -460,8 +471,6 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
             }
         }
     }
-    if (c->num_big && (c->d.flags & TGNH_FLAG_MERGE_SCALE_KE))
-        c->d.flags &= ~TGNH_FLAG_MERGE_SCALE_KE;   // a rescale+KE launch would need the big molecules' COM twice: plain passes instead
     local_dof_terms(c);
     c->global_terms = c->local_terms;
     // constraint arrays are only needed during create
@@ -469,7 +478,9 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     c->d.constraint_i = c->d.constraint_j = nullptr;
 
     c->grid = GRID_CAP;                       // partials are sized for the largest grid
+#ifdef TGNH_TUNING       // environment knobs exist in tuning builds only (tools/build_variant.py -DTGNH_TUNING)
     if (const char* e = getenv("TGNH_GRID")) { int g = atoi(e); if (g >= 1) c->grid_override = std::min(g, GRID_CAP); }
+#endif
     if (!host_only) {
         hipDeviceProp_t prop;
         HIP_OK(hipGetDeviceProperties(&prop, d->device));
@@ -479,18 +490,17 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     {   // One-link chains run inside the rescale launch: one wavefront per work-group computes the factors while
         // the other three have their tile loads in flight, so the chain (~3.5 us) costs the launch nothing, and
         // the chain launch that remains only sums the partial rows (profiles/r01_tuning_sweep.log: +7 % steps/s
-        // at 625 k slots, +1.5 % at 5 M).  TGNH_INLINE_CHAIN=0 forces the separate chain launch.
-        // (Summing the rows in that prologue too, to drop the launch altogether, was measured slower: the rows are
-        // an L2-missing read of a dozen dependent batches, 7-9 us on the critical path against a 6 us launch.)
-        const char* e = getenv("TGNH_INLINE_CHAIN");
-        const bool want = e ? e[0] != '0' : true;
-        if (const char* e4 = getenv("TGNH_INLINE_SUM_ROWS")) c->inline_sum_rows = atoi(e4);   // tuning: 0 = never
-        // ... up to 2 M slots: beyond, the launches are bandwidth-bound, the gain shrinks to 0.7 % and the row read would
-        // only lengthen the dominant launch (its bandwidth figure is what DESIGN.md section 4 reports)
+        // at 625 k slots, +1.5 % at 5 M).
+        bool want = true;
+        // The partial rows are summed in that prologue too (no sum launch) up to 2 M slots: beyond, the launches are
+        // bandwidth-bound, the gain shrinks to 0.7 % and the row read would only lengthen the dominant launch
         c->inline_sum_all = d->num_particles < 2000000;
+#ifdef TGNH_TUNING
+        if (const char* e = getenv("TGNH_INLINE_CHAIN")) want = e[0] != '0';
+        if (const char* e4 = getenv("TGNH_INLINE_SUM_ROWS")) c->inline_sum_rows = atoi(e4);   // 0 = never
         if (const char* e5 = getenv("TGNH_INLINE_SUM_ALL")) c->inline_sum_all = e5[0] != '0';
-        const char* e3 = getenv("TGNH_ALTERNATE_SWEEPS");
-        c->alternate_sweeps = !(e3 && e3[0] == '0');
+        if (const char* e3 = getenv("TGNH_ALTERNATE_SWEEPS")) c->alternate_sweeps = e3[0] != '0';
+#endif
         // dualNH qualifies too: with useDrudeNHChains its real and Drude chains are independent (Chain1Map), without
         // them coupled through one shuffle per sub-step (chain1q_run)
         c->inline_chain = c->L.C == 1 && want;
@@ -503,6 +513,8 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         HIP_OK(hipMalloc(&c->d_stage, sizeof(double) * c->L.total));
         HIP_OK(hipMalloc(&c->d_status, sizeof(uint32_t)));
         HIP_OK(hipMemset(c->d_status, 0, sizeof(uint32_t)));
+        HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&c->h_status_seen), sizeof(uint32_t), hipHostMallocDefault));
+        *c->h_status_seen = 0;
 
         HIP_OK(hipMalloc(&c->d_scalar, sizeof(double)));
         return TGNH_OK;
@@ -527,8 +539,9 @@ extern "C" tgnh_status tgnh_bind_buffers(tgnh_handle h, void* posq, void* posq_c
     if (h->host_only) return fail(TGNH_ERR_STATE, "host-only handle (device -1): no GPU work can be launched on it");
     if (!posq || !velm || !force) return fail(TGNH_ERR_ARG, "posq, velm and force are required");
     if (h->d.precision == TGNH_PREC_MIXED && !posq_correction) return fail(TGNH_ERR_ARG, "mixed precision needs posqCorrection");
+    if (h->kick_pending && (velm != h->velm || force != h->force))
+        return fail(TGNH_ERR_STATE, "tgnh_bind_buffers: velm / force may not be rebound while a deferred half kick is pending (tgnh_flush first)");
     h->posq = posq; h->posq_corr = posq_correction; h->velm = velm; h->force = force; h->pos_delta = pos_delta;
-    h->ke_valid = false;
     return TGNH_OK;
 }
 
@@ -655,7 +668,12 @@ extern "C" tgnh_status tgnh_exchange_detach(tgnh_handle h) {
     if (!h->xchg_on) return TGNH_OK;
     HIP_OK(hipSetDevice(h->device));
     HIP_OK(hipDeviceSynchronize());
-    if (h->chain_pending && h->xwait_pending) {       // an exchange is half done (sent, not yet waited for): finish it
+    {   // a time-out that nobody has asked about yet
+        uint32_t f = 0;
+        HIP_OK(hipMemcpy(&f, h->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        note_status(h, f);
+    }
+    if (h->chain_pending && h->xwait_pending && !h->failed_code) {       // an exchange is half done (sent, not yet waited for): finish it
         tgnh_status rc = materialize_chain(h, (hipStream_t)0); if (rc) return rc;
         HIP_OK(hipDeviceSynchronize());
     }
@@ -669,6 +687,27 @@ extern "C" tgnh_status tgnh_set_allreduce(tgnh_handle h, tgnh_allreduce_fn fn, v
     CHECK_H(h);
     h->allreduce = fn; h->allreduce_user = user;
     return TGNH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device-reported failures
+// ---------------------------------------------------------------------------
+constexpr int64_t STATUS_POLL_EVERY = 64;
+
+// Called wherever the status word has reached the host.  bit 2: a mailbox exchange timed out -- from then on the
+// kinetic-energy sums are incomplete and the ranks' thermostats diverge; bit 0 in dualNH mode: the Reference platform
+// throws (Ref :311-312).  Both make every later step / query fail (entry()).  bit 1 (the harness SHAKE did not
+// converge) is reported by tgnh_get_status_flags only: OpenMM's own constraint kernels do not throw either.
+static void note_status(tgnh_handle h, uint32_t flags) {
+    if (h->failed_code) return;
+    if (flags & 4u) {
+        h->failed_code = TGNH_ERR_STATE;
+        h->failed = "mailbox exchange timed out (noticed at step " + std::to_string((long long)h->step_count) +
+                    "): a peer did not send its kinetic-energy sums; the run cannot continue";
+    } else if ((flags & 1u) && h->d.mode == TGNH_MODE_DUALNH) {
+        h->failed_code = TGNH_ERR_HARDWALL;
+        h->failed = "Drude particle moved too far beyond hard wall constraint";        // Ref :311-312
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -825,14 +864,13 @@ static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
         return TGNH_OK;
     }
     if (h->inline_chain && !h->allreduce && h->L.NT <= CHAIN_INLINE_SUM_NT &&
-        (h->ke_parts + h->num_big <= h->inline_sum_rows || h->inline_sum_all) && !(h->d.flags & TGNH_FLAG_MERGE_SCALE_KE)) {
+        (h->ke_parts + h->num_big <= h->inline_sum_rows || h->inline_sum_all)) {
         // Unsharded, one-link chains, G <= 8: nothing to launch -- the next rescale launch sums the partial rows and
         // runs the chain in its prologue (3 launches per step).  Up to 256 rows its chain wavefront reads them alone
         // (one batch of loads); more rows are read by all four wavefronts, a quarter each, ahead of their tile
         // loads (read by one wavefront they were a chain of L2 misses on the critical path, +7-9 us) -- that up to 2 M
         // slots (inline_sum_all).  +4 % steps/s at 625 k slots, +7-17 % for small systems
-        // (profiles/r01_tuning_sweep.log).  (Not with
-        // MERGE_SCALE_KE: its rescale launch writes new rows while late work-groups could still be reading the old.)
+        // (profiles/r01_tuning_sweep.log).
         h->chain_pending = true; h->sum_pending = true; h->chain_pending_twice = twice;
         return TGNH_OK;
     }
@@ -873,93 +911,123 @@ static tgnh_status materialize_chain(tgnh_handle h, hipStream_t s) {
 // make scale[] hold the first thermostat half step for the current velocities (Ref :231, Cu :336)
 static tgnh_status first_half(tgnh_handle h, hipStream_t s) {
     if (h->first_half_done) return TGNH_OK;               // DEFER_SCALE: already folded into scale[]
-    if (!h->ke_valid) { tgnh_status rc = run_tile(h, OP_KE, KID_KE, s); if (rc) return rc; }
-    h->ke_valid = false;
+    tgnh_status rc = run_tile(h, OP_KE, KID_KE, s); if (rc) return rc;
     return run_chain(h, s, false);
 }
 
+// Every entry point that launches work or hands results back starts here: a failure the device reported earlier
+// (a mailbox exchange that timed out; in dualNH mode a Drude beyond twice the hard wall, Ref :311-312) is sticky --
+// the trajectory is no longer the integrator's, so nothing more is computed on it.
+static tgnh_status entry(tgnh_handle h, bool need_bufs) {
+    if (!h) return fail(TGNH_ERR_ARG, "null handle");
+    if (need_bufs) { tgnh_status rc = need_buffers(h); if (rc) return rc; }
+    if (!h->host_only) {
+        HIP_OK(hipSetDevice(h->device));
+        if (h->h_status_seen) note_status(h, *h->h_status_seen);     // the last periodic read-back, if it has landed
+    }
+    if (h->failed_code) return fail(h->failed_code, h->failed);
+    return TGNH_OK;
+}
+
+// Every STATUS_POLL_EVERY steps the status word is copied to pinned host memory behind the step (no synchronisation;
+// looked at on a later entry): a caller that never asks for anything still learns of a failure within that many steps.
+static tgnh_status poll_status_async(tgnh_handle h, hipStream_t s) {
+    if (!h->h_status_seen || h->step_count % STATUS_POLL_EVERY != 0) return TGNH_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return TGNH_OK;
+    HIP_OK(hipMemcpyAsync(h->h_status_seen, h->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    return TGNH_OK;
+}
+
 extern "C" tgnh_status tgnh_step_begin(tgnh_handle h, void* stream) {
-    CHECK_H(h);
-    tgnh_status rc = need_buffers(h); if (rc) return rc;
-    HIP_OK(hipSetDevice(h->device));
+    tgnh_status rc = entry(h, true); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     rc = first_half(h, s); if (rc) return rc;
-    rc = run_tile(h, OP_SCALE | OP_KICK | OP_DRIFT, KID_SKD, s); if (rc) return rc;   // Cu :351-376 fused
-    h->scale_pending = false; h->first_half_done = false; h->ke_valid = false;
+    // Cu :351-376 fused; with a half kick still pending from the last step_end (DEFER_SCALE) that kick comes first
+    rc = run_tile(h, (h->kick_pending ? OP_PREKICK : 0) | OP_SCALE | OP_KICK | OP_DRIFT, KID_SKD, s); if (rc) return rc;
+    h->scale_pending = false; h->kick_pending = false; h->first_half_done = false;
     return TGNH_OK;
 }
 
 static tgnh_status second_half(tgnh_handle h, hipStream_t s, int kick_ops) {
-    tgnh_status rc = run_tile(h, kick_ops | OP_KE, kick_ops ? KID_KICK_KE : KID_KE, s); if (rc) return rc;   // Cu :384-388 + :474-488
-    const int flags = h->d.flags;
-    if (flags & TGNH_FLAG_DEFER_SCALE) {
+    tgnh_status rc;
+    const bool defer = (h->d.flags & TGNH_FLAG_DEFER_SCALE) != 0;
+    if (h->scale_pending || h->kick_pending) { rc = flush_impl(h, s); if (rc) return rc; }   // two end halves in a row
+    // DEFER_SCALE, fused path: the kicked velocities only feed the sums (Cu :384-388 + :474-488); the next step's first
+    // launch -- or tgnh_flush -- forms them again from the same force buffer and goes on from there
+    const int nostore = (defer && kick_ops) ? OP_NOSTORE : 0;
+    rc = run_tile(h, kick_ops | OP_KE | nostore, kick_ops ? KID_KICK_KE : KID_KE, s); if (rc) return rc;
+    if (defer) {
         rc = run_chain(h, s, true); if (rc) return rc;
-        h->scale_pending = true; h->first_half_done = true;
-    } else if (flags & TGNH_FLAG_MERGE_SCALE_KE) {
-        rc = run_chain(h, s, false); if (rc) return rc;
-        rc = run_tile(h, OP_SCALE | OP_KE, KID_SCALE, s); if (rc) return rc;       // Cu :402 + next step's :474-488
-        h->ke_valid = true;
+        h->scale_pending = true; h->first_half_done = true; h->kick_pending = nostore != 0;
     } else {
         rc = run_chain(h, s, false); if (rc) return rc;                            // Cu :394-395
         rc = run_tile(h, OP_SCALE, KID_SCALE, s); if (rc) return rc;               // Cu :402
     }
     h->time += h->d.step_size;                                                     // Cu :405-406 ; Ref :413-414
     h->step_count += 1;
-    return TGNH_OK;
+    return poll_status_async(h, s);
 }
 
 extern "C" tgnh_status tgnh_step_end(tgnh_handle h, void* stream) {
-    CHECK_H(h);
-    tgnh_status rc = need_buffers(h); if (rc) return rc;
-    HIP_OK(hipSetDevice(h->device));
+    tgnh_status rc = entry(h, true); if (rc) return rc;
     return second_half(h, (hipStream_t)stream, OP_KICK);
 }
 
+// The split entry points work on stored velocities: a deferred half kick is materialised first.
+static tgnh_status settle_kick(tgnh_handle h, hipStream_t s) {
+    return h->kick_pending ? flush_impl(h, s) : TGNH_OK;
+}
+
 extern "C" tgnh_status tgnh_step_begin_kick(tgnh_handle h, void* stream) {
-    CHECK_H(h);
-    tgnh_status rc = need_buffers(h); if (rc) return rc;
-    HIP_OK(hipSetDevice(h->device));
+    tgnh_status rc = entry(h, true); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    rc = settle_kick(h, s); if (rc) return rc;
     rc = first_half(h, s); if (rc) return rc;
     rc = run_tile(h, OP_SCALE | OP_KICK | OP_POSDELTA, KID_OTHER, s); if (rc) return rc;   // Cu :351-360
-    h->scale_pending = false; h->first_half_done = false; h->ke_valid = false;
+    h->scale_pending = false; h->first_half_done = false;
     return TGNH_OK;
 }
 extern "C" tgnh_status tgnh_step_begin_move(tgnh_handle h, void* stream) {
-    CHECK_H(h);
-    tgnh_status rc = need_buffers(h); if (rc) return rc;
-    HIP_OK(hipSetDevice(h->device));
+    tgnh_status rc = entry(h, true); if (rc) return rc;
+    rc = settle_kick(h, (hipStream_t)stream); if (rc) return rc;
     return run_tile(h, OP_MOVE, KID_OTHER, (hipStream_t)stream);                   // Cu :366-376
 }
 extern "C" tgnh_status tgnh_step_end_kick(tgnh_handle h, void* stream) {
-    CHECK_H(h);
-    tgnh_status rc = need_buffers(h); if (rc) return rc;
-    HIP_OK(hipSetDevice(h->device));
+    tgnh_status rc = entry(h, true); if (rc) return rc;
+    rc = settle_kick(h, (hipStream_t)stream); if (rc) return rc;
     return run_tile(h, OP_KICK, KID_OTHER, (hipStream_t)stream);                   // Cu :384-388
 }
 extern "C" tgnh_status tgnh_step_end_thermo(tgnh_handle h, void* stream) {
-    CHECK_H(h);
-    tgnh_status rc = need_buffers(h); if (rc) return rc;
-    HIP_OK(hipSetDevice(h->device));
+    tgnh_status rc = entry(h, true); if (rc) return rc;
     return second_half(h, (hipStream_t)stream, 0);                                 // Cu :394-406
 }
 extern "C" tgnh_status tgnh_half_kick(tgnh_handle h, void* stream) { return tgnh_step_end_kick(h, stream); }
 
-extern "C" tgnh_status tgnh_flush(tgnh_handle h, void* stream) {
-    CHECK_H(h);
-    if (!h->scale_pending) return TGNH_OK;
-    tgnh_status rc = need_buffers(h); if (rc) return rc;
-    HIP_OK(hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
-    rc = materialize_chain(h, s); if (rc) return rc;
-    rc = run_tile(h, OP_SCALE, KID_SCALE, s, h->d_state + h->L.off_scale_a); if (rc) return rc;
-    HIP_OK(hipMemcpyAsync(h->d_state + h->L.off_scale, h->d_state + h->L.off_scale_b, sizeof(double) * h->L.NT,
-                          hipMemcpyDeviceToDevice, s));
+// velm <- the reference's end-of-step velocities: the pending half kick (same force buffer), then the end-of-step
+// factors; scale[] keeps only the pre-run first half of the coming step
+static tgnh_status flush_impl(tgnh_handle h, hipStream_t s) {
+    if (!h->scale_pending && !h->kick_pending) return TGNH_OK;
+    tgnh_status rc = materialize_chain(h, s); if (rc) return rc;
+    if (h->scale_pending) {
+        rc = run_tile(h, (h->kick_pending ? OP_PREKICK : 0) | OP_SCALE, KID_SCALE, s, h->d_state + h->L.off_scale_a); if (rc) return rc;
+        HIP_OK(hipMemcpyAsync(h->d_state + h->L.off_scale, h->d_state + h->L.off_scale_b, sizeof(double) * h->L.NT,
+                              hipMemcpyDeviceToDevice, s));
+    } else {
+        rc = run_tile(h, OP_KICK, KID_OTHER, s); if (rc) return rc;
+    }
     if (h->num_big && h->d.mode == TGNH_MODE_TGNH && h->d.use_com_temp_group) {
         rc = run_big_com(h, false, s); if (rc) return rc;             // the velocities just changed: refresh the COM table
     }
-    h->scale_pending = false;      // first_half_done stays: scale[] now holds only the pre-run half step
+    h->scale_pending = false; h->kick_pending = false;   // first_half_done stays
     return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_flush(tgnh_handle h, void* stream) {
+    CHECK_H(h);
+    if (!h->scale_pending && !h->kick_pending) return TGNH_OK;
+    tgnh_status rc = entry(h, true); if (rc) return rc;
+    return flush_impl(h, (hipStream_t)stream);
 }
 
 extern "C" tgnh_status tgnh_note_replayed_steps(tgnh_handle h, int nsteps) {
@@ -970,11 +1038,19 @@ extern "C" tgnh_status tgnh_note_replayed_steps(tgnh_handle h, int nsteps) {
     return TGNH_OK;
 }
 
+// Restores the clock of a checkpointed run (the reference keeps time / stepCount in the platform data, Ref :413-414,
+// Cu :405-406, and OpenMM's checkpoints carry them).
+extern "C" tgnh_status tgnh_set_time(tgnh_handle h, double time, int64_t step_count) {
+    CHECK_H(h);
+    if (step_count < 0) return fail(TGNH_ERR_ARG, "negative step count");
+    h->time = time;
+    h->step_count = step_count;
+    return TGNH_OK;
+}
+
 extern "C" tgnh_status tgnh_state_changed(tgnh_handle h) {
     CHECK_H(h);
-    tgnh_status rc = deferred_guard(h, "tgnh_state_changed"); if (rc) return rc;
-    h->ke_valid = false;
-    return TGNH_OK;
+    return deferred_guard(h, "tgnh_state_changed");       // kinetic energies are recomputed at every step anyway
 }
 
 // ---------------------------------------------------------------------------
@@ -982,10 +1058,13 @@ extern "C" tgnh_status tgnh_state_changed(tgnh_handle h) {
 // ---------------------------------------------------------------------------
 static tgnh_status read_state(tgnh_handle h, int off, int n, hipStream_t s, double* out) {
     if (h->host_only) { std::copy(h->h_state.begin() + off, h->h_state.begin() + off + n, out); return TGNH_OK; }
-    HIP_OK(hipSetDevice(h->device));
+    { tgnh_status rc = entry(h, false); if (rc) return rc; }
     { tgnh_status rc = materialize_chain(h, s); if (rc) return rc; }
     HIP_OK(hipMemcpyAsync(out, h->d_state + off, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(h->h_status_seen, h->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
+    note_status(h, *h->h_status_seen);       // what was just read may come from a failed exchange: say so now
+    if (h->failed_code) return fail(h->failed_code, h->failed);
     return TGNH_OK;
 }
 
@@ -995,9 +1074,8 @@ extern "C" tgnh_status tgnh_get_kinetic_energy(tgnh_handle h, int ke_sum_valid, 
     hipStream_t s = (hipStream_t)stream;
     if (h->d.mode == TGNH_MODE_TGNH && ke_sum_valid)                               // Cu :654-658
         return read_state(h, h->L.off_kesum, 1, s, out);
-    tgnh_status rc = need_buffers(h); if (rc) return rc;
-    rc = tgnh_flush(h, stream); if (rc) return rc;
-    HIP_OK(hipSetDevice(h->device));
+    tgnh_status rc = entry(h, true); if (rc) return rc;
+    rc = flush_impl(h, s); if (rc) return rc;
     const double ts = h->d.mode == TGNH_MODE_DUALNH ? 0.5 * h->d.step_size : 0.0; // Ref :587 ; Cu :656
     HIP_OK(launch_plain_ke(h->d.precision, h->velm, reinterpret_cast<const long long*>(h->force), h->d.num_particles,
                            h->d.padded_num_particles, ts, h->d_scalar, s));
@@ -1021,12 +1099,14 @@ extern "C" tgnh_status tgnh_get_last_scale_factors(tgnh_handle h, void* stream, 
 }
 extern "C" tgnh_status tgnh_get_status_flags(tgnh_handle h, void* stream, uint32_t* flags) {
     CHECK_H(h);
+    if (!flags) return fail(TGNH_ERR_ARG, "null flags");
     if (h->host_only) { *flags = 0; return TGNH_OK; }
     HIP_OK(hipSetDevice(h->device));
-    HIP_OK(hipMemcpyAsync(flags, h->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_OK(hipMemcpyAsync(h->h_status_seen, h->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));
-    if ((*flags & 1u) && h->d.mode == TGNH_MODE_DUALNH)                            // Ref :311-312
-        return fail(TGNH_ERR_HARDWALL, "Drude particle moved too far beyond hard wall constraint");
+    *flags = *h->h_status_seen;              // always handed back, also beside an error code
+    note_status(h, *flags);
+    if (h->failed_code) return fail(h->failed_code, h->failed);
     return TGNH_OK;
 }
 extern "C" tgnh_status tgnh_get_time(tgnh_handle h, double* time, int64_t* step_count) {
@@ -1071,7 +1151,10 @@ extern "C" tgnh_status tgnh_set_thermostat_state(tgnh_handle h, int which, void*
     if (h->host_only) { std::copy(in, in + len, h->h_state.begin() + off); return TGNH_OK; }
     HIP_OK(hipSetDevice(h->device));
     rc = materialize_chain(h, (hipStream_t)stream); if (rc) return rc;
+    // both copies: the in-kernel chain rewrites only the fields it advances in the staging block, and the next commit
+    // copies that block over d_state whole -- a field set here alone (etaMass, an unused etaDot slot) would revert
     HIP_OK(hipMemcpyAsync(h->d_state + off, in, sizeof(double) * len, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_OK(hipMemcpyAsync(h->d_stage + off, in, sizeof(double) * len, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));
     return TGNH_OK;
 }
@@ -1107,10 +1190,9 @@ extern "C" tgnh_status tgnh_get_topology(tgnh_handle h, int which, int32_t* out)
 }
 
 extern "C" tgnh_status tgnh_compute_kinetic_energies(tgnh_handle h, void* stream) {
-    CHECK_H(h);
-    tgnh_status rc = need_buffers(h); if (rc) return rc;
-    HIP_OK(hipSetDevice(h->device));
+    tgnh_status rc = entry(h, true); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    rc = settle_kick(h, s); if (rc) return rc;
     rc = materialize_chain(h, s); if (rc) return rc;      // ke_red is about to be overwritten
     rc = run_tile(h, OP_KE, KID_KE, s); if (rc) return rc;
     ChainArgs a = chain_args(h);
@@ -1129,10 +1211,8 @@ extern "C" tgnh_status tgnh_compute_kinetic_energies(tgnh_handle h, void* stream
 // ---------------------------------------------------------------------------
 extern "C" tgnh_status tgnh_harness_force(tgnh_handle h, const void* x0, double k_drude, double k_tether,
                                           void* force_out, void* stream) {
-    CHECK_H(h);
-    tgnh_status rc = need_buffers(h); if (rc) return rc;
+    tgnh_status rc = entry(h, true); if (rc) return rc;
     if (!x0 || !force_out) return fail(TGNH_ERR_ARG, "null x0 / force_out");
-    HIP_OK(hipSetDevice(h->device));
     ForceArgs a{};
     a.posq = h->posq; a.posq_corr = h->posq_corr; a.x0 = x0; a.meta = h->d_meta;
     a.force = reinterpret_cast<long long*>(force_out);
@@ -1173,7 +1253,16 @@ extern "C" tgnh_status tgnh_timing_enable(tgnh_handle h, int on) {
     if (h->host_only) return fail(TGNH_ERR_STATE, "host-only handle");
     HIP_OK(hipSetDevice(h->device));
     if (!on) drain_events(h);
-    else { for (int k = 0; k < KID_COUNT; k++) { h->t_total[k] = 0; h->t_count[k] = 0; } h->ev_used = 0; }
+    else {
+        for (int k = 0; k < KID_COUNT; k++) { h->t_total[k] = 0; h->t_count[k] = 0; }
+        h->ev_used = 0;
+        while (h->ev_pool.size() < 2048) {        // created here, not lazily inside somebody's timed region
+            tgnh_context::Ev e; e.kid = 0;
+            if (hipEventCreate(&e.a) != hipSuccess) break;
+            if (hipEventCreate(&e.b) != hipSuccess) { (void)hipEventDestroy(e.a); break; }
+            h->ev_pool.push_back(e);
+        }
+    }
     h->timing = on != 0;
     h->timing_only = on >= 2 ? on - 2 : -1;   // on = 2 + kernel id: time that kernel only (2 events per step, not 8)
     return TGNH_OK;
@@ -1196,7 +1285,7 @@ extern "C" tgnh_status tgnh_algorithmic_bytes(tgnh_handle h, int kernel, double*
     double b = 0;
     switch (kernel) {
         case KID_SKD: b = N * (2 * V + F + 2 * X); break;       // scale+kick+drift: V r/w, F r, X r/w
-        case KID_KICK_KE: b = N * (2 * V + F); break;           // kick+KE: V r/w, F r
+        case KID_KICK_KE: b = N * ((h->d.flags & TGNH_FLAG_DEFER_SCALE ? 1 : 2) * V + F); break;   // kick+KE: V r(/w), F r; DEFER_SCALE leaves the kicked velocities unstored
         case KID_SCALE: b = N * (2 * V); break;                 // rescale (+KE): V r/w
         case KID_KE: b = N * V; break;                          // KE: V r
         case KID_FORCE: b = N * (X + F); break;                 // harness: X r, F w (x0 excluded)

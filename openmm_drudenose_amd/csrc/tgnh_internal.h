@@ -20,9 +20,6 @@ namespace tgnh {
 #ifndef TGNH_SPT
 #define TGNH_SPT 2
 #endif
-#ifndef TGNH_PREFETCH
-#define TGNH_PREFETCH 0   // software prefetch of the next tile: measured slower on MI355X (profiles/r01_tuning.md)
-#endif
 #ifndef TGNH_TBLOCK
 #define TGNH_TBLOCK 256
 #endif
@@ -51,7 +48,9 @@ enum : int {
     OP_DRIFT = 4,      // A8  x += dt v (no constraints)
     OP_KE = 8,         // A3/A4 kinetic-energy partial sums
     OP_POSDELTA = 16,  // write posDelta = dt v         (constrained path)
-    OP_MOVE = 32       // x += posDelta, v = posDelta/dt (K integrateDrudeTGNHPositions)
+    OP_MOVE = 32,      // x += posDelta, v = posDelta/dt (K integrateDrudeTGNHPositions)
+    OP_PREKICK = 64,   // first apply the half kick the previous step's kick+KE launch left unstored (DEFER_SCALE)
+    OP_NOSTORE = 128   // kick+KE: the kicked velocities feed the sums only; the next launch redoes the kick (OP_PREKICK)
 };
 
 // kernel ids for timing / algorithmic bytes (include/drude_tgnh.h)
@@ -246,6 +245,9 @@ struct tgnh_context {
     bool chain_pending = false, chain_pending_twice = false;   // summed KE waits for the next rescale launch to run the chain
     bool inline_chain = false;        // numNHChains == 1: the chain runs inside the rescale launch
     uint32_t* d_status = nullptr;
+    uint32_t* h_status_seen = nullptr;   // pinned: where read-backs of the status word land (periodic, and at every query)
+    int failed_code = 0;                 // sticky: a failure the device reported (note_status); every later entry returns it
+    std::string failed;
     double* d_scalar = nullptr;       // plain KE result
     // harness call-outs (tgnh_harness.hip)
     int4* d_cl_atoms = nullptr; double* d_cl_dist = nullptr; int num_clusters = 0;
@@ -257,8 +259,8 @@ struct tgnh_context {
     void *posq = nullptr, *posq_corr = nullptr, *velm = nullptr, *pos_delta = nullptr;
     const void* force = nullptr;
     // run state
-    bool ke_valid = false;            // ke_red/scale hold the thermostat half-step for the current velocities
     bool scale_pending = false;       // DEFER_SCALE: velm lags by scale[]
+    bool kick_pending = false;        // DEFER_SCALE: velm also lags by the second half kick (force buffer unchanged since)
     bool first_half_done = false;     // DEFER_SCALE: chain for the coming step's first half already run
     double time = 0;
     int64_t step_count = 0;

@@ -45,32 +45,6 @@ __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
 __device__ __forceinline__ float abs_(float x) { return fabsf(x); }
 __device__ __forceinline__ double abs_(double x) { return fabs(x); }
 
-// Streaming accesses, optionally non-temporal (TGNH_NT bit 0: loads, bit 1: stores) -- a tuning knob, see
-// profiles/r01_tuning_sweep.log for what it measured.
-#ifndef TGNH_NT
-#define TGNH_NT 0
-#endif
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-typedef double v4d_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld_s(const float4* p) {
-    if (TGNH_NT & 1) { const v4f_t t = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(p)); return make_float4(t.x, t.y, t.z, t.w); }
-    return *p;
-}
-__device__ __forceinline__ double4 ld_s(const double4* p) {
-    if (TGNH_NT & 1) { const v4d_t t = __builtin_nontemporal_load(reinterpret_cast<const v4d_t*>(p)); return make_double4(t.x, t.y, t.z, t.w); }
-    return *p;
-}
-__device__ __forceinline__ long long ld_s(const long long* p) { return (TGNH_NT & 1) ? __builtin_nontemporal_load(p) : *p; }
-__device__ __forceinline__ uint32_t ld_s(const uint32_t* p) { return (TGNH_NT & 1) ? __builtin_nontemporal_load(p) : *p; }
-__device__ __forceinline__ void st_s(float4* p, const float4 v) {
-    if (TGNH_NT & 2) { v4f_t t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<v4f_t*>(p)); }
-    else *p = v;
-}
-__device__ __forceinline__ void st_s(double4* p, const double4 v) {
-    if (TGNH_NT & 2) { v4d_t t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<v4d_t*>(p)); }
-    else *p = v;
-}
-
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -120,9 +94,12 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
     typedef typename Prec<PREC>::mixed4 mixed4;
     constexpr bool DO_SCALE = OPS & OP_SCALE, DO_KICK = OPS & OP_KICK, DO_DRIFT = OPS & OP_DRIFT;
     constexpr bool DO_KE = OPS & OP_KE, DO_PD = OPS & OP_POSDELTA, DO_MOVE = OPS & OP_MOVE;
+    // OP_PREKICK: the half kick a kick+KE launch of the previous step formed for its sums but did not store
+    // (OP_NOSTORE) is applied first -- same force buffer, same expression, same bits (DESIGN.md "deferred kick")
+    constexpr bool DO_PREKICK = OPS & OP_PREKICK, NOSTORE = OPS & OP_NOSTORE;
+    constexpr bool NEED_F = DO_KICK || DO_PREKICK;
     constexpr bool POS = DO_DRIFT || DO_MOVE;            // positions are read and written
-    constexpr bool VEL_W = DO_SCALE || DO_KICK || DO_MOVE;   // velocities are written
-    constexpr bool PREFETCH = TGNH_PREFETCH != 0;
+    constexpr bool VEL_W = (DO_SCALE || DO_KICK || DO_MOVE) && !NOSTORE;   // velocities are written
 
     __shared__ double s_scale[MAX_GROUPS + 2];           // velocity scale factors of this launch (80 B: keeps smem 16-B aligned)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -168,9 +145,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
     const mixed dt = (mixed)a.dt;
     const mixed fscale = (mixed)(0.5 * a.dt / 4294967296.0);     // Cu :295
 
-    // Raw register image of one tile's global loads.  The loads of tile t+gridDim are issued before tile t is
-    // processed (software prefetch): a work-group is then never without HBM requests in flight while it
-    // sits in its LDS phases and barriers.
+    // Raw register image of one tile's global loads.
     struct TileIn {
         int ts, te, rs, nres;
         mixed4 v[SPT];
@@ -190,16 +165,16 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
         for (int k = 0; k < SPT; k++) {
             const int idx = in.ts + k * TBLOCK + tid;
             if (idx < in.te) {
-                in.v[k] = ld_s(&velm[idx]);
-                in.meta[k] = ld_s(&a.meta[idx]);
-                if (DO_KICK) {
-                    in.fx[k] = ld_s(&a.force[idx]);
-                    in.fy[k] = ld_s(&a.force[idx + a.padded]);
-                    in.fz[k] = ld_s(&a.force[idx + 2 * a.padded]);
+                in.v[k] = velm[idx];
+                in.meta[k] = a.meta[idx];
+                if (NEED_F) {
+                    in.fx[k] = a.force[idx];
+                    in.fy[k] = a.force[idx + a.padded];
+                    in.fz[k] = a.force[idx + 2 * a.padded];
                 }
                 if (POS) {
-                    in.p[k] = ld_s(&posq[idx]);
-                    if (PREC == TGNH_PREC_MIXED) in.c[k] = ld_s(&pcorr[idx]);       // K :443-445
+                    in.p[k] = posq[idx];
+                    if (PREC == TGNH_PREC_MIXED) in.c[k] = pcorr[idx];       // K :443-445
                 }
                 if (DO_MOVE) in.pd[k] = pdelta[idx];
             } else {
@@ -209,7 +184,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
         }
     };
 
-    TileIn cur, nxt;
+    TileIn cur;
     TRACE(0);
     if (a.commit_len > 0 && blockIdx.x == 0) {            // take over the thermostat block an in-kernel chain staged
         for (int i = tid; i < a.commit_len; i += TBLOCK)
@@ -322,7 +297,6 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
     TRACE(2);
     for (int t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
         const bool more = t + (int)gridDim.x < a.num_tiles;
-        if (PREFETCH && more) load_tile(t + gridDim.x, nxt);
         const int ts = cur.ts, te = cur.te;
         const int rs = cur.rs, nres = cur.nres;
         TRACE_WAIT(); TRACE(3 + 4 * trace_tile);
@@ -339,7 +313,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
             ok[k] = ts + k * TBLOCK + tid < te;
             v[k] = cur.v[k];
             meta[k] = cur.meta[k];
-            if (DO_KICK) { fx[k] = cur.fx[k]; fy[k] = cur.fy[k]; fz[k] = cur.fz[k]; }
+            if (NEED_F) { fx[k] = cur.fx[k]; fy[k] = cur.fy[k]; fz[k] = cur.fz[k]; }
             if (POS) {
                 px[k] = cur.p[k].x; py[k] = cur.p[k].y; pz[k] = cur.p[k].z; pq[k] = cur.p[k].w;
                 if (PREC == TGNH_PREC_MIXED) { px[k] += (mixed)cur.c[k].x; py[k] += (mixed)cur.c[k].y; pz[k] += (mixed)cur.c[k].z; }
@@ -352,6 +326,17 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
         mixed mass[SPT];
 #pragma unroll
         for (int k = 0; k < SPT; k++) mass[k] = v[k].w != 0 ? rcp_(v[k].w) : (mixed)0;
+        if (DO_PREKICK) {                                            // the pending half kick (A7), as below
+#pragma unroll
+            for (int k = 0; k < SPT; k++) {
+                if (v[k].w != 0) {
+                    const mixed c = fscale * v[k].w;
+                    v[k].x += c * (mixed)fx[k];
+                    v[k].y += c * (mixed)fy[k];
+                    v[k].z += c * (mixed)fz[k];
+                }
+            }
+        }
         auto img = [&](int k) { return mk4(v[k].x, v[k].y, v[k].z, mass[k]); };
 
         bool lds_read = false;   // some lane may still be reading sv/scom of this tile
@@ -496,38 +481,28 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                         mixed deltaT = dt;
                         mixed dotvr1 = vel1.x * bx + vel1.y * by + vel1.z * bz;
                         const mixed vp1x = vel1.x - bx * dotvr1, vp1y = vel1.y - by * dotvr1, vp1z = vel1.z - bz * dotvr1;
-                        if (mass2 == 0) {                             // K :504-526 massless parent
-                            if (dotvr1 != 0) deltaT = deltaR / abs_(dotvr1);
-                            if (deltaT > dt) deltaT = dt;
-                            dotvr1 = -dotvr1 * hws / (abs_(dotvr1) * sqrt_(mass1));
-                            const mixed dr = -deltaR + deltaT * dotvr1;
-                            if (is_d) {
-                                px[k] += bx * dr; py[k] += by * dr; pz[k] += bz * dr;
-                                v[k].x = vp1x + bx * dotvr1; v[k].y = vp1y + by * dotvr1; v[k].z = vp1z + bz * dotvr1;
-                            }
-                        } else {                                      // K :527-571
-                            const mixed invTot = rcp_(mass1 + mass2);
-                            mixed dotvr2 = vel2.x * bx + vel2.y * by + vel2.z * bz;
-                            const mixed vp2x = vel2.x - bx * dotvr2, vp2y = vel2.y - by * dotvr2, vp2z = vel2.z - bz * dotvr2;
-                            const mixed vbCMass = (mass1 * dotvr1 + mass2 * dotvr2) * invTot;
-                            dotvr1 -= vbCMass;
-                            dotvr2 -= vbCMass;
-                            if (dotvr1 != dotvr2) deltaT = deltaR / abs_(dotvr1 - dotvr2);
-                            if (deltaT > dt) deltaT = dt;
-                            const mixed vBond = hws / sqrt_(mass1);
-                            dotvr1 = -dotvr1 * vBond * mass2 * invTot / abs_(dotvr1);
-                            dotvr2 = -dotvr2 * vBond * mass1 * invTot / abs_(dotvr2);
-                            const mixed dr1 = -deltaR * mass2 * invTot + deltaT * dotvr1;
-                            const mixed dr2 = deltaR * mass1 * invTot + deltaT * dotvr2;
-                            dotvr1 += vbCMass;
-                            dotvr2 += vbCMass;
-                            if (is_d) {
-                                px[k] += bx * dr1; py[k] += by * dr1; pz[k] += bz * dr1;
-                                v[k].x = vp1x + bx * dotvr1; v[k].y = vp1y + by * dotvr1; v[k].z = vp1z + bz * dotvr1;
-                            } else {
-                                px[k] += bx * dr2; py[k] += by * dr2; pz[k] += bz * dr2;
-                                v[k].x = vp2x + bx * dotvr2; v[k].y = vp2y + by * dotvr2; v[k].z = vp2z + bz * dotvr2;
-                            }
+                        // K :527-571 (a massless parent, K :504-526, cannot occur: tgnh_create rejects massless pair members)
+                        const mixed invTot = rcp_(mass1 + mass2);
+                        mixed dotvr2 = vel2.x * bx + vel2.y * by + vel2.z * bz;
+                        const mixed vp2x = vel2.x - bx * dotvr2, vp2y = vel2.y - by * dotvr2, vp2z = vel2.z - bz * dotvr2;
+                        const mixed vbCMass = (mass1 * dotvr1 + mass2 * dotvr2) * invTot;
+                        dotvr1 -= vbCMass;
+                        dotvr2 -= vbCMass;
+                        if (dotvr1 != dotvr2) deltaT = deltaR / abs_(dotvr1 - dotvr2);
+                        if (deltaT > dt) deltaT = dt;
+                        const mixed vBond = hws / sqrt_(mass1);
+                        dotvr1 = -dotvr1 * vBond * mass2 * invTot / abs_(dotvr1);
+                        dotvr2 = -dotvr2 * vBond * mass1 * invTot / abs_(dotvr2);
+                        const mixed dr1 = -deltaR * mass2 * invTot + deltaT * dotvr1;
+                        const mixed dr2 = deltaR * mass1 * invTot + deltaT * dotvr2;
+                        dotvr1 += vbCMass;
+                        dotvr2 += vbCMass;
+                        if (is_d) {
+                            px[k] += bx * dr1; py[k] += by * dr1; pz[k] += bz * dr1;
+                            v[k].x = vp1x + bx * dotvr1; v[k].y = vp1y + by * dotvr1; v[k].z = vp1z + bz * dotvr1;
+                        } else {
+                            px[k] += bx * dr2; py[k] += by * dr2; pz[k] += bz * dr2;
+                            v[k].x = vp2x + bx * dotvr2; v[k].y = vp2y + by * dotvr2; v[k].z = vp2z + bz * dotvr2;
                         }
                     }
                 }
@@ -541,14 +516,14 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
         for (int k = 0; k < SPT; k++) {
             const int idx = ts + k * TBLOCK + tid;
             if (ok[k]) {
-                if (VEL_W || (POS && hardwall)) st_s(&velm[idx], v[k]);
+                if (VEL_W || (POS && hardwall)) velm[idx] = v[k];
                 if (POS) {
                     if (PREC == TGNH_PREC_MIXED) {                   // K :457-458
                         const float hx = (float)px[k], hy = (float)py[k], hz = (float)pz[k];
-                        st_s(&posq[idx], mk4((real)hx, (real)hy, (real)hz, pq[k]));
-                        st_s(&pcorr[idx], make_float4((float)(px[k] - hx), (float)(py[k] - hy), (float)(pz[k] - hz), 0.0f));
+                        posq[idx] = mk4((real)hx, (real)hy, (real)hz, pq[k]);
+                        pcorr[idx] = make_float4((float)(px[k] - hx), (float)(py[k] - hy), (float)(pz[k] - hz), 0.0f);
                     } else {
-                        st_s(&posq[idx], mk4((real)px[k], (real)py[k], (real)pz[k], pq[k]));
+                        posq[idx] = mk4((real)px[k], (real)py[k], (real)pz[k], pq[k]);
                     }
                 }
             }
@@ -628,7 +603,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
 #ifdef TGNH_TRACE
         trace_tile++;
 #endif
-        if (more) { if (PREFETCH) cur = nxt; else load_tile(t + gridDim.x, cur); }
+        if (more) load_tile(t + gridDim.x, cur);
     }
 
     // ---- work-group reduction of the fp64 KE bins: 64-lane butterflies, then one LDS hop ----
@@ -971,9 +946,11 @@ static tile_fn_t tile_fn_ops(int ops, int gb) {
     switch (ops) {
         case OP_KE: return tile_fn_gb<PREC, OP_KE>(gb);
         case OP_SCALE: return tile_fn_gb<PREC, OP_SCALE>(gb);
-        case OP_SCALE | OP_KE: return tile_fn_gb<PREC, OP_SCALE | OP_KE>(gb);
         case OP_SCALE | OP_KICK | OP_DRIFT: return tile_fn_gb<PREC, OP_SCALE | OP_KICK | OP_DRIFT>(gb);
         case OP_KICK | OP_KE: return tile_fn_gb<PREC, OP_KICK | OP_KE>(gb);
+        case OP_KICK | OP_KE | OP_NOSTORE: return tile_fn_gb<PREC, OP_KICK | OP_KE | OP_NOSTORE>(gb);
+        case OP_PREKICK | OP_SCALE | OP_KICK | OP_DRIFT: return tile_fn_gb<PREC, OP_PREKICK | OP_SCALE | OP_KICK | OP_DRIFT>(gb);
+        case OP_PREKICK | OP_SCALE: return tile_fn_gb<PREC, OP_PREKICK | OP_SCALE>(gb);
         case OP_KICK: return tile_fn_gb<PREC, OP_KICK>(gb);
         case OP_SCALE | OP_KICK | OP_POSDELTA: return tile_fn_gb<PREC, OP_SCALE | OP_KICK | OP_POSDELTA>(gb);
         case OP_MOVE: return tile_fn_gb<PREC, OP_MOVE>(gb);

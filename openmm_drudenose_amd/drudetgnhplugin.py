@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (MODE_DUALNH, MODE_TGNH, PREC_SINGLE, PREC_MIXED, PREC_DOUBLE,  # noqa: F401
-                   FLAG_MERGE_SCALE_KE, FLAG_DEFER_SCALE)
+                   FLAG_DEFER_SCALE)
 from .synth import KB
 
 _PREC = {"single": PREC_SINGLE, "mixed": PREC_MIXED, "double": PREC_DOUBLE}
@@ -542,8 +542,17 @@ class HipContext(_HandleQueries):
         replay.graph = g
         return replay
 
+    def status_flags(self):
+        """The device's status word (bit 0 Drude beyond 2x the hard wall, bit 1 harness SHAKE not converged, bit 2 mailbox
+        exchange timed out), whether or not it spells a failure.  Synchronises the stream."""
+        flags = C.c_uint32()
+        self.lib.tgnh_get_status_flags(self.h, self._stream(), C.byref(flags))
+        return flags.value
+
     def check(self):
-        """Raises if the device flagged a Drude beyond 2x the hard wall (dualNH mode, Ref :311-312)."""
+        """The status word; raises TgnhError for the failures among its bits: a Drude beyond 2x the hard wall in dualNH
+        mode (Ref :311-312), a mailbox exchange that timed out.  Once seen, a failure is sticky in the library: every
+        later step or query raises too."""
         flags = C.c_uint32()
         _check(self.lib.tgnh_get_status_flags(self.h, self._stream(), C.byref(flags)))
         return flags.value
@@ -576,6 +585,10 @@ class HipContext(_HandleQueries):
         t, k = C.c_double(), C.c_int64()
         _check(self.lib.tgnh_get_time(self.h, C.byref(t), C.byref(k)))
         return t.value, k.value
+
+    def set_time(self, time, step_count):
+        """Context::setTime / setStepCount of a restored checkpoint."""
+        _check(self.lib.tgnh_set_time(self.h, float(time), int(step_count)))
 
     def timing(self, on):
         _check(self.lib.tgnh_timing_enable(self.h, int(on)))

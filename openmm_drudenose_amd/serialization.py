@@ -61,12 +61,17 @@ def deserialize(text):
 
 
 def save_thermostat(ctx):
-    """Thermostat variables + clock of a context: what a checkpoint must hold besides positions/velocities."""
+    """Thermostat variables + clock of a context: what a checkpoint must hold besides positions/velocities.
+    (Between steps of a TGNH_FLAG_DEFER_SCALE context the chain already holds the coming step's first half: checkpoint
+    a plain-variant context, or the deferred one before its first step.)"""
     t, k = ctx.time()
     return {"eta": ctx.thermostat_state(0), "etaDot": ctx.thermostat_state(1), "etaDotDot": ctx.thermostat_state(2),
-            "time": t, "stepCount": k}
+            "etaMass": ctx.thermostat_state(3), "time": t, "stepCount": k}
 
 
 def load_thermostat(ctx, state):
-    for which, key in enumerate(("eta", "etaDot", "etaDotDot")):
-        ctx.set_thermostat_state(which, np.asarray(state[key], np.float64))
+    for which, key in enumerate(("eta", "etaDot", "etaDotDot", "etaMass")):
+        if key in state:
+            ctx.set_thermostat_state(which, np.asarray(state[key], np.float64))
+    if "time" in state and "stepCount" in state:
+        ctx.set_time(float(state["time"]), int(state["stepCount"]))
