@@ -46,9 +46,10 @@ def parse():
     p.add_argument("--molecules", type=int, default=1_000_000, help="SWM4 molecules = Drude pairs (metric: 1,000,000)")
     p.add_argument("--precision", default="mixed", choices=["single", "mixed", "double"])
     p.add_argument("--mode", default="TGNH", choices=["TGNH", "dualNH"])
-    p.add_argument("--variant", default="defer", choices=["plain", "defer"],
-                   help="defer (default) = end-of-step rescale and second half kick folded into the next step's first pass; "
-                        "plain = the reference's pass structure (what the OpenMM glue runs) (DESIGN.md)")
+    p.add_argument("--variant", default="auto", choices=["auto", "plain", "defer", "resident"],
+                   help="defer = end-of-step rescale and second half kick folded into the next step's first pass; resident = "
+                        "defer with the whole step in ONE launch whose work-groups meet on the device (step_kernel); plain = "
+                        "the reference's pass structure (what the OpenMM glue runs); auto = resident (DESIGN.md)")
     p.add_argument("--chains", type=int, default=1)
     p.add_argument("--drude-steps", type=int, default=20, help="drudeStepsPerRealStep (reference default 20)")
     p.add_argument("--hardwall", type=float, default=0.02, help="maxDrudeDistance nm (example/nacl_tg.py:22); 0 = off")
@@ -70,11 +71,11 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
     import torch
     import torch.distributed as dist
     from openmm_drudenose_amd import DrudeTGNHIntegrator, HipContext
-    from openmm_drudenose_amd.drudetgnhplugin import FLAG_DEFER_SCALE
+    from openmm_drudenose_amd.drudetgnhplugin import FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP
     from openmm_drudenose_amd.system import shard_bounds
     it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, args.drude_steps, args.chains, True, True)
     it.setMaxDrudeDistance(args.hardwall)
-    flags = {"plain": 0, "defer": FLAG_DEFER_SCALE}[variant]
+    flags = {"plain": 0, "defer": FLAG_DEFER_SCALE, "resident": FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP}[variant]
     local, lgroup = system, group
     if world > 1:
         b = shard_bounds(system, world)
@@ -167,7 +168,13 @@ def validate_mailbox(args, rank, world):
     return True
 
 
-def timed_run(ctx, steps, warmup, world, graph_steps=0):
+def dominant_kid(variant):
+    """the launch that carries most of a step: step_kernel (resident) or the fused rescale + half kick + drift pass"""
+    from openmm_drudenose_amd import _lib
+    return _lib.KID_STEP if variant == "resident" else _lib.KID_SKD
+
+
+def timed_run(ctx, steps, warmup, world, graph_steps=0, dom_kid=0):
     """W untimed warm-up steps, then exactly `steps` steps between barrier + synchronize pairs; max over ranks.
     graph_steps > 0: the steps are replays of a hipGraph holding graph_steps steps (+ an eager remainder).
     Leaves ctx.leg = what the JSON line reports for this leg, including the sum of the per-kernel times of one step
@@ -196,7 +203,7 @@ def timed_run(ctx, steps, warmup, world, graph_steps=0):
             torch.cuda.synchronize()
     ctx.graph_used = replay is not None
     if replay is None:
-        ctx.timing(2 + 0)          # HIP events around the dominant kernel (rescale+kick+drift) only: 2 records per step
+        ctx.timing(2 + dom_kid)    # HIP events around the dominant kernel only: 2 records per step
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -219,7 +226,7 @@ def timed_run(ctx, steps, warmup, world, graph_steps=0):
     dom = None
     if replay is None:
         ctx.timing(False)
-        dom = ctx.timing_read(0)                       # (total ms, launches) of the dominant kernel inside the timed region
+        dom = ctx.timing_read(dom_kid)                 # (total ms, launches) of the dominant kernel inside the timed region
     # full per-kernel table: an instrumented repeat of the same steps right after the timed region (event records
     # around all kernels cost ~20 us per step, which is why they are not inside it)
     nrep = max(1, min(steps, 200))
@@ -231,7 +238,7 @@ def timed_run(ctx, steps, warmup, world, graph_steps=0):
     rows = kernel_table(ctx)
     sum_us = sum(v["avg_us"] * v["launches"] for v in rows.values()) / nrep
     ms = dt / steps * 1e3
-    ctx.leg = {"steps_per_s": round(steps / dt, 2), "ms_per_step": round(ms, 4),
+    ctx.leg = {"steps_per_s": round(steps / dt, 2), "ms_per_step": round(ms, 4), "instrumented_steps": nrep,
                "sum_kernels_us_per_step": round(sum_us, 2), "host_enqueue_ms": round(t_enq * 1e3, 3),
                "suspect": bool(sum_us > 0 and ms * 1e3 > 1.3 * sum_us), "kernels": rows}
     if dom and dom[1]:
@@ -289,7 +296,7 @@ def pmc_traffic(precision, slots, variant):
         d = json.load(open(path))
         if d.get("slots") != slots or d.get("csrc_sha") != csrc_sha() or d.get("variant") != variant:
             return None, path
-        return d["kernels"][f"tile<{precision},rescale+kick+drift>"]["hbm_bytes_per_launch"], path
+        return d["kernels"]["dominant"]["hbm_bytes_per_launch"], path
     except Exception:
         return None, path
 
@@ -382,12 +389,14 @@ def step_model_bytes(num_slots, precision, variant):
     V = 16 if precision == "single" else 32
     X = 16 if precision == "single" else 32
     F = 24
-    per = {"plain": 7 * V + 2 * F + 2 * X, "defer": 3 * V + 2 * F + 2 * X}[variant]
+    per = {"plain": 7 * V + 2 * F + 2 * X, "defer": 3 * V + 2 * F + 2 * X, "resident": 3 * V + 2 * F + 2 * X}[variant]
     return num_slots * per
 
 
 def main():
     args = parse()
+    if args.variant == "auto":
+        args.variant = "resident"
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
         self_launch(args, sys.argv[1:])                # does not return
@@ -440,7 +449,7 @@ def main():
         if exchange == "mailbox" and not attach_mailbox(ctx, rank, world):
             close_sharded(ctx)
             return None, None
-        dt = timed_run(ctx, args.steps, args.warmup, world, gsteps)
+        dt = timed_run(ctx, args.steps, args.warmup, world, gsteps, dominant_kid(args.variant))
         return ctx, dt
 
     headline_exchange = args.exchange if use_dist else None
@@ -460,13 +469,18 @@ def main():
     leg = ctx.leg
     rows = leg["kernels"]
     assert ctx.check() == 0
-    # dominant kernel: the fused rescale + half kick + drift (+ hard wall) pass
-    bytes_dom = ctx.algorithmic_bytes(_lib.KID_SKD)
-    if ctx.dominant_in_timed_region and ctx.dominant_in_timed_region[1]:
+    # dominant kernel: step_kernel (resident variant: the whole step but the force call-out) or the fused rescale +
+    # half kick + drift (+ hard wall) pass; a handle that cannot run step_kernel (RCCL hook) falls back to the passes
+    dkid = dominant_kid(args.variant)
+    if _lib.KERNEL_NAMES[dkid] not in rows:
+        dkid = _lib.KID_SKD
+    dom_name = _lib.KERNEL_NAMES[dkid]
+    bytes_dom = ctx.algorithmic_bytes(dkid)
+    if dkid == dominant_kid(args.variant) and ctx.dominant_in_timed_region and ctx.dominant_in_timed_region[1]:
         ms, n = ctx.dominant_in_timed_region
         dom = {"avg_us": round(ms / n * 1e3, 3), "launches": n, "where": "HIP events inside the timed region"}
     else:
-        dom = dict(rows.get("scale+kick+drift"), where="HIP events in the instrumented repeat (timed region was a hipGraph replay)")
+        dom = dict(rows.get(dom_name), where="HIP events in the instrumented repeat (timed region was a hipGraph replay)")
     achieved = bytes_dom / (dom["avg_us"] * 1e-6) / 1e9
     local_slots = ctx.n
     close_sharded(ctx)
@@ -494,11 +508,11 @@ def main():
     if mailbox_info:
         extra["mailbox"] = dict(extra.get("mailbox", {}), **mailbox_info)
     if world == 1 and not args.no_extra:
-        for prec, var in ((args.precision, "plain"), ("single", "defer")):
+        for prec, var in ((args.precision, "plain"), (args.precision, "defer"), ("single", args.variant)):
             if (prec, var) == (args.precision, args.variant):
                 continue
             c2 = build_context(args, system, group, ngroups, rank, world, prec, var)
-            timed_run(c2, args.steps, args.warmup, world)
+            timed_run(c2, args.steps, args.warmup, world, 0, dominant_kid(var))
             extra[f"{prec}/{var}"] = c2.leg
             c2.close()
         if args.mode == "TGNH":                  # the other semantic mode (platforms/reference's algorithm), same workload
@@ -506,7 +520,7 @@ def main():
             a2 = copy.copy(args)
             a2.mode = "dualNH"
             c2 = build_context(a2, system, group, ngroups, rank, world, args.precision, args.variant)
-            timed_run(c2, args.steps, args.warmup, world)
+            timed_run(c2, args.steps, args.warmup, world, 0, dominant_kid(args.variant))
             extra[f"dualNH/{args.precision}/{args.variant}"] = c2.leg
             c2.close()
     copy_gbps = device_copy_gbps() if rank == 0 else None
@@ -536,7 +550,8 @@ def main():
                 "sum_kernels_us_per_step": leg["sum_kernels_us_per_step"], "suspect": leg["suspect"],
                 "csrc_sha": csrc_sha(),
             },
-            "roofline": {"bound": "hbm", "kernel": "tile_kernel<scale+kick+drift>", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "step_kernel" if dkid == _lib.KID_STEP else "tile_kernel<scale+kick+drift>",
+                         "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,
                          "traffic_source": f"{os.path.relpath(traffic_path, ROOT)} (separate rocprofv3 --pmc passes, bytes per launch; "
@@ -549,7 +564,7 @@ def main():
         }
         # `value` times whole steps, the harness force call-out included (in a real context that slot is OpenMM's
         # calcForcesAndEnergy).  The integrator's own launches alone (SURVEY 8d reports the force kernel separately):
-        own = sum(v["avg_us"] * v["launches"] for k, v in rows.items() if k != "harness force") / max(1, rows.get("scale+kick+drift", {}).get("launches", 1))
+        own = sum(v["avg_us"] * v["launches"] for k, v in rows.items() if k != "harness force") / leg["instrumented_steps"]
         if own > 0:
             out["integrator_only"] = {"steps_per_s": round(1e6 / own, 1), "us_per_step": round(own, 2),
                                       "how": "sum of the durations of the integrator's own launches per step (instrumented repeat), force call-out excluded; "

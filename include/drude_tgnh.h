@@ -60,6 +60,12 @@ enum { TGNH_FLAG_DEFER_SCALE = 2 };    /* the end-of-step rescale AND the second
                                         * into the next step's first pass: between tgnh_step_end and the next
                                         * tgnh_step_begin velm lags and the force buffer must stay as it is; tgnh_flush
                                         * makes velm the reference's end-of-step state.  (1 is reserved.) */
+enum { TGNH_FLAG_RESIDENT_STEP = 4 };  /* with DEFER_SCALE: tgnh_step_end launches nothing and the next tgnh_step_begin runs
+                                        * that end half and its own begin half in ONE launch whose work-groups meet on the
+                                        * device.  The handle needs the device to itself while stepping (see
+                                        * tgnh_set_resident_share); one-link chains, <= 8 temperature groups, no collective
+                                        * hook -- otherwise the handle quietly steps the DEFER_SCALE way.  With a mailbox
+                                        * exchange attached, state queries between steps are collective over the ranks. */
 
 typedef struct tgnh_desc {
     uint32_t struct_size;         /* sizeof(tgnh_desc), ABI check */
@@ -126,6 +132,10 @@ tgnh_status tgnh_set_max_drude_distance(tgnh_handle h, double d);
 tgnh_status tgnh_get_local_dof_terms(tgnh_handle h, double* terms, int* count);
 tgnh_status tgnh_set_global_dof_terms(tgnh_handle h, const double* terms, int count);
 tgnh_status tgnh_set_allreduce(tgnh_handle h, tgnh_allreduce_fn fn, void* user);
+/* TGNH_FLAG_RESIDENT_STEP: this handle may fill 1/share of the device's resident work-group slots (default 1 = all of
+ * them).  Several handles that step concurrently on one device (replicas, or the ranks of a rehearsal on one GPU) must
+ * share it, or their launches wait for each other's work-groups until the meeting times out (status bit 3). */
+tgnh_status tgnh_set_resident_share(tgnh_handle h, int share);
 
 /* Mailbox exchange: the same all-reduce of the NT kinetic-energy sums, done by the integrator's own kernels with
  * plain stores into every peer's mailbox over xGMI (no collective launch on the step's critical path).  Optional;
@@ -182,8 +192,8 @@ tgnh_status tgnh_get_kinetic_energy(tgnh_handle h, int ke_sum_valid, void* strea
 tgnh_status tgnh_get_num_thermostats(tgnh_handle h, int* count);               /* NT: TGNH G+2 = [groups.., COM, Drude]; DUALNH 3 = [real, unused, Drude] */
 tgnh_status tgnh_get_last_kinetic_energies(tgnh_handle h, void* stream, double* ke);   /* no 1/2; before the chain */
 tgnh_status tgnh_get_last_scale_factors(tgnh_handle h, void* stream, double* scale);
-/* bit0: a Drude beyond 2x the hard wall; bit1: the harness SHAKE did not converge; bit2: a mailbox exchange timed out.
- * *flags is always filled in.  bit2 -- and bit0 in DUALNH mode, where the Reference platform throws
+/* bit0: a Drude beyond 2x the hard wall; bit1: the harness SHAKE did not converge; bit2: a mailbox exchange timed out;
+ * bit3: the work-groups of a resident step did not all meet.  *flags is always filled in.  bit2, bit3 -- and bit0 in DUALNH mode, where the Reference platform throws
  * (ReferenceDrudeTGNHKernels.cpp:311-312) -- are FAILURES and sticky: once the host has seen one (here, at any other
  * tgnh_get_*, at tgnh_exchange_detach, or through the read-back the library enqueues behind every 64th step) every later
  * tgnh_step_*, tgnh_flush and tgnh_get_* returns TGNH_ERR_STATE / TGNH_ERR_HARDWALL with the message in tgnh_last_error(). */
@@ -234,7 +244,7 @@ tgnh_status tgnh_run_harness_constrained(tgnh_handle h, const void* x0, double k
 
 /* Per-kernel launch statistics gathered with HIP events on `stream` while
  * enabled (bench.py's live roofline).  kernel: 0 scale+kick+drift, 1 kick+KE,
- * 2 rescale(+KE), 3 KE, 4 chain, 5 harness force.  on = 1: every kernel; on = 2 + k: kernel k only
+ * 2 rescale, 3 KE, 4 chain, 5 harness force, 6 other, 7 resident step.  on = 1: every kernel; on = 2 + k: kernel k only
  * (two event records per step instead of eight, for timing inside a throughput measurement); 0: off. */
 tgnh_status tgnh_timing_enable(tgnh_handle h, int on);
 tgnh_status tgnh_timing_read(tgnh_handle h, int kernel, double* total_ms, int64_t* launches);

@@ -9,10 +9,10 @@ TGNH_OK = 0
 ERR_ARG, ERR_GROUP_MISMATCH, ERR_HARDWALL, ERR_UNSUPPORTED, ERR_HIP, ERR_STATE = -1, -2, -3, -4, -5, -6
 MODE_DUALNH, MODE_TGNH = 0, 1
 PREC_SINGLE, PREC_MIXED, PREC_DOUBLE = 0, 1, 2
-FLAG_DEFER_SCALE = 2
-KID_SKD, KID_KICK_KE, KID_SCALE, KID_KE, KID_CHAIN, KID_FORCE, KID_OTHER = range(7)
+FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP = 2, 4
+KID_SKD, KID_KICK_KE, KID_SCALE, KID_KE, KID_CHAIN, KID_FORCE, KID_OTHER, KID_STEP = range(8)
 KERNEL_NAMES = {KID_SKD: "scale+kick+drift", KID_KICK_KE: "kick+KE", KID_SCALE: "rescale", KID_KE: "KE",
-                KID_CHAIN: "chain", KID_FORCE: "harness force", KID_OTHER: "other"}
+                KID_CHAIN: "chain", KID_FORCE: "harness force", KID_OTHER: "other", KID_STEP: "resident step"}
 
 c_i32p = C.POINTER(C.c_int32)
 c_f64p = C.POINTER(C.c_double)
@@ -49,6 +49,7 @@ SIGNATURES = {
     "tgnh_get_local_dof_terms": (C.c_int, [C.c_void_p, c_f64p, C.POINTER(C.c_int)]),
     "tgnh_set_global_dof_terms": (C.c_int, [C.c_void_p, c_f64p, C.c_int]),
     "tgnh_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+    "tgnh_set_resident_share": (C.c_int, [C.c_void_p, C.c_int]),
     "tgnh_exchange_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "tgnh_exchange_attach": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tgnh_exchange_attach_pointers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -423,11 +423,13 @@ __device__ __forceinline__ void xchg_send(const XchgArgs& x, const int NT, const
     }
 }
 // Called by all 64 lanes of one wavefront, converged; s_val = LDS scratch of world*NT doubles owned by that wavefront.
-// Returns the all-rank sum of thermostat `lane` (lanes < NT).
-__device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT, const int lane, double* s_val) {
+// Returns the all-rank sum of thermostat `lane` (lanes < NT).  seq_expected != 0: the exchange to wait for when this
+// rank's own send may not have happened yet (step_kernel: sender and waiters are work-groups of one launch).
+__device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT, const int lane, double* s_val,
+                                                const unsigned long long seq_expected = 0ull) {
     const int cells = x.world * NT;
     // first batch: counter, latch and both parities of this lane's first cell, all in flight together
-    const unsigned long long seq_raw = __hip_atomic_load(x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long seq_raw = seq_expected ? seq_expected : __hip_atomic_load(x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned dead = __hip_atomic_load(x.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long a0 = 0, a1 = 0, b0 = 0, b1 = 0;
     if (lane < cells) {

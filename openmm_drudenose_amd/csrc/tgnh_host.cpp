@@ -41,6 +41,7 @@ static void note_status(tgnh_handle h, uint32_t flags);
 static tgnh_status entry(tgnh_handle h, bool need_bufs);
 static tgnh_status flush_impl(tgnh_handle h, hipStream_t s);
 static tgnh_status settle_kick(tgnh_handle h, hipStream_t s);
+static tgnh_status settle_end(tgnh_handle h, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // A1: topology + tiles
@@ -340,7 +341,7 @@ static tgnh_status finalize_thermostat(tgnh_context* c) {
         HIP_OK(hipMemcpy(c->d_stage, st.data(), sizeof(double) * L.total, hipMemcpyHostToDevice));
     }
     c->chain_pending = false; c->stage_pending = false;
-    c->scale_pending = false; c->kick_pending = false; c->first_half_done = false;
+    c->scale_pending = false; c->kick_pending = false; c->first_half_done = false; c->end_pending = false;
     return TGNH_OK;
 }
 
@@ -413,6 +414,10 @@ static void free_device(tgnh_context* c) {
     if (c->h_status_seen) (void)hipHostFree(c->h_status_seen);
     c->h_status_seen = nullptr;
     if (c->d_scalar) (void)hipFree(c->d_scalar);
+    if (c->d_sync) (void)hipFree(c->d_sync);
+    if (c->d_rows) (void)hipFree(c->d_rows);
+    if (c->self_box) (void)hipFree(c->self_box);
+    if (c->d_self_misc) (void)hipFree(c->d_self_misc);
     if (c->d_cl_atoms) (void)hipFree(c->d_cl_atoms);
     if (c->d_cl_dist) (void)hipFree(c->d_cl_dist);
     if (c->d_vs_atoms) (void)hipFree(c->d_vs_atoms);
@@ -457,8 +462,17 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     c->realkbT = d->kB * d->temperature;                                      // Ref :107-108, Cu :80-81
     c->drudekbT = d->kB * d->drude_temperature;
     make_layout(c);
+    c->gb = c->L.G <= 1 ? 1 : (c->L.G <= 4 ? 4 : (c->L.G <= 8 ? 8 : 0));   // 0: KE bins in LDS
+    if (!host_only) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+    }
     tgnh_status rc = build_topology(c, d);
     if (rc != TGNH_OK) { free_device(c); delete c; return rc; }
+    if ((d->flags & TGNH_FLAG_RESIDENT_STEP) && !(d->flags & TGNH_FLAG_DEFER_SCALE)) {
+        free_device(c); delete c;
+        return fail(TGNH_ERR_ARG, "TGNH_FLAG_RESIDENT_STEP needs TGNH_FLAG_DEFER_SCALE");
+    }
     if ((d->flags & TGNH_FLAG_DEFER_SCALE) && d->mode == TGNH_MODE_TGNH && d->use_com_temp_group) {
         // s^2 KE is the exact post-rescale KE only if no molecule spans two temperature groups
         for (int r = 0; r < d->num_residues; r++) {
@@ -481,12 +495,6 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
 #ifdef TGNH_TUNING       // environment knobs exist in tuning builds only (tools/build_variant.py -DTGNH_TUNING)
     if (const char* e = getenv("TGNH_GRID")) { int g = atoi(e); if (g >= 1) c->grid_override = std::min(g, GRID_CAP); }
 #endif
-    if (!host_only) {
-        hipDeviceProp_t prop;
-        HIP_OK(hipGetDeviceProperties(&prop, d->device));
-        c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    c->gb = c->L.G <= 1 ? 1 : (c->L.G <= 4 ? 4 : (c->L.G <= 8 ? 8 : 0));   // 0: KE bins in LDS
     {   // One-link chains run inside the rescale launch: one wavefront per work-group computes the factors while
         // the other three have their tile loads in flight, so the chain (~3.5 us) costs the launch nothing, and
         // the chain launch that remains only sums the partial rows (profiles/r01_tuning_sweep.log: +7 % steps/s
@@ -517,6 +525,30 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         *c->h_status_seen = 0;
 
         HIP_OK(hipMalloc(&c->d_scalar, sizeof(double)));
+        HIP_OK(hipMalloc(&c->d_sync, 2 * sizeof(unsigned int)));
+        HIP_OK(hipMemset(c->d_sync, 0, 2 * sizeof(unsigned int)));
+        if (c->d.flags & TGNH_FLAG_RESIDENT_STEP) {
+            // step_kernel's meeting place: the work-groups' tagged rows, and a private one-rank mailbox that carries the
+            // sums from work-group 0 to all the others when no sharded exchange is attached (uncached, like the mailboxes)
+            const size_t rb = sizeof(unsigned long long) * 2 * (size_t)GRID_CAP * CHAIN_INLINE_SUM_NT;
+            void* p = nullptr;
+            HIP_OK(hipExtMallocWithFlags(&p, rb, hipDeviceMallocUncached));
+            c->d_rows = static_cast<unsigned long long*>(p);
+            HIP_OK(hipMemset(c->d_rows, 0, rb));
+            HIP_OK(hipExtMallocWithFlags(&p, XCHG_MAILBOX_BYTES(1), hipDeviceMallocUncached));
+            c->self_box = static_cast<unsigned long long*>(p);
+            HIP_OK(hipMemset(c->self_box, 0, XCHG_MAILBOX_BYTES(1)));
+            HIP_OK(hipMalloc(&c->d_self_misc, 4 * sizeof(unsigned long long)));     // [0] seq, [1] dead latch, [2] peers[0]
+            HIP_OK(hipMemset(c->d_self_misc, 0, 4 * sizeof(unsigned long long)));
+            HIP_OK(hipMemcpy(c->d_self_misc + 2, &c->self_box, sizeof(unsigned long long*), hipMemcpyHostToDevice));
+            c->self_x = XchgArgs{};
+            c->self_x.on = 1; c->self_x.world = 1; c->self_x.rank = 0;
+            c->self_x.peers = reinterpret_cast<unsigned long long* const*>(c->d_self_misc + 2);
+            c->self_x.mine = c->self_box;
+            c->self_x.seq = c->d_self_misc;
+            c->self_x.dead = reinterpret_cast<unsigned int*>(c->d_self_misc + 1);
+            c->self_x.status = c->d_status;
+        }
         return TGNH_OK;
     };
     rc = alloc();
@@ -539,14 +571,14 @@ extern "C" tgnh_status tgnh_bind_buffers(tgnh_handle h, void* posq, void* posq_c
     if (h->host_only) return fail(TGNH_ERR_STATE, "host-only handle (device -1): no GPU work can be launched on it");
     if (!posq || !velm || !force) return fail(TGNH_ERR_ARG, "posq, velm and force are required");
     if (h->d.precision == TGNH_PREC_MIXED && !posq_correction) return fail(TGNH_ERR_ARG, "mixed precision needs posqCorrection");
-    if (h->kick_pending && (velm != h->velm || force != h->force))
+    if ((h->kick_pending || h->end_pending) && (velm != h->velm || force != h->force))
         return fail(TGNH_ERR_STATE, "tgnh_bind_buffers: velm / force may not be rebound while a deferred half kick is pending (tgnh_flush first)");
     h->posq = posq; h->posq_corr = posq_correction; h->velm = velm; h->force = force; h->pos_delta = pos_delta;
     return TGNH_OK;
 }
 
 static tgnh_status deferred_guard(tgnh_handle h, const char* what) {
-    if (h->first_half_done)
+    if (h->first_half_done || h->end_pending)
         return fail(TGNH_ERR_STATE, std::string(what) + ": not allowed between steps with TGNH_FLAG_DEFER_SCALE (the next thermostat half step has already run)");
     return TGNH_OK;
 }
@@ -673,6 +705,10 @@ extern "C" tgnh_status tgnh_exchange_detach(tgnh_handle h) {
         HIP_OK(hipMemcpy(&f, h->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost));
         note_status(h, f);
     }
+    if (h->end_pending && !h->failed_code) {          // settle collectively: every rank detaches at the same step
+        tgnh_status rc = settle_end(h, (hipStream_t)0); if (rc) return rc;
+        HIP_OK(hipDeviceSynchronize());
+    }
     if (h->chain_pending && h->xwait_pending && !h->failed_code) {       // an exchange is half done (sent, not yet waited for): finish it
         tgnh_status rc = materialize_chain(h, (hipStream_t)0); if (rc) return rc;
         HIP_OK(hipDeviceSynchronize());
@@ -685,7 +721,16 @@ extern "C" tgnh_status tgnh_exchange_detach(tgnh_handle h) {
 
 extern "C" tgnh_status tgnh_set_allreduce(tgnh_handle h, tgnh_allreduce_fn fn, void* user) {
     CHECK_H(h);
+    tgnh_status rc = deferred_guard(h, "tgnh_set_allreduce"); if (rc) return rc;
     h->allreduce = fn; h->allreduce_user = user;
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_set_resident_share(tgnh_handle h, int share) {
+    CHECK_H(h);
+    if (share < 1 || share > 64) return fail(TGNH_ERR_ARG, "resident share must be 1..64");
+    h->resident_share = share;
+    h->resident_grid = h->resident_grid_hw = 0;
     return TGNH_OK;
 }
 
@@ -704,6 +749,10 @@ static void note_status(tgnh_handle h, uint32_t flags) {
         h->failed_code = TGNH_ERR_STATE;
         h->failed = "mailbox exchange timed out (noticed at step " + std::to_string((long long)h->step_count) +
                     "): a peer did not send its kinetic-energy sums; the run cannot continue";
+    } else if (flags & 8u) {
+        h->failed_code = TGNH_ERR_STATE;
+        h->failed = "resident step (noticed at step " + std::to_string((long long)h->step_count) + "): the launch's work-groups did "
+                    "not all become resident within the time limit (TGNH_FLAG_RESIDENT_STEP needs the device to itself)";
     } else if ((flags & 1u) && h->d.mode == TGNH_MODE_DUALNH) {
         h->failed_code = TGNH_ERR_HARDWALL;
         h->failed = "Drude particle moved too far beyond hard wall constraint";        // Ref :311-312
@@ -899,11 +948,51 @@ static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
 
 // a chain that is still waiting for its rescale launch is run now, in place, by the standalone kernel
 static tgnh_status materialize_chain(tgnh_handle h, hipStream_t s) {
+    { tgnh_status rc = settle_end(h, s); if (rc) return rc; }
     if (!h->chain_pending) return commit_stage(h, s);
     ChainArgs a = chain_args(h);
     a.do_sum = h->sum_pending ? 1 : 0; a.do_chain = 1; a.chain_twice = h->chain_pending_twice ? 1 : 0;
     a.x_wait = h->xwait_pending ? 1 : 0;
     { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
+    h->chain_pending = false; h->sum_pending = false; h->xwait_pending = false;
+    return TGNH_OK;
+}
+
+// ---- TGNH_FLAG_RESIDENT_STEP: one launch per time step (step_kernel) ----
+// Eligible: deferred pass structure, one-link chains (the chain runs inside the launch), at most 8 temperature groups,
+// and an exchange the kernel can do itself (none, or the mailboxes -- a collective hook is a launch of its own).
+static bool resident_now(tgnh_handle h) {
+    return (h->d.flags & TGNH_FLAG_RESIDENT_STEP) && (h->d.flags & TGNH_FLAG_DEFER_SCALE) && h->d_rows && h->inline_chain && h->gb != 0 &&
+           h->L.NT <= CHAIN_INLINE_SUM_NT && (h->xchg_on || !h->allreduce);
+}
+
+static tgnh_status run_resident_step(tgnh_handle h, hipStream_t s) {
+    if (h->stage_pending) { tgnh_status rc = commit_stage(h, s); if (rc) return rc; }
+    TileArgs a = tile_args(h, nullptr);
+    const bool hw = a.hardwall != 0;
+    const size_t lds = tile_lds_bytes(h->d.precision, OP_PREKICK | OP_SCALE | OP_KICK | OP_DRIFT, hw, a.use_com != 0);
+    int& grid = hw ? h->resident_grid_hw : h->resident_grid;
+    if (grid == 0) {       // the work-groups that are resident at once -- all of them meet inside the launch
+        int per_cu = step_blocks_per_cu(h->d.precision, h->gb, lds);
+        if (per_cu < 1) return fail(TGNH_ERR_HIP, "step_kernel: occupancy query failed");
+        grid = std::max(1, std::min(std::min(h->num_tiles, per_cu * h->num_cus / h->resident_share), GRID_CAP));
+    }
+    a.chain_on = 1;
+    a.chain = chain_args(h);
+    a.chain.chain_twice = 1;
+    a.chain.nparts = grid;
+    a.x_wait = 1;
+    if (!h->xchg_on) a.chain.x = h->self_x;            // unsharded: the private one-rank mailbox
+    a.st_in = h->d_state; a.st_out = h->d_state;       // advanced in place by work-group 0 after everybody has read it
+    a.sync = h->d_sync; a.rows = h->d_rows;
+    if (h->num_big && a.use_com) { tgnh_status rc = run_big_com(h, true, s); if (rc) return rc; }
+    h->ke_parts = grid;
+    {
+        Timed t(h, s, KID_STEP);
+        HIP_OK(launch_step(h->d.precision, h->gb, a, grid, lds, s));
+    }
+    // the first pass walked the tiles in direction sweep_reverse, the second one back: the next launch starts here
+    h->end_pending = false; h->scale_pending = false; h->kick_pending = false; h->first_half_done = false;
     h->chain_pending = false; h->sum_pending = false; h->xwait_pending = false;
     return TGNH_OK;
 }
@@ -942,6 +1031,10 @@ static tgnh_status poll_status_async(tgnh_handle h, hipStream_t s) {
 extern "C" tgnh_status tgnh_step_begin(tgnh_handle h, void* stream) {
     tgnh_status rc = entry(h, true); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (h->end_pending) {
+        if (resident_now(h)) return run_resident_step(h, s);         // the last step's end half and this begin half: one launch
+        rc = settle_end(h, s); if (rc) return rc;
+    }
     rc = first_half(h, s); if (rc) return rc;
     // Cu :351-376 fused; with a half kick still pending from the last step_end (DEFER_SCALE) that kick comes first
     rc = run_tile(h, (h->kick_pending ? OP_PREKICK : 0) | OP_SCALE | OP_KICK | OP_DRIFT, KID_SKD, s); if (rc) return rc;
@@ -952,7 +1045,15 @@ extern "C" tgnh_status tgnh_step_begin(tgnh_handle h, void* stream) {
 static tgnh_status second_half(tgnh_handle h, hipStream_t s, int kick_ops) {
     tgnh_status rc;
     const bool defer = (h->d.flags & TGNH_FLAG_DEFER_SCALE) != 0;
-    if (h->scale_pending || h->kick_pending) { rc = flush_impl(h, s); if (rc) return rc; }   // two end halves in a row
+    if (h->scale_pending || h->kick_pending || h->end_pending) { rc = flush_impl(h, s); if (rc) return rc; }   // two end halves in a row
+    if (kick_ops && resident_now(h)) {
+        // TGNH_FLAG_RESIDENT_STEP: nothing is launched here -- the next tgnh_step_begin runs this end half and its own
+        // begin half in one launch (step_kernel); anything that needs the state earlier settles it the classic way
+        h->end_pending = true;
+        h->time += h->d.step_size;
+        h->step_count += 1;
+        return poll_status_async(h, s);
+    }
     // DEFER_SCALE, fused path: the kicked velocities only feed the sums (Cu :384-388 + :474-488); the next step's first
     // launch -- or tgnh_flush -- forms them again from the same force buffer and goes on from there
     const int nostore = (defer && kick_ops) ? OP_NOSTORE : 0;
@@ -976,7 +1077,18 @@ extern "C" tgnh_status tgnh_step_end(tgnh_handle h, void* stream) {
 
 // The split entry points work on stored velocities: a deferred half kick is materialised first.
 static tgnh_status settle_kick(tgnh_handle h, hipStream_t s) {
-    return h->kick_pending ? flush_impl(h, s) : TGNH_OK;
+    return (h->kick_pending || h->end_pending) ? flush_impl(h, s) : TGNH_OK;
+}
+
+// TGNH_FLAG_RESIDENT_STEP left the end half of the last step to the next tgnh_step_begin; somebody needs it now:
+// the classic launches (kick+KE without a velocity store, row sum [+ exchange], both chain halves pending)
+static tgnh_status settle_end(tgnh_handle h, hipStream_t s) {
+    if (!h->end_pending) return TGNH_OK;
+    h->end_pending = false;
+    tgnh_status rc = run_tile(h, OP_KICK | OP_KE | OP_NOSTORE, KID_KICK_KE, s); if (rc) return rc;
+    rc = run_chain(h, s, true); if (rc) return rc;
+    h->scale_pending = true; h->first_half_done = true; h->kick_pending = true;
+    return TGNH_OK;
 }
 
 extern "C" tgnh_status tgnh_step_begin_kick(tgnh_handle h, void* stream) {
@@ -1007,8 +1119,9 @@ extern "C" tgnh_status tgnh_half_kick(tgnh_handle h, void* stream) { return tgnh
 // velm <- the reference's end-of-step velocities: the pending half kick (same force buffer), then the end-of-step
 // factors; scale[] keeps only the pre-run first half of the coming step
 static tgnh_status flush_impl(tgnh_handle h, hipStream_t s) {
+    tgnh_status rc = settle_end(h, s); if (rc) return rc;
     if (!h->scale_pending && !h->kick_pending) return TGNH_OK;
-    tgnh_status rc = materialize_chain(h, s); if (rc) return rc;
+    rc = materialize_chain(h, s); if (rc) return rc;
     if (h->scale_pending) {
         rc = run_tile(h, (h->kick_pending ? OP_PREKICK : 0) | OP_SCALE, KID_SCALE, s, h->d_state + h->L.off_scale_a); if (rc) return rc;
         HIP_OK(hipMemcpyAsync(h->d_state + h->L.off_scale, h->d_state + h->L.off_scale_b, sizeof(double) * h->L.NT,
@@ -1025,7 +1138,7 @@ static tgnh_status flush_impl(tgnh_handle h, hipStream_t s) {
 
 extern "C" tgnh_status tgnh_flush(tgnh_handle h, void* stream) {
     CHECK_H(h);
-    if (!h->scale_pending && !h->kick_pending) return TGNH_OK;
+    if (!h->scale_pending && !h->kick_pending && !h->end_pending) return TGNH_OK;
     tgnh_status rc = entry(h, true); if (rc) return rc;
     return flush_impl(h, (hipStream_t)stream);
 }
@@ -1289,6 +1402,7 @@ extern "C" tgnh_status tgnh_algorithmic_bytes(tgnh_handle h, int kernel, double*
         case KID_SCALE: b = N * (2 * V); break;                 // rescale (+KE): V r/w
         case KID_KE: b = N * V; break;                          // KE: V r
         case KID_FORCE: b = N * (X + F); break;                 // harness: X r, F w (x0 excluded)
+        case KID_STEP: b = N * (3 * V + 2 * F + 2 * X); break;  // step_kernel: its two passes (V r, F r) + (V r/w, F r, X r/w)
         default: b = 0;
     }
     *bytes = b;

@@ -55,7 +55,7 @@ enum : int {
 
 // kernel ids for timing / algorithmic bytes (include/drude_tgnh.h)
 enum : int { KID_SKD = 0, KID_KICK_KE = 1, KID_SCALE = 2, KID_KE = 3, KID_CHAIN = 4, KID_FORCE = 5,
-             KID_OTHER = 6, KID_COUNT = 7 };
+             KID_OTHER = 6, KID_STEP = 7, KID_COUNT = 8 };
 
 // thermostat block in device memory (doubles), offsets in doubles
 struct ChainLayout {
@@ -143,7 +143,9 @@ struct TileArgs {
     const void* big_com;       // mixed4 [num_big] COM velocity (w = 1/M) of the molecules longer than a tile
     const double* scale;       // [NT] velocity scale factors (device)
     double* partials;          // [grid][NT] per-work-group KE partial sums
-    uint32_t* status;          // bit0: Drude beyond 2x hard wall
+    uint32_t* status;          // bit0: Drude beyond 2x hard wall; bit2: exchange time-out; bit3: step_kernel's meeting timed out
+    unsigned int* sync;        // step_kernel: [1] number of the last launch (its rows' tag)
+    unsigned long long* rows;  // step_kernel: [grid][NT] tagged cells (2 words each), uncached
     int num_tiles;
     int reverse;               // walk the tiles last-to-first: start where the previous launch ended (its lines are still in the Infinity Cache)
     int padded;
@@ -196,6 +198,8 @@ struct ForceArgs {
 // launchers (tgnh_kernels.hip)
 hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s);
 int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds);   // occupancy of that instantiation
+hipError_t launch_step(int precision, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s);   // step_kernel
+int step_blocks_per_cu(int precision, int gb, size_t lds);
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s);
 hipError_t launch_big_com(int precision, const BigComArgs& a, hipStream_t s);
 hipError_t launch_force(int precision, const ForceArgs& a, hipStream_t s);
@@ -261,6 +265,13 @@ struct tgnh_context {
     // run state
     bool scale_pending = false;       // DEFER_SCALE: velm lags by scale[]
     bool kick_pending = false;        // DEFER_SCALE: velm also lags by the second half kick (force buffer unchanged since)
+    bool end_pending = false;         // RESIDENT_STEP: the whole end half of the last step waits for the next step_begin's launch
+    unsigned int* d_sync = nullptr;   // step_kernel's meeting: launch number
+    unsigned long long* d_rows = nullptr;   // ... and the tagged rows (uncached)
+    unsigned long long* self_box = nullptr;      // RESIDENT_STEP without a sharded exchange: a private one-rank mailbox
+    unsigned long long* d_self_misc = nullptr;   // ... its counter, latch and peer table
+    tgnh::XchgArgs self_x{};
+    int resident_grid = 0, resident_grid_hw = 0, resident_share = 1;
     bool first_half_done = false;     // DEFER_SCALE: chain for the coming step's first half already run
     double time = 0;
     int64_t step_count = 0;

@@ -86,105 +86,521 @@ extern "C" int tgnh_debug_clear_trace() {
 #define TRACE_WAIT() do {} while (0)
 #endif
 
-template <int PREC, int OPS, int GB>
-__global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileArgs a) {
-    typedef typename Prec<PREC>::real real;
-    typedef typename Prec<PREC>::mixed mixed;
-    typedef typename Prec<PREC>::real4 real4;
-    typedef typename Prec<PREC>::mixed4 mixed4;
-    constexpr bool DO_SCALE = OPS & OP_SCALE, DO_KICK = OPS & OP_KICK, DO_DRIFT = OPS & OP_DRIFT;
-    constexpr bool DO_KE = OPS & OP_KE, DO_PD = OPS & OP_POSDELTA, DO_MOVE = OPS & OP_MOVE;
-    // OP_PREKICK: the half kick a kick+KE launch of the previous step formed for its sums but did not store
-    // (OP_NOSTORE) is applied first -- same force buffer, same expression, same bits (DESIGN.md "deferred kick")
-    constexpr bool DO_PREKICK = OPS & OP_PREKICK, NOSTORE = OPS & OP_NOSTORE;
-    constexpr bool NEED_F = DO_KICK || DO_PREKICK;
-    constexpr bool POS = DO_DRIFT || DO_MOVE;            // positions are read and written
-    constexpr bool VEL_W = (DO_SCALE || DO_KICK || DO_MOVE) && !NOSTORE;   // velocities are written
+// Raw register image of one tile's global loads.
+template <int PREC> struct TileIn {
+    int ts, te, rs, nres;
+    typename Prec<PREC>::mixed4 v[SPT];
+    uint32_t meta[SPT];
+    long long fx[SPT], fy[SPT], fz[SPT];
+    typename Prec<PREC>::real4 p[SPT];
+    float4 c[SPT];
+    typename Prec<PREC>::mixed4 pd[SPT];
+    int2 rt;                 // this lane's molecule entry (lane r < nres): fetched with the tile, not after the first barrier
+};
 
-    __shared__ double s_scale[MAX_GROUPS + 2];           // velocity scale factors of this launch (80 B: keeps smem 16-B aligned)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    mixed4* sv = reinterpret_cast<mixed4*>(smem);        // [TILE_SLOTS] velocity image
-    mixed4* scom = sv + TILE_SLOTS;                      // [TILE_RES]   molecular COM velocity, w = 1/M
-    mixed4* sx = scom + TILE_RES;                        // [TILE_SLOTS] position image (hard wall only)
+// What a work-group carries through a launch: the LDS carve, its KE accumulators, launch constants.
+template <int PREC, int GB> struct TileEnv {
+    typedef typename Prec<PREC>::mixed mixed;
+    typedef typename Prec<PREC>::mixed4 mixed4;
     // fp64 images are kept component-wise (x[], y[], z[], w[]): a 32-byte double4 per lane is a 2-way bank conflict on
     // every ds_read/ds_write_b128 and on the per-molecule walk (SQ_LDS_BANK_CONFLICT was 48 % of the LDS cycles);
     // 8-byte components at lane stride 8 (or 8 x molecule size) are conflict-free.  float4 images stay packed.
-    constexpr bool SOA = sizeof(mixed) == 8;
-    mixed* svc = reinterpret_cast<mixed*>(sv);
-    mixed* sxc = reinterpret_cast<mixed*>(sx);
-    auto st_img = [&](mixed4* img, mixed* imgc, int i, const mixed4& u) {
+    static constexpr bool SOA = sizeof(mixed) == 8;
+    static constexpr int GBR = GB > 0 ? GB : 1;
+    mixed4* sv;              // [TILE_SLOTS] velocity image
+    mixed4* scom;            // [TILE_RES]   molecular COM velocity, w = 1/M
+    mixed4* sx;              // [TILE_SLOTS] position image (hard wall only)
+    double* s_scale;         // [NT] velocity scale factors of this launch
+    double* wbins0;          // more than 8 groups: one row of fp64 bins per wavefront in LDS, behind the images (GB == 0)
+    char* smem;
+    int tid, G;
+    bool use_com;
+    mixed dt, fscale, s_com, s_drude;
+    double ke_g[GBR], ke_com, ke_drude;
+    __device__ __forceinline__ static void st_img(mixed4* img, int i, const mixed4& u) {
+        mixed* imgc = reinterpret_cast<mixed*>(img);
         if (SOA) { imgc[i] = u.x; imgc[TILE_SLOTS + i] = u.y; imgc[2 * TILE_SLOTS + i] = u.z; imgc[3 * TILE_SLOTS + i] = u.w; }
         else img[i] = u;
-    };
-    auto ld_img = [&](const mixed4* img, const mixed* imgc, int i) -> mixed4 {
+    }
+    __device__ __forceinline__ static mixed4 ld_img(const mixed4* img, int i) {
+        const mixed* imgc = reinterpret_cast<const mixed*>(img);
         if (SOA) return mk4(imgc[i], imgc[TILE_SLOTS + i], imgc[2 * TILE_SLOTS + i], imgc[3 * TILE_SLOTS + i]);
         return img[i];
-    };
-
-    const int tid = threadIdx.x;
-    const bool use_com = a.use_com != 0;
-    const bool hardwall = POS && (a.hardwall != 0);
-    const int G = a.num_groups;
-
-    mixed4* __restrict__ velm = reinterpret_cast<mixed4*>(a.velm);
-    real4* __restrict__ posq = reinterpret_cast<real4*>(a.posq);
-    float4* __restrict__ pcorr = reinterpret_cast<float4*>(a.posq_corr);
-    mixed4* __restrict__ pdelta = reinterpret_cast<mixed4*>(a.pos_delta);
-
-    constexpr int GBR = GB > 0 ? GB : 1;
-    double ke_g[GBR];
-#pragma unroll
-    for (int b = 0; b < GBR; b++) ke_g[b] = 0.0;
-    // more than 8 groups: one row of fp64 bins per wavefront in LDS, behind the images (GB == 0)
-    double* wbins = reinterpret_cast<double*>(sx + (hardwall ? TILE_SLOTS : 0)) + (tid >> 6) * G;
-    if (DO_KE && GB == 0) {
-        for (int g = tid & 63; g < G; g += 64) wbins[g] = 0.0;
     }
-    double ke_com = 0.0, ke_drude = 0.0;
+    __device__ __forceinline__ void init(const TileArgs& a, char* smem_, double* s_scale_, bool hardwall_lds) {
+        smem = smem_; s_scale = s_scale_;
+        sv = reinterpret_cast<mixed4*>(smem); scom = sv + TILE_SLOTS; sx = scom + TILE_RES;
+        tid = threadIdx.x; G = a.num_groups; use_com = a.use_com != 0;
+        dt = (mixed)a.dt;
+        fscale = (mixed)(0.5 * a.dt / 4294967296.0);     // Cu :295
+        s_com = 1; s_drude = 1;
+        wbins0 = reinterpret_cast<double*>(sx + (hardwall_lds ? TILE_SLOTS : 0));
+        clear_ke();
+    }
+    __device__ __forceinline__ void clear_ke() {
+#pragma unroll
+        for (int b = 0; b < GBR; b++) ke_g[b] = 0.0;
+        ke_com = 0.0; ke_drude = 0.0;
+        if (GB == 0) { double* w = wbins0 + (tid >> 6) * G; for (int g = tid & 63; g < G; g += 64) w[g] = 0.0; }
+    }
+};
 
-    const mixed dt = (mixed)a.dt;
-    const mixed fscale = (mixed)(0.5 * a.dt / 4294967296.0);     // Cu :295
+// which arrays a pass touches
+template <int OPS> struct OpsOf {
+    static constexpr bool DO_SCALE = OPS & OP_SCALE, DO_KICK = OPS & OP_KICK, DO_DRIFT = OPS & OP_DRIFT;
+    static constexpr bool DO_KE = OPS & OP_KE, DO_PD = OPS & OP_POSDELTA, DO_MOVE = OPS & OP_MOVE;
+    // OP_PREKICK: the half kick a kick+KE pass of the previous step formed for its sums but did not store
+    // (OP_NOSTORE) is applied first -- same force buffer, same expression, same bits (DESIGN.md "deferred kick")
+    static constexpr bool DO_PREKICK = OPS & OP_PREKICK, NOSTORE = OPS & OP_NOSTORE;
+    static constexpr bool NEED_F = DO_KICK || DO_PREKICK;
+    static constexpr bool POS = DO_DRIFT || DO_MOVE;            // positions are read and written
+    static constexpr bool VEL_W = (DO_SCALE || DO_KICK || DO_MOVE) && !NOSTORE;   // velocities are written
+};
 
-    // Raw register image of one tile's global loads.
-    struct TileIn {
-        int ts, te, rs, nres;
-        mixed4 v[SPT];
-        uint32_t meta[SPT];
-        long long fx[SPT], fy[SPT], fz[SPT];
-        real4 p[SPT];
-        float4 c[SPT];
-        mixed4 pd[SPT];
-        int2 rt;                 // this lane's molecule entry (lane r < nres): fetched with the tile, not after the first barrier
-    };
-    auto load_tile = [&](int tt, TileIn& in) {
-        const int t = a.reverse ? a.num_tiles - 1 - tt : tt;
+// issue the global loads of tile t for a pass with operations OPS (KEEP_VF: velocities, meta and forces are already in `in`)
+template <int PREC, int OPS, bool KEEP_VF = false>
+__device__ __forceinline__ void tile_load(const TileArgs& a, const int t, TileIn<PREC>& in) {
+    typedef typename Prec<PREC>::mixed mixed;
+    typedef typename Prec<PREC>::real4 real4;
+    typedef typename Prec<PREC>::mixed4 mixed4;
+    typedef OpsOf<OPS> O;
+    const int tid = threadIdx.x;
+    const mixed4* __restrict__ velm = reinterpret_cast<const mixed4*>(a.velm);
+    const real4* __restrict__ posq = reinterpret_cast<const real4*>(a.posq);
+    const float4* __restrict__ pcorr = reinterpret_cast<const float4*>(a.posq_corr);
+    const mixed4* __restrict__ pdelta = reinterpret_cast<const mixed4*>(a.pos_delta);
+    if (!KEEP_VF) {
         in.ts = a.tile_start[t]; in.te = a.tile_start[t + 1];
         in.rs = a.tile_res[t]; in.nres = a.tile_res[t + 1] - in.rs;
-        if ((DO_SCALE || DO_KE) && a.use_com && tid < in.nres) in.rt = a.res_table[in.rs + tid];
+        if ((O::DO_SCALE || O::DO_KE) && a.use_com && tid < in.nres) in.rt = a.res_table[in.rs + tid];
+    }
 #pragma unroll
-        for (int k = 0; k < SPT; k++) {
-            const int idx = in.ts + k * TBLOCK + tid;
-            if (idx < in.te) {
+    for (int k = 0; k < SPT; k++) {
+        const int idx = in.ts + k * TBLOCK + tid;
+        if (idx < in.te) {
+            if (!KEEP_VF) {
                 in.v[k] = velm[idx];
                 in.meta[k] = a.meta[idx];
-                if (NEED_F) {
+                if (O::NEED_F) {
                     in.fx[k] = a.force[idx];
                     in.fy[k] = a.force[idx + a.padded];
                     in.fz[k] = a.force[idx + 2 * a.padded];
                 }
-                if (POS) {
-                    in.p[k] = posq[idx];
-                    if (PREC == TGNH_PREC_MIXED) in.c[k] = pcorr[idx];       // K :443-445
-                }
-                if (DO_MOVE) in.pd[k] = pdelta[idx];
-            } else {
-                in.v[k] = mk4((mixed)0, (mixed)0, (mixed)0, (mixed)0);       // w = 0: treated as massless, never stored
-                in.meta[k] = 0u;
+            }
+            if (O::POS) {
+                in.p[k] = posq[idx];
+                if (PREC == TGNH_PREC_MIXED) in.c[k] = pcorr[idx];       // K :443-445
+            }
+            if (O::DO_MOVE) in.pd[k] = pdelta[idx];
+        } else if (!KEEP_VF) {
+            in.v[k] = mk4((mixed)0, (mixed)0, (mixed)0, (mixed)0);       // w = 0: treated as massless, never stored
+            in.meta[k] = 0u;
+        }
+    }
+}
+
+// One tile, loaded into `cur`, through the operations OPS (A3/A4, A6, A7, A8, A10).  Ends with the LDS images free.
+// REUSE_IMG (step_kernel): the velocity image and the COM table of this very tile are still in LDS from the pass before.
+template <int PREC, int OPS, int GB, bool REUSE_IMG = false>
+__device__ __forceinline__ void tile_body(const TileArgs& a, TileEnv<PREC, GB>& e, const TileIn<PREC>& cur, const int trace_tile) {
+    typedef typename Prec<PREC>::real real;
+    typedef typename Prec<PREC>::mixed mixed;
+    typedef typename Prec<PREC>::real4 real4;
+    typedef typename Prec<PREC>::mixed4 mixed4;
+    typedef OpsOf<OPS> O;
+    typedef TileEnv<PREC, GB> E;
+    constexpr bool DO_SCALE = O::DO_SCALE, DO_KICK = O::DO_KICK, DO_DRIFT = O::DO_DRIFT, DO_KE = O::DO_KE, DO_PD = O::DO_PD;
+    constexpr bool DO_MOVE = O::DO_MOVE, DO_PREKICK = O::DO_PREKICK, NEED_F = O::NEED_F, POS = O::POS, VEL_W = O::VEL_W;
+    (void)trace_tile;
+    mixed4* const sv = e.sv; mixed4* const scom = e.scom; mixed4* const sx = e.sx;
+    const double* const s_scale = e.s_scale;
+    const int tid = e.tid, G = e.G;
+    const bool use_com = e.use_com;
+    const bool hardwall = POS && (a.hardwall != 0);
+    const mixed dt = e.dt, fscale = e.fscale, s_com = e.s_com, s_drude = e.s_drude;
+    double (&ke_g)[E::GBR] = e.ke_g;
+    double& ke_com = e.ke_com; double& ke_drude = e.ke_drude;
+    double* const wbins = e.wbins0 + (tid >> 6) * G;
+    mixed4* __restrict__ velm = reinterpret_cast<mixed4*>(a.velm);
+    real4* __restrict__ posq = reinterpret_cast<real4*>(a.posq);
+    float4* __restrict__ pcorr = reinterpret_cast<float4*>(a.posq_corr);
+    mixed4* __restrict__ pdelta = reinterpret_cast<mixed4*>(a.pos_delta);
+    auto st_img = [&](mixed4* img, int i, const mixed4& u) { E::st_img(img, i, u); };
+    auto ld_img = [&](const mixed4* img, int i) -> mixed4 { return E::ld_img(img, i); };
+    (void)G; (void)s_com; (void)s_drude; (void)dt; (void)fscale; (void)wbins; (void)ke_com; (void)ke_drude; (void)ke_g;
+    (void)posq; (void)pcorr; (void)pdelta; (void)velm; (void)s_scale;
+
+    const int ts = cur.ts, te = cur.te;
+    const int rs = cur.rs, nres = cur.nres;
+    TRACE_WAIT(); TRACE(3 + 4 * trace_tile);
+
+    mixed4 v[SPT];
+    uint32_t meta[SPT];
+    long long fx[SPT], fy[SPT], fz[SPT];
+    mixed px[SPT], py[SPT], pz[SPT];
+    real pq[SPT];
+    mixed4 pd[SPT];
+    bool ok[SPT];
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+        ok[k] = ts + k * TBLOCK + tid < te;
+        v[k] = cur.v[k];
+        meta[k] = cur.meta[k];
+        if (NEED_F) { fx[k] = cur.fx[k]; fy[k] = cur.fy[k]; fz[k] = cur.fz[k]; }
+        if (POS) {
+            px[k] = cur.p[k].x; py[k] = cur.p[k].y; pz[k] = cur.p[k].z; pq[k] = cur.p[k].w;
+            if (PREC == TGNH_PREC_MIXED) { px[k] += (mixed)cur.c[k].x; py[k] += (mixed)cur.c[k].y; pz[k] += (mixed)cur.c[k].z; }
+        }
+        if (DO_MOVE) pd[k] = cur.pd[k];
+    }
+    // One fp64 division per slot: the mass.  The LDS images carry it in .w (0 = massless), so the per-molecule walk
+    // and the pair arithmetic multiply by masses instead of dividing by inverse masses again (K forms RECIP(w) in
+    // every kernel; an fp64 reciprocal is ~15 VALU instructions and these launches are VALU-heavy at small sizes).
+    mixed mass[SPT];
+#pragma unroll
+    for (int k = 0; k < SPT; k++) mass[k] = v[k].w != 0 ? rcp_(v[k].w) : (mixed)0;
+    if (DO_PREKICK) {                                            // the pending half kick (A7), as below
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            if (v[k].w != 0) {
+                const mixed c = fscale * v[k].w;
+                v[k].x += c * (mixed)fx[k];
+                v[k].y += c * (mixed)fy[k];
+                v[k].z += c * (mixed)fz[k];
             }
         }
-    };
+    }
+    auto img = [&](int k) { return mk4(v[k].x, v[k].y, v[k].z, mass[k]); };
 
-    TileIn cur;
+    bool lds_read = false;   // some lane may still be reading sv/scom of this tile
+
+    // ---------------- A6: rescale (K :249-301 ; Ref :516-541) ----------------
+    if (DO_SCALE) {
+      if (!REUSE_IMG) {
+#pragma unroll
+        for (int k = 0; k < SPT; k++) st_img(sv, k * TBLOCK + tid, img(k));
+        __syncthreads();
+        if (use_com) {
+            for (int r = tid; r < nres; r += TBLOCK) {            // K :86-111
+                const int2 rt = r == tid ? cur.rt : a.res_table[rs + r];
+                if (rt.x < 0) { scom[r] = reinterpret_cast<const mixed4*>(a.big_com)[-rt.x - 1]; continue; }   // molecule longer than a tile
+                const int first = rt.y - ts;
+                mixed cx = 0, cy = 0, cz = 0, cm = 0;
+                for (int j = 0; j < rt.x; j++) {
+                    const mixed4 u = ld_img(sv, first + j);
+                    const mixed m = u.w;                       // mass (0 for massless sites)
+                    cx += u.x * m; cy += u.y * m; cz += u.z * m; cm += m;
+                }
+                const mixed w = rcp_(cm);
+                scom[r] = mk4(cx * w, cy * w, cz * w, w);
+            }
+            __syncthreads();
+        }
+      }
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            const uint32_t m = meta[k];
+            const uint32_t role = m & 3u, g = (m >> 2) & 255u;
+            mixed cx = 0, cy = 0, cz = 0;
+            if (use_com) { const mixed4 c = scom[m >> 21]; cx = c.x; cy = c.y; cz = c.z; }
+            const mixed s_g = (mixed)s_scale[g];
+            if (role == ROLE_NORMAL) {
+                if (v[k].w != 0) {                               // K :260-265
+                    const mixed rx = v[k].x - cx, ry = v[k].y - cy, rz = v[k].z - cz;
+                    v[k].x = s_g * rx + s_com * (v[k].x - rx);
+                    v[k].y = s_g * ry + s_com * (v[k].y - ry);
+                    v[k].z = s_g * rz + s_com * (v[k].z - rz);
+                }
+            } else {                                             // K :270-300
+                // Written from the lane's own point of view (self s, partner p), which needs no role selects:
+                // with cm = (r_s m_s + r_p m_p)/M and K's rel = r_parent - r_drude, both
+                //   v_drude'  = s_g cm - s_D rel m_parent/M + s_COM v_com      (K :292-294)
+                //   v_parent' = s_g cm + s_D rel m_drude/M  + s_COM v_com      (K :295-297)
+                // read  v_s' = s_g cm + s_D (r_s - r_p) m_p/M + s_COM (v_s - r_s).
+                const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
+                const mixed4 u = ld_img(sv, pl);           // partner velocity, .w = partner mass
+                const mixed rsx = v[k].x - cx, rsy = v[k].y - cy, rsz = v[k].z - cz;
+                const mixed rpx = u.x - cx, rpy = u.y - cy, rpz = u.z - cz;
+                const mixed invTot = rcp_(mass[k] + u.w);
+                const mixed msf = invTot * mass[k], mpf = invTot * u.w;
+                const mixed sdp = s_drude * mpf;
+                v[k].x = s_g * (rsx * msf + rpx * mpf) + sdp * (rsx - rpx) + s_com * (v[k].x - rsx);
+                v[k].y = s_g * (rsy * msf + rpy * mpf) + sdp * (rsy - rpy) + s_com * (v[k].y - rsy);
+                v[k].z = s_g * (rsz * msf + rpz * mpf) + sdp * (rsz - rpz) + s_com * (v[k].z - rsz);
+            }
+        }
+        lds_read = true;
+    }
+
+    TRACE(4 + 4 * trace_tile);
+    // ---------------- A8 (constrained path): x += posDelta, v = posDelta/dt (K :435-466) ---
+    if (DO_MOVE) {
+        const double invStep = 1.0 / a.dt;                       // K :436
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            if (v[k].w != 0) {
+                px[k] += pd[k].x; py[k] += pd[k].y; pz[k] += pd[k].z;
+                v[k].x = (mixed)(invStep * pd[k].x);
+                v[k].y = (mixed)(invStep * pd[k].y);
+                v[k].z = (mixed)(invStep * pd[k].z);
+            }
+        }
+    }
+
+    // ---------------- A7: half kick (K :307-365 ; Ref :548-584) ----------------
+    // Per-particle form v += (dt/2) F/m.  The reference writes the pair kick in
+    // COM/relative coordinates; that is algebraically the same update
+    // (tests/test_oracle.py::test_pair_kick_identity), so no partner access is needed here.
+    if (DO_KICK) {
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            if (v[k].w != 0) {
+                const mixed c = fscale * v[k].w;
+                v[k].x += c * (mixed)fx[k];
+                v[k].y += c * (mixed)fy[k];
+                v[k].z += c * (mixed)fz[k];
+            }
+        }
+    }
+
+    // ---------------- A8: drift (Ref :253-258 ; K :322-324, :450-452) ----------------
+    if (DO_DRIFT) {
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            if (v[k].w != 0) {
+                px[k] += dt * v[k].x; py[k] += dt * v[k].y; pz[k] += dt * v[k].z;
+            }
+        }
+    }
+    if (DO_PD) {
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            const int idx = ts + k * TBLOCK + tid;
+            if (ok[k]) {
+                const bool mv = v[k].w != 0;
+                pdelta[idx] = mk4(mv ? dt * v[k].x : (mixed)0, mv ? dt * v[k].y : (mixed)0, mv ? dt * v[k].z : (mixed)0, (mixed)0);
+            }
+        }
+    }
+
+    // ---------------- A10: hard wall (K :471-574 ; Ref :298-363) ----------------
+    if (POS && hardwall) {
+        if (lds_read) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            st_img(sv, k * TBLOCK + tid, img(k));
+            st_img(sx, k * TBLOCK + tid, mk4(px[k], py[k], pz[k], (mixed)0));
+        }
+        __syncthreads();
+        const mixed maxd = (mixed)a.max_dist, hws = (mixed)a.hw_scale;
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            const uint32_t m = meta[k];
+            const uint32_t role = m & 3u;
+            if (role != ROLE_NORMAL) {
+                const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
+                const mixed4 ux = ld_img(sx, pl);
+                const mixed sxd = px[k] - ux.x, syd = py[k] - ux.y, szd = pz[k] - ux.z;     // self - partner
+                const mixed d2 = sxd * sxd + syd * syd + szd * szd;
+                if (d2 > maxd * maxd) {                           // r > max  <=>  rInv*max < 1 (K :490): the rest only for violators
+                    const mixed4 uv = ld_img(sv, pl);
+                    const bool is_d = role == ROLE_DRUDE;
+                    const mixed4 vel1 = is_d ? v[k] : uv, vel2 = is_d ? uv : v[k];
+                    const mixed dx = is_d ? sxd : -sxd, dy = is_d ? syd : -syd, dz = is_d ? szd : -szd;   // Drude - parent (K :487)
+                    const mixed r = sqrt_(d2);
+                    const mixed rInv = rcp_(r);
+                    if (rInv * maxd < (mixed)0.5) atomicOr(a.status, 1u);     // Ref :311-312
+                    const mixed bx = dx * rInv, by = dy * rInv, bz = dz * rInv;
+                    const mixed mass1 = is_d ? mass[k] : uv.w, mass2 = is_d ? uv.w : mass[k];   // image .w = mass
+                    const mixed deltaR = r - maxd;
+                    mixed deltaT = dt;
+                    mixed dotvr1 = vel1.x * bx + vel1.y * by + vel1.z * bz;
+                    const mixed vp1x = vel1.x - bx * dotvr1, vp1y = vel1.y - by * dotvr1, vp1z = vel1.z - bz * dotvr1;
+                    // K :527-571 (a massless parent, K :504-526, cannot occur: tgnh_create rejects massless pair members)
+                    const mixed invTot = rcp_(mass1 + mass2);
+                    mixed dotvr2 = vel2.x * bx + vel2.y * by + vel2.z * bz;
+                    const mixed vp2x = vel2.x - bx * dotvr2, vp2y = vel2.y - by * dotvr2, vp2z = vel2.z - bz * dotvr2;
+                    const mixed vbCMass = (mass1 * dotvr1 + mass2 * dotvr2) * invTot;
+                    dotvr1 -= vbCMass;
+                    dotvr2 -= vbCMass;
+                    if (dotvr1 != dotvr2) deltaT = deltaR / abs_(dotvr1 - dotvr2);
+                    if (deltaT > dt) deltaT = dt;
+                    const mixed vBond = hws / sqrt_(mass1);
+                    dotvr1 = -dotvr1 * vBond * mass2 * invTot / abs_(dotvr1);
+                    dotvr2 = -dotvr2 * vBond * mass1 * invTot / abs_(dotvr2);
+                    const mixed dr1 = -deltaR * mass2 * invTot + deltaT * dotvr1;
+                    const mixed dr2 = deltaR * mass1 * invTot + deltaT * dotvr2;
+                    dotvr1 += vbCMass;
+                    dotvr2 += vbCMass;
+                    if (is_d) {
+                        px[k] += bx * dr1; py[k] += by * dr1; pz[k] += bz * dr1;
+                        v[k].x = vp1x + bx * dotvr1; v[k].y = vp1y + by * dotvr1; v[k].z = vp1z + bz * dotvr1;
+                    } else {
+                        px[k] += bx * dr2; py[k] += by * dr2; pz[k] += bz * dr2;
+                        v[k].x = vp2x + bx * dotvr2; v[k].y = vp2y + by * dotvr2; v[k].z = vp2z + bz * dotvr2;
+                    }
+                }
+            }
+        }
+        lds_read = true;
+    }
+
+    TRACE(5 + 4 * trace_tile);
+    // ---------------- stores ----------------
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+        const int idx = ts + k * TBLOCK + tid;
+        if (ok[k]) {
+            if (VEL_W || (POS && hardwall)) velm[idx] = v[k];
+            if (POS) {
+                if (PREC == TGNH_PREC_MIXED) {                   // K :457-458
+                    const float hx = (float)px[k], hy = (float)py[k], hz = (float)pz[k];
+                    posq[idx] = mk4((real)hx, (real)hy, (real)hz, pq[k]);
+                    pcorr[idx] = make_float4((float)(px[k] - hx), (float)(py[k] - hy), (float)(pz[k] - hz), 0.0f);
+                } else {
+                    posq[idx] = mk4((real)px[k], (real)py[k], (real)pz[k], pq[k]);
+                }
+            }
+        }
+    }
+
+    // ---------------- A3/A4: kinetic energies (K :82-200 ; Ref :439-460) ----------------
+    if (DO_KE) {
+        if (lds_read) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SPT; k++) st_img(sv, k * TBLOCK + tid, img(k));
+        __syncthreads();
+        if (use_com) {
+            for (int r = tid; r < nres; r += TBLOCK) {            // K :86-111, :152-158
+                const int2 rt = r == tid ? cur.rt : a.res_table[rs + r];
+                if (rt.x < 0) { scom[r] = reinterpret_cast<const mixed4*>(a.big_com)[-rt.x - 1]; continue; }   // its M v_com^2 comes from big_com_kernel
+                const int first = rt.y - ts;
+                mixed cx = 0, cy = 0, cz = 0, cm = 0;
+                for (int j = 0; j < rt.x; j++) {
+                    const mixed4 u = ld_img(sv, first + j);
+                    const mixed m = u.w;                       // mass (0 for massless sites)
+                    cx += u.x * m; cy += u.y * m; cz += u.z * m; cm += m;
+                }
+                const mixed w = rcp_(cm);
+                cx *= w; cy *= w; cz *= w;
+                scom[r] = mk4(cx, cy, cz, w);
+                ke_com += ((double)cx * cx + (double)cy * cy + (double)cz * cz) * (double)cm;     // M v_com^2 (K :154)
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            const uint32_t m = meta[k];
+            const uint32_t role = m & 3u, g = (m >> 2) & 255u;
+            double cx = 0, cy = 0, cz = 0;
+            if (use_com) { const mixed4 c = scom[m >> 21]; cx = c.x; cy = c.y; cz = c.z; }
+            double val = 0.0;
+            if (role == ROLE_NORMAL) {
+                if (v[k].w != 0) {                               // K :161-168
+                    const double rx = v[k].x - cx, ry = v[k].y - cy, rz = v[k].z - cz;
+                    val = (rx * rx + ry * ry + rz * rz) * (double)mass[k];
+                }
+            } else if (role == ROLE_DRUDE) {                     // K :171-186 (one lane per pair)
+                const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
+                const mixed4 u = ld_img(sv, pl);
+                const double r1x = v[k].x - cx, r1y = v[k].y - cy, r1z = v[k].z - cz;
+                const double r2x = u.x - cx, r2y = u.y - cy, r2z = u.z - cz;
+                const double mass1 = mass[k], mass2 = u.w;               // image .w = mass
+                const double invTot = rcp_(mass1 + mass2);
+                const double m1f = invTot * mass1, m2f = invTot * mass2;
+                const double cmx = r1x * m1f + r2x * m2f, cmy = r1y * m1f + r2y * m2f, cmz = r1z * m1f + r2z * m2f;
+                const double rlx = r2x - r1x, rly = r2y - r1y, rlz = r2z - r1z;
+                val = (cmx * cmx + cmy * cmy + cmz * cmz) * (mass1 + mass2);
+                ke_drude += (rlx * rlx + rly * rly + rlz * rlz) * (mass1 * mass2 * invTot);   // reduced mass = 1/invReducedMass (K :178, :185)
+            }
+            if constexpr (GB > 0) {
+#pragma unroll
+                for (int b = 0; b < GB; b++) ke_g[b] += (g == (uint32_t)b) ? val : 0.0;
+            } else {
+                // one pass per distinct group present in this wavefront (usually 1-3): butterfly-sum the lanes of
+                // that group, lane 0 adds the sum to the wave's LDS bin.  The order depends on the data only.
+                const bool has = role == ROLE_DRUDE || (role == ROLE_NORMAL && v[k].w != 0);
+                unsigned long long rem = __ballot(has);
+                while (rem) {
+                    const int src = __ffsll((long long)rem) - 1;
+                    const uint32_t g0 = __shfl(g, src, 64);
+                    const bool mine = has && g == g0;
+                    const double sg = wave_sum(mine ? val : 0.0);
+                    if ((tid & 63) == 0) wbins[g0] += sg;
+                    rem &= ~__ballot(mine);
+                }
+            }
+        }
+        lds_read = true;
+    }
+    if (lds_read) __syncthreads();       // LDS image is reused by the next tile
+}
+
+// Work-group reduction of the fp64 KE bins: 64-lane butterflies, then one LDS hop; one row of `partials` per work-group.
+// TAGGED: the row is read by another work-group of the SAME launch (step_kernel): every sum goes out as a cell of two
+// 8-byte words {32 bits of the double, tag} into a.rows -- data and "it is there" in one atomic store, as in the mailboxes.
+template <int PREC, int GB, bool TAGGED>
+__device__ __forceinline__ void ke_reduce(const TileArgs& a, TileEnv<PREC, GB>& e, const unsigned tag = 0u, double* scratch = nullptr) {
+    typedef TileEnv<PREC, GB> E;
+    const int tid = e.tid, G = e.G;
+    double (&ke_g)[E::GBR] = e.ke_g;
+    double ke_com = e.ke_com, ke_drude = e.ke_drude;
+    auto put = [&](double* p, double v) {
+        if (TAGGED) {
+            unsigned long long* cell = a.rows + (size_t)(p - a.partials) * 2;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
+            __hip_atomic_store(cell, t | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(cell + 1, t | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else *p = v;
+    };
+    double* sred = scratch ? scratch : reinterpret_cast<double*>(e.smem);   // [TBLOCK/64][GB+2]
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int b = 0; b < GB; b++) ke_g[b] = wave_sum(ke_g[b]);
+    if (GB == 0) __syncthreads();                                // every wave's LDS bins are final
+    ke_com = wave_sum(ke_com);
+    ke_drude = wave_sum(ke_drude);
+    if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < GB; b++) sred[wv * (GB + 2) + b] = ke_g[b];
+        sred[wv * (GB + 2) + GB] = ke_com;
+        sred[wv * (GB + 2) + GB + 1] = ke_drude;
+    }
+    __syncthreads();
+    if (tid < GB + 2) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < TBLOCK / 64; w++) s += sred[w * (GB + 2) + tid];   // fixed order
+        const int NT = G + 2;
+        if (tid < GB) { if (tid < G) put(&a.partials[(size_t)blockIdx.x * NT + tid], s); }
+        else put(&a.partials[(size_t)blockIdx.x * NT + G + (tid - GB)], s);
+    }
+    if (GB == 0) {
+        const double* w0 = e.wbins0;
+        for (int g = tid; g < G; g += TBLOCK) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < TBLOCK / 64; w++) s += w0[w * G + g];     // fixed order
+            put(&a.partials[(size_t)blockIdx.x * (G + 2) + g], s);
+        }
+    }
+}
+
+template <int PREC, int OPS, int GB>
+__global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileArgs a) {
+    typedef typename Prec<PREC>::mixed mixed;
+    typedef OpsOf<OPS> O;
+    constexpr bool DO_SCALE = O::DO_SCALE, DO_KE = O::DO_KE, POS = O::POS;
+
+    __shared__ double s_scale[MAX_GROUPS + 2];           // velocity scale factors of this launch (80 B: keeps smem 16-B aligned)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int G = a.num_groups;
+    TileEnv<PREC, GB> e;
+    e.init(a, smem, s_scale, POS && a.hardwall != 0);
+    auto load_tile = [&](int tt, TileIn<PREC>& in) { tile_load<PREC, OPS>(a, a.reverse ? a.num_tiles - 1 - tt : tt, in); };
+
+    TileIn<PREC> cur;
     TRACE(0);
     if (a.commit_len > 0 && blockIdx.x == 0) {            // take over the thermostat block an in-kernel chain staged
         for (int i = tid; i < a.commit_len; i += TBLOCK)
@@ -200,7 +616,6 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
     // three wavefronts' loads.  (Wavefront 0 everywhere: the dispatcher starts consecutive work-groups of a compute
     // unit on consecutive SIMDs -- HW_ID, tools/trace_probe.py -- so the resident chains already sit on different
     // SIMDs; rotating the wavefront by residency slot made two of three collide.)
-    mixed s_com = 1, s_drude = 1;
     const bool chain_wave = DO_SCALE && a.chain_on && tid < 64;
     const bool have_tile = (int)blockIdx.x < a.num_tiles;
     // sum_rows == 2 (many partial rows, no chain launch): ALL four wavefronts read a quarter of the rows each, in
@@ -292,353 +707,178 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
             s_scale[tid] = a.scale[tid];
         }
         __syncthreads();
-        s_com = (mixed)s_scale[G]; s_drude = (mixed)s_scale[G + 1];
+        e.s_com = (mixed)s_scale[G]; e.s_drude = (mixed)s_scale[G + 1];
     }
     TRACE(2);
     for (int t = blockIdx.x; t < a.num_tiles; t += gridDim.x) {
         const bool more = t + (int)gridDim.x < a.num_tiles;
-        const int ts = cur.ts, te = cur.te;
-        const int rs = cur.rs, nres = cur.nres;
-        TRACE_WAIT(); TRACE(3 + 4 * trace_tile);
-
-        mixed4 v[SPT];
-        uint32_t meta[SPT];
-        long long fx[SPT], fy[SPT], fz[SPT];
-        mixed px[SPT], py[SPT], pz[SPT];
-        real pq[SPT];
-        mixed4 pd[SPT];
-        bool ok[SPT];
-#pragma unroll
-        for (int k = 0; k < SPT; k++) {
-            ok[k] = ts + k * TBLOCK + tid < te;
-            v[k] = cur.v[k];
-            meta[k] = cur.meta[k];
-            if (NEED_F) { fx[k] = cur.fx[k]; fy[k] = cur.fy[k]; fz[k] = cur.fz[k]; }
-            if (POS) {
-                px[k] = cur.p[k].x; py[k] = cur.p[k].y; pz[k] = cur.p[k].z; pq[k] = cur.p[k].w;
-                if (PREC == TGNH_PREC_MIXED) { px[k] += (mixed)cur.c[k].x; py[k] += (mixed)cur.c[k].y; pz[k] += (mixed)cur.c[k].z; }
-            }
-            if (DO_MOVE) pd[k] = cur.pd[k];
-        }
-        // One fp64 division per slot: the mass.  The LDS images carry it in .w (0 = massless), so the per-molecule walk
-        // and the pair arithmetic multiply by masses instead of dividing by inverse masses again (K forms RECIP(w) in
-        // every kernel; an fp64 reciprocal is ~15 VALU instructions and these launches are VALU-heavy at small sizes).
-        mixed mass[SPT];
-#pragma unroll
-        for (int k = 0; k < SPT; k++) mass[k] = v[k].w != 0 ? rcp_(v[k].w) : (mixed)0;
-        if (DO_PREKICK) {                                            // the pending half kick (A7), as below
-#pragma unroll
-            for (int k = 0; k < SPT; k++) {
-                if (v[k].w != 0) {
-                    const mixed c = fscale * v[k].w;
-                    v[k].x += c * (mixed)fx[k];
-                    v[k].y += c * (mixed)fy[k];
-                    v[k].z += c * (mixed)fz[k];
-                }
-            }
-        }
-        auto img = [&](int k) { return mk4(v[k].x, v[k].y, v[k].z, mass[k]); };
-
-        bool lds_read = false;   // some lane may still be reading sv/scom of this tile
-
-        // ---------------- A6: rescale (K :249-301 ; Ref :516-541) ----------------
-        if (DO_SCALE) {
-#pragma unroll
-            for (int k = 0; k < SPT; k++) st_img(sv, svc, k * TBLOCK + tid, img(k));
-            __syncthreads();
-            if (use_com) {
-                for (int r = tid; r < nres; r += TBLOCK) {            // K :86-111
-                    const int2 rt = r == tid ? cur.rt : a.res_table[rs + r];
-                    if (rt.x < 0) { scom[r] = reinterpret_cast<const mixed4*>(a.big_com)[-rt.x - 1]; continue; }   // molecule longer than a tile
-                    const int first = rt.y - ts;
-                    mixed cx = 0, cy = 0, cz = 0, cm = 0;
-                    for (int j = 0; j < rt.x; j++) {
-                        const mixed4 u = ld_img(sv, svc, first + j);
-                        const mixed m = u.w;                       // mass (0 for massless sites)
-                        cx += u.x * m; cy += u.y * m; cz += u.z * m; cm += m;
-                    }
-                    const mixed w = rcp_(cm);
-                    scom[r] = mk4(cx * w, cy * w, cz * w, w);
-                }
-                __syncthreads();
-            }
-#pragma unroll
-            for (int k = 0; k < SPT; k++) {
-                const uint32_t m = meta[k];
-                const uint32_t role = m & 3u, g = (m >> 2) & 255u;
-                mixed cx = 0, cy = 0, cz = 0;
-                if (use_com) { const mixed4 c = scom[m >> 21]; cx = c.x; cy = c.y; cz = c.z; }
-                const mixed s_g = (mixed)s_scale[g];
-                if (role == ROLE_NORMAL) {
-                    if (v[k].w != 0) {                               // K :260-265
-                        const mixed rx = v[k].x - cx, ry = v[k].y - cy, rz = v[k].z - cz;
-                        v[k].x = s_g * rx + s_com * (v[k].x - rx);
-                        v[k].y = s_g * ry + s_com * (v[k].y - ry);
-                        v[k].z = s_g * rz + s_com * (v[k].z - rz);
-                    }
-                } else {                                             // K :270-300
-                    // Written from the lane's own point of view (self s, partner p), which needs no role selects:
-                    // with cm = (r_s m_s + r_p m_p)/M and K's rel = r_parent - r_drude, both
-                    //   v_drude'  = s_g cm - s_D rel m_parent/M + s_COM v_com      (K :292-294)
-                    //   v_parent' = s_g cm + s_D rel m_drude/M  + s_COM v_com      (K :295-297)
-                    // read  v_s' = s_g cm + s_D (r_s - r_p) m_p/M + s_COM (v_s - r_s).
-                    const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
-                    const mixed4 u = ld_img(sv, svc, pl);           // partner velocity, .w = partner mass
-                    const mixed rsx = v[k].x - cx, rsy = v[k].y - cy, rsz = v[k].z - cz;
-                    const mixed rpx = u.x - cx, rpy = u.y - cy, rpz = u.z - cz;
-                    const mixed invTot = rcp_(mass[k] + u.w);
-                    const mixed msf = invTot * mass[k], mpf = invTot * u.w;
-                    const mixed sdp = s_drude * mpf;
-                    v[k].x = s_g * (rsx * msf + rpx * mpf) + sdp * (rsx - rpx) + s_com * (v[k].x - rsx);
-                    v[k].y = s_g * (rsy * msf + rpy * mpf) + sdp * (rsy - rpy) + s_com * (v[k].y - rsy);
-                    v[k].z = s_g * (rsz * msf + rpz * mpf) + sdp * (rsz - rpz) + s_com * (v[k].z - rsz);
-                }
-            }
-            lds_read = true;
-        }
-
-        TRACE(4 + 4 * trace_tile);
-        // ---------------- A8 (constrained path): x += posDelta, v = posDelta/dt (K :435-466) ---
-        if (DO_MOVE) {
-            const double invStep = 1.0 / a.dt;                       // K :436
-#pragma unroll
-            for (int k = 0; k < SPT; k++) {
-                if (v[k].w != 0) {
-                    px[k] += pd[k].x; py[k] += pd[k].y; pz[k] += pd[k].z;
-                    v[k].x = (mixed)(invStep * pd[k].x);
-                    v[k].y = (mixed)(invStep * pd[k].y);
-                    v[k].z = (mixed)(invStep * pd[k].z);
-                }
-            }
-        }
-
-        // ---------------- A7: half kick (K :307-365 ; Ref :548-584) ----------------
-        // Per-particle form v += (dt/2) F/m.  The reference writes the pair kick in
-        // COM/relative coordinates; that is algebraically the same update
-        // (tests/test_oracle.py::test_pair_kick_identity), so no partner access is needed here.
-        if (DO_KICK) {
-#pragma unroll
-            for (int k = 0; k < SPT; k++) {
-                if (v[k].w != 0) {
-                    const mixed c = fscale * v[k].w;
-                    v[k].x += c * (mixed)fx[k];
-                    v[k].y += c * (mixed)fy[k];
-                    v[k].z += c * (mixed)fz[k];
-                }
-            }
-        }
-
-        // ---------------- A8: drift (Ref :253-258 ; K :322-324, :450-452) ----------------
-        if (DO_DRIFT) {
-#pragma unroll
-            for (int k = 0; k < SPT; k++) {
-                if (v[k].w != 0) {
-                    px[k] += dt * v[k].x; py[k] += dt * v[k].y; pz[k] += dt * v[k].z;
-                }
-            }
-        }
-        if (DO_PD) {
-#pragma unroll
-            for (int k = 0; k < SPT; k++) {
-                const int idx = ts + k * TBLOCK + tid;
-                if (ok[k]) {
-                    const bool mv = v[k].w != 0;
-                    pdelta[idx] = mk4(mv ? dt * v[k].x : (mixed)0, mv ? dt * v[k].y : (mixed)0, mv ? dt * v[k].z : (mixed)0, (mixed)0);
-                }
-            }
-        }
-
-        // ---------------- A10: hard wall (K :471-574 ; Ref :298-363) ----------------
-        if (POS && hardwall) {
-            if (lds_read) __syncthreads();
-#pragma unroll
-            for (int k = 0; k < SPT; k++) {
-                st_img(sv, svc, k * TBLOCK + tid, img(k));
-                st_img(sx, sxc, k * TBLOCK + tid, mk4(px[k], py[k], pz[k], (mixed)0));
-            }
-            __syncthreads();
-            const mixed maxd = (mixed)a.max_dist, hws = (mixed)a.hw_scale;
-#pragma unroll
-            for (int k = 0; k < SPT; k++) {
-                const uint32_t m = meta[k];
-                const uint32_t role = m & 3u;
-                if (role != ROLE_NORMAL) {
-                    const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
-                    const mixed4 ux = ld_img(sx, sxc, pl);
-                    const mixed sxd = px[k] - ux.x, syd = py[k] - ux.y, szd = pz[k] - ux.z;     // self - partner
-                    const mixed d2 = sxd * sxd + syd * syd + szd * szd;
-                    if (d2 > maxd * maxd) {                           // r > max  <=>  rInv*max < 1 (K :490): the rest only for violators
-                        const mixed4 uv = ld_img(sv, svc, pl);
-                        const bool is_d = role == ROLE_DRUDE;
-                        const mixed4 vel1 = is_d ? v[k] : uv, vel2 = is_d ? uv : v[k];
-                        const mixed dx = is_d ? sxd : -sxd, dy = is_d ? syd : -syd, dz = is_d ? szd : -szd;   // Drude - parent (K :487)
-                        const mixed r = sqrt_(d2);
-                        const mixed rInv = rcp_(r);
-                        if (rInv * maxd < (mixed)0.5) atomicOr(a.status, 1u);     // Ref :311-312
-                        const mixed bx = dx * rInv, by = dy * rInv, bz = dz * rInv;
-                        const mixed mass1 = is_d ? mass[k] : uv.w, mass2 = is_d ? uv.w : mass[k];   // image .w = mass
-                        const mixed deltaR = r - maxd;
-                        mixed deltaT = dt;
-                        mixed dotvr1 = vel1.x * bx + vel1.y * by + vel1.z * bz;
-                        const mixed vp1x = vel1.x - bx * dotvr1, vp1y = vel1.y - by * dotvr1, vp1z = vel1.z - bz * dotvr1;
-                        // K :527-571 (a massless parent, K :504-526, cannot occur: tgnh_create rejects massless pair members)
-                        const mixed invTot = rcp_(mass1 + mass2);
-                        mixed dotvr2 = vel2.x * bx + vel2.y * by + vel2.z * bz;
-                        const mixed vp2x = vel2.x - bx * dotvr2, vp2y = vel2.y - by * dotvr2, vp2z = vel2.z - bz * dotvr2;
-                        const mixed vbCMass = (mass1 * dotvr1 + mass2 * dotvr2) * invTot;
-                        dotvr1 -= vbCMass;
-                        dotvr2 -= vbCMass;
-                        if (dotvr1 != dotvr2) deltaT = deltaR / abs_(dotvr1 - dotvr2);
-                        if (deltaT > dt) deltaT = dt;
-                        const mixed vBond = hws / sqrt_(mass1);
-                        dotvr1 = -dotvr1 * vBond * mass2 * invTot / abs_(dotvr1);
-                        dotvr2 = -dotvr2 * vBond * mass1 * invTot / abs_(dotvr2);
-                        const mixed dr1 = -deltaR * mass2 * invTot + deltaT * dotvr1;
-                        const mixed dr2 = deltaR * mass1 * invTot + deltaT * dotvr2;
-                        dotvr1 += vbCMass;
-                        dotvr2 += vbCMass;
-                        if (is_d) {
-                            px[k] += bx * dr1; py[k] += by * dr1; pz[k] += bz * dr1;
-                            v[k].x = vp1x + bx * dotvr1; v[k].y = vp1y + by * dotvr1; v[k].z = vp1z + bz * dotvr1;
-                        } else {
-                            px[k] += bx * dr2; py[k] += by * dr2; pz[k] += bz * dr2;
-                            v[k].x = vp2x + bx * dotvr2; v[k].y = vp2y + by * dotvr2; v[k].z = vp2z + bz * dotvr2;
-                        }
-                    }
-                }
-            }
-            lds_read = true;
-        }
-
-        TRACE(5 + 4 * trace_tile);
-        // ---------------- stores ----------------
-#pragma unroll
-        for (int k = 0; k < SPT; k++) {
-            const int idx = ts + k * TBLOCK + tid;
-            if (ok[k]) {
-                if (VEL_W || (POS && hardwall)) velm[idx] = v[k];
-                if (POS) {
-                    if (PREC == TGNH_PREC_MIXED) {                   // K :457-458
-                        const float hx = (float)px[k], hy = (float)py[k], hz = (float)pz[k];
-                        posq[idx] = mk4((real)hx, (real)hy, (real)hz, pq[k]);
-                        pcorr[idx] = make_float4((float)(px[k] - hx), (float)(py[k] - hy), (float)(pz[k] - hz), 0.0f);
-                    } else {
-                        posq[idx] = mk4((real)px[k], (real)py[k], (real)pz[k], pq[k]);
-                    }
-                }
-            }
-        }
-
-        // ---------------- A3/A4: kinetic energies (K :82-200 ; Ref :439-460) ----------------
-        if (DO_KE) {
-            if (lds_read) __syncthreads();
-#pragma unroll
-            for (int k = 0; k < SPT; k++) st_img(sv, svc, k * TBLOCK + tid, img(k));
-            __syncthreads();
-            if (use_com) {
-                for (int r = tid; r < nres; r += TBLOCK) {            // K :86-111, :152-158
-                    const int2 rt = r == tid ? cur.rt : a.res_table[rs + r];
-                    if (rt.x < 0) { scom[r] = reinterpret_cast<const mixed4*>(a.big_com)[-rt.x - 1]; continue; }   // its M v_com^2 comes from big_com_kernel
-                    const int first = rt.y - ts;
-                    mixed cx = 0, cy = 0, cz = 0, cm = 0;
-                    for (int j = 0; j < rt.x; j++) {
-                        const mixed4 u = ld_img(sv, svc, first + j);
-                        const mixed m = u.w;                       // mass (0 for massless sites)
-                        cx += u.x * m; cy += u.y * m; cz += u.z * m; cm += m;
-                    }
-                    const mixed w = rcp_(cm);
-                    cx *= w; cy *= w; cz *= w;
-                    scom[r] = mk4(cx, cy, cz, w);
-                    ke_com += ((double)cx * cx + (double)cy * cy + (double)cz * cz) * (double)cm;     // M v_com^2 (K :154)
-                }
-                __syncthreads();
-            }
-#pragma unroll
-            for (int k = 0; k < SPT; k++) {
-                const uint32_t m = meta[k];
-                const uint32_t role = m & 3u, g = (m >> 2) & 255u;
-                double cx = 0, cy = 0, cz = 0;
-                if (use_com) { const mixed4 c = scom[m >> 21]; cx = c.x; cy = c.y; cz = c.z; }
-                double val = 0.0;
-                if (role == ROLE_NORMAL) {
-                    if (v[k].w != 0) {                               // K :161-168
-                        const double rx = v[k].x - cx, ry = v[k].y - cy, rz = v[k].z - cz;
-                        val = (rx * rx + ry * ry + rz * rz) * (double)mass[k];
-                    }
-                } else if (role == ROLE_DRUDE) {                     // K :171-186 (one lane per pair)
-                    const int pl = k * TBLOCK + tid + (int)((m >> 10) & 2047u) - 1024;
-                    const mixed4 u = ld_img(sv, svc, pl);
-                    const double r1x = v[k].x - cx, r1y = v[k].y - cy, r1z = v[k].z - cz;
-                    const double r2x = u.x - cx, r2y = u.y - cy, r2z = u.z - cz;
-                    const double mass1 = mass[k], mass2 = u.w;               // image .w = mass
-                    const double invTot = rcp_(mass1 + mass2);
-                    const double m1f = invTot * mass1, m2f = invTot * mass2;
-                    const double cmx = r1x * m1f + r2x * m2f, cmy = r1y * m1f + r2y * m2f, cmz = r1z * m1f + r2z * m2f;
-                    const double rlx = r2x - r1x, rly = r2y - r1y, rlz = r2z - r1z;
-                    val = (cmx * cmx + cmy * cmy + cmz * cmz) * (mass1 + mass2);
-                    ke_drude += (rlx * rlx + rly * rly + rlz * rlz) * (mass1 * mass2 * invTot);   // reduced mass = 1/invReducedMass (K :178, :185)
-                }
-                if constexpr (GB > 0) {
-#pragma unroll
-                    for (int b = 0; b < GB; b++) ke_g[b] += (g == (uint32_t)b) ? val : 0.0;
-                } else {
-                    // one pass per distinct group present in this wavefront (usually 1-3): butterfly-sum the lanes of
-                    // that group, lane 0 adds the sum to the wave's LDS bin.  The order depends on the data only.
-                    const bool has = role == ROLE_DRUDE || (role == ROLE_NORMAL && v[k].w != 0);
-                    unsigned long long rem = __ballot(has);
-                    while (rem) {
-                        const int src = __ffsll((long long)rem) - 1;
-                        const uint32_t g0 = __shfl(g, src, 64);
-                        const bool mine = has && g == g0;
-                        const double sg = wave_sum(mine ? val : 0.0);
-                        if ((tid & 63) == 0) wbins[g0] += sg;
-                        rem &= ~__ballot(mine);
-                    }
-                }
-            }
-            lds_read = true;
-        }
-        if (lds_read) __syncthreads();       // LDS image is reused by the next tile
+        tile_body<PREC, OPS, GB>(a, e, cur, trace_tile);
         TRACE(6 + 4 * trace_tile);
 #ifdef TGNH_TRACE
         trace_tile++;
 #endif
         if (more) load_tile(t + gridDim.x, cur);
     }
+    if (DO_KE) ke_reduce<PREC, GB, false>(a, e);
+    TRACE(15);
+}
 
-    // ---- work-group reduction of the fp64 KE bins: 64-lane butterflies, then one LDS hop ----
-    if (DO_KE) {
-        double* sred = reinterpret_cast<double*>(smem);              // [TBLOCK/64][GB+2]
-        const int lane = tid & 63, wv = tid >> 6;
+// ---------------------------------------------------------------------------
+// step_kernel: a whole time step of the deferred pass structure in ONE launch (TGNH_FLAG_RESIDENT_STEP).
+//
+//   pass 1   half kick (unstored) + kinetic-energy sums over the work-group's tiles          (Cu :384-388, :474-488)
+//   meet     every work-group leaves its row of sums as tagged cells (data and "it is there" in one 8-byte store);
+//            work-group 0 collects the rows (fixed order: reproducible bits), and sends the sums to the mailbox of
+//            every rank -- its own included; unsharded, the handle's private one-rank mailbox -- where every
+//            work-group of every rank waits for all ranks' sums.  No read-modify-write atomics anywhere: 768
+//            work-groups arriving at one counter cost ~70 us, plain tagged stores and polling loads a few
+//   chain    both thermostat half steps back to back, by one wavefront of every work-group      (Cu :433-652 twice)
+//   pass 2   the kick again, rescale, half kick, drift, hard wall over the same tiles           (Cu :351-376)
+//
+// The grid is the work-groups that are resident at once (occupancy x CUs), so work-group 0's wait cannot deadlock as
+// long as this launch has its share of the device to itself; every wait is bounded all the same (status bits 2 / 3,
+// never a hung device).  Pass 2 walks the work-group's tiles backwards: its first tile is pass 1's last, whose
+// velocities, forces and index words are still in registers -- only its positions are fetched, and that before the
+// meeting, which hides them.  At shard sizes (<= 2 tiles per work-group) most of the step's state therefore never
+// leaves the chip between the passes.  The thermostat block is advanced in place by work-group 0: every work-group
+// reads it before it hands in its row, and work-group 0 writes only after it has everybody's.
+// ---------------------------------------------------------------------------
+constexpr int STEP_OPS1 = OP_KICK | OP_KE | OP_NOSTORE;
+constexpr int STEP_OPS2 = OP_PREKICK | OP_SCALE | OP_KICK | OP_DRIFT;
+
+// (Measured and dropped, profiles/r02_resident_tuning.md: a second register image to load a work-group's next tile under
+// the current one -- 198 VGPRs, occupancy 2 -- and tiles cut to N / (k x work-groups) slots for equal walks: both a few
+// per cent slower at 625 k slots.  Pass 2 already moves its 73 MB at the 6.6 TB/s the Infinity Cache gives.)
+template <int PREC, int GB>
+__global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileArgs a) {
+    typedef typename Prec<PREC>::mixed mixed;
+    __shared__ double s_scale[MAX_GROUPS + 2];
+    __shared__ double s_part[TBLOCK / 64][CHAIN_INLINE_SUM_NT];
+    __shared__ double s_x[64 + XCHG_MAX_WORLD * CHAIN_INLINE_SUM_NT];      // scratch of the sums and the exchange: the images stay intact
+    __shared__ int s_go;
+    __shared__ unsigned s_gen;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, G = a.num_groups, NT = G + 2;
+    const int grid = (int)gridDim.x;
+    const bool chain_wave = tid < 64, leader = blockIdx.x == 0;
+    const int itg = tid & 63;
+    TileEnv<PREC, GB> e;
+    e.init(a, smem, s_scale, a.hardwall != 0);
+    auto tile_of = [&](int tt) { return a.reverse ? a.num_tiles - 1 - tt : tt; };
+
+    // this launch's number (the tag of its rows) and the exchange it will wait for: read before anything is handed in
+    unsigned gen0 = 0;
+    unsigned long long seq0 = 0;
+    if (chain_wave) {
+        gen0 = __hip_atomic_load(&a.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seq0 = __hip_atomic_load(a.chain.x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // ---- pass 1
+    TRACE(0);
+    TileIn<PREC> cur;
+    int tt = blockIdx.x;                                   // grid <= num_tiles: every work-group has a tile
+    tile_load<PREC, STEP_OPS1>(a, tile_of(tt), cur);
+    for (;;) {
+        tile_body<PREC, STEP_OPS1, GB>(a, e, cur, 4);      // (trace slots >= 16: not recorded)
+        if (tt + grid >= a.num_tiles) break;
+        tt += grid;
+        tile_load<PREC, STEP_OPS1>(a, tile_of(tt), cur);
+    }
+    const int tt_last = tt;                                // stays in `cur`; its velocity image and COM table stay in LDS
+    TRACE(1);
+    ke_reduce<PREC, GB, true>(a, e, gen0 + 1u, s_x);
+    TRACE(2);
+    // thermostat state of this wavefront's chain and the held tile's positions: issued now, needed after the meeting
+    const ChainLayout& L = a.chain.L;
+    Chain1Regs creg{};
+    if (chain_wave && itg < NT) creg = chain1_load(a.chain, a.st_in, itg);
+    tile_load<PREC, STEP_OPS2, true>(a, tile_of(tt_last), cur);
+
+    // ---- meet: work-group 0 collects the rows.  Thread t owns rows t, t + 256, ...: it polls their cells until all
+    // carry this launch's tag and adds them in row order; then butterflies and one LDS hop, fixed order throughout.
+    if (tid == 0) s_gen = gen0;
+    __syncthreads();
+    const unsigned long long want = (unsigned long long)(s_gen + 1u);
+    if (leader) {
+        double acc[CHAIN_INLINE_SUM_NT];
 #pragma unroll
-        for (int b = 0; b < GB; b++) ke_g[b] = wave_sum(ke_g[b]);
-        if (GB == 0) __syncthreads();                                // every wave's LDS bins are final
-        ke_com = wave_sum(ke_com);
-        ke_drude = wave_sum(ke_drude);
-        if (lane == 0) {
+        for (int b = 0; b < CHAIN_INLINE_SUM_NT; b++) acc[b] = 0.0;
+        bool ok = true;
+        for (int r = tid; r < grid && ok; r += TBLOCK) {
+            const unsigned long long* cell = a.rows + (size_t)r * NT * 2;
+            unsigned long long w[2 * CHAIN_INLINE_SUM_NT];
+            unsigned n = 0;
+            for (;;) {                                     // a row's cells in one batch of loads; again until all carry the tag
+                bool all = true;
 #pragma unroll
-            for (int b = 0; b < GB; b++) sred[wv * (GB + 2) + b] = ke_g[b];
-            sred[wv * (GB + 2) + GB] = ke_com;
-            sred[wv * (GB + 2) + GB + 1] = ke_drude;
+                for (int b = 0; b < 2 * CHAIN_INLINE_SUM_NT; b++) if (b < 2 * NT) w[b] = xchg_ld(cell + b);
+#pragma unroll
+                for (int b = 0; b < 2 * CHAIN_INLINE_SUM_NT; b++) if (b < 2 * NT) all = all && (w[b] >> 32) == want;
+                if (all) break;
+                if (++n > XCHG_SPIN_LIMIT) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int b = 0; b < CHAIN_INLINE_SUM_NT; b++)
+                if (b < NT) acc[b] += __longlong_as_double((long long)((w[2 * b + 1] << 32) | (w[2 * b] & 0xffffffffull)));
         }
-        __syncthreads();
-        if (tid < GB + 2) {
-            double s = 0.0;
-#pragma unroll
-            for (int w = 0; w < TBLOCK / 64; w++) s += sred[w * (GB + 2) + tid];   // fixed order
-            const int NT = G + 2;
-            if (tid < GB) { if (tid < G) a.partials[(size_t)blockIdx.x * NT + tid] = s; }
-            else a.partials[(size_t)blockIdx.x * NT + G + (tid - GB)] = s;
+        if (!ok) {                                         // a work-group never handed in its row: nobody goes on
+            atomicOr(a.status, 8u);
+            __hip_atomic_store(a.chain.x.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (GB == 0) {
-            const double* w0 = reinterpret_cast<const double*>(sx + (hardwall ? TILE_SLOTS : 0));
-            for (int g = tid; g < G; g += TBLOCK) {
-                double s = 0.0;
+        const double* big = a.partials + (size_t)GRID_CAP * NT;               // rows of big_com_kernel (an earlier launch)
+        for (int r = tid; r < a.chain.nbig; r += TBLOCK)
 #pragma unroll
-                for (int w = 0; w < TBLOCK / 64; w++) s += w0[w * G + g];     // fixed order
-                a.partials[(size_t)blockIdx.x * (G + 2) + g] = s;
+            for (int b = 0; b < CHAIN_INLINE_SUM_NT; b++) if (b < NT) acc[b] += big[(size_t)r * NT + b];
+#pragma unroll
+        for (int b = 0; b < CHAIN_INLINE_SUM_NT; b++) {
+            if (b < NT) {
+                const double t = wave_sum(acc[b]);
+                if ((tid & 63) == 0) s_part[tid >> 6][b] = t;
             }
         }
+        __syncthreads();
+        double mine = 0.0;
+        if (tid < NT) {
+#pragma unroll
+            for (int w = 0; w < TBLOCK / 64; w++) mine += s_part[w][tid];
+        }
+        TRACE(7);
+        if (tid == 0) a.sync[1] = s_gen + 1u;              // the next launch's rows carry the next tag
+        xchg_send(a.chain.x, NT, tid, TBLOCK, s_x, mine);
+        __syncthreads();
+    }
+    if (chain_wave) {
+        const double mine = xchg_wait_sum(a.chain.x, NT, itg, s_x + 64, seq0 + 1ull);
+        TRACE(8);
+        double kesum = 0.0;
+        for (int i = 0; i < NT; i++) kesum += __shfl(mine, i, 64);
+        const bool dead = __hip_atomic_load(a.chain.x.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        if (itg == 0) s_go = dead ? 0 : 1;
+        if (!dead) {
+            const bool write = leader;
+            creg.ke = mine;
+            if (write && itg < NT) a.st_out[L.off_ke_red + itg] = mine;
+            if (write && itg == 63) a.st_out[L.off_kesum] = 0.5 * kesum;              // Cu :493-497
+            if (itg < NT) {
+                if (L.c1_quirk) chain1q_run(a.chain, creg, a.st_out, write, s_scale, itg);
+                else chain1_run(a.chain, creg, a.st_out, write, s_scale, itg);
+            }
+        }
+    }
+    __syncthreads();
+    if (!s_go) return;                                     // an exchange timed out: reported by the status word; nothing is stored
+    e.s_com = (mixed)s_scale[G]; e.s_drude = (mixed)s_scale[G + 1];
+    TRACE(9);
+
+    // ---- pass 2, backwards from the held tile
+    tt = tt_last;
+    tile_body<PREC, STEP_OPS2, GB, true>(a, e, cur, 0);    // image and COM table of pass 1
+    while (tt - grid >= 0) {
+        tt -= grid;
+        tile_load<PREC, STEP_OPS2>(a, tile_of(tt), cur);
+        tile_body<PREC, STEP_OPS2, GB>(a, e, cur, 0);
     }
     TRACE(15);
 }
@@ -972,6 +1212,34 @@ hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int gr
     if (!fn) return hipErrorInvalidValue;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(TBLOCK), lds, s, a);
     return hipGetLastError();
+}
+
+typedef void (*step_fn_t)(const TileArgs);
+template <int PREC> static step_fn_t step_fn_gb(int gb) {
+    if (gb <= 1) return step_kernel<PREC, 1>;
+    if (gb <= 4) return step_kernel<PREC, 4>;
+    return step_kernel<PREC, 8>;
+}
+static step_fn_t step_fn(int precision, int gb) {
+    if (gb == 0) return nullptr;                          // more than 8 groups: the tile kernels
+    switch (precision) {
+        case TGNH_PREC_SINGLE: return step_fn_gb<TGNH_PREC_SINGLE>(gb);
+        case TGNH_PREC_MIXED: return step_fn_gb<TGNH_PREC_MIXED>(gb);
+        case TGNH_PREC_DOUBLE: return step_fn_gb<TGNH_PREC_DOUBLE>(gb);
+        default: return nullptr;
+    }
+}
+hipError_t launch_step(int precision, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s) {
+    step_fn_t fn = step_fn(precision, gb);
+    if (!fn) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(TBLOCK), lds, s, a);
+    return hipGetLastError();
+}
+int step_blocks_per_cu(int precision, int gb, size_t lds) {
+    step_fn_t fn = step_fn(precision, gb);
+    int n = 0;
+    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(fn), TBLOCK, lds) != hipSuccess) return 0;
+    return n;
 }
 
 int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds) {

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (MODE_DUALNH, MODE_TGNH, PREC_SINGLE, PREC_MIXED, PREC_DOUBLE,  # noqa: F401
-                   FLAG_DEFER_SCALE)
+                   FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP)
 from .synth import KB
 
 _PREC = {"single": PREC_SINGLE, "mixed": PREC_MIXED, "double": PREC_DOUBLE}
@@ -375,6 +375,10 @@ class HipContext(_HandleQueries):
     def exchange_attach_pointers(self, pointers):
         arr = (C.c_void_p * len(pointers))(*[C.c_void_p(p) for p in pointers])
         _check(self.lib.tgnh_exchange_attach_pointers(self.h, arr))
+
+    def set_resident_share(self, share):
+        """FLAG_RESIDENT_STEP: this context may fill 1/share of the device (several contexts stepping concurrently)."""
+        _check(self.lib.tgnh_set_resident_share(self.h, int(share)))
 
     def exchange_detach(self):
         _check(self.lib.tgnh_exchange_detach(self.h))

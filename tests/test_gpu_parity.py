@@ -12,7 +12,7 @@ import pytest
 
 from openmm_drudenose_amd import synth, _lib
 from openmm_drudenose_amd.drudetgnhplugin import (DrudeTGNHIntegrator, HipContext, TgnhError,
-                                                   FLAG_DEFER_SCALE)
+                                                   FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP)
 from helpers import make_oracle, oracle_run, rel_err, to_internal
 
 pytestmark = pytest.mark.gpu
@@ -397,6 +397,141 @@ def test_100_step_parity_deferred_rescale(mode, precision):
     print(f"deferred {mode} {precision}: pos {ep:.2e} vel {ev:.2e}")
     assert ep <= TOL and ev <= TOL
     ctx.close()
+
+
+RESIDENT = FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP
+
+
+@pytest.mark.parametrize("precision", ["mixed", "double"])
+@pytest.mark.parametrize("sysname,mode,drude_chains,com", [
+    ("mixed", "TGNH", True, True), ("mixed", "dualNH", True, True), ("mixed", "dualNH", False, True),
+    ("polymer", "TGNH", True, True), ("water1000", "TGNH", True, False), ("il40", "TGNH", True, True),
+    ("ragged6", "TGNH", True, True)])
+def test_100_step_parity_resident_step(sysname, mode, drude_chains, com, precision):
+    """TGNH_FLAG_RESIDENT_STEP: one launch per time step (step_kernel: kick + KE sums, the work-groups meet on the
+    device, row sum, both chain halves, kick + rescale + kick + drift + hard wall) against the oracle directly."""
+    s, g, ng, it, ctx = make(sysname, mode, precision, flags=RESIDENT, chains=1, drude_chains=drude_chains, com=com, hardwall=0.02)
+    o = make_oracle(s, g, ng, mode, it)
+    pos_o, vel_o = oracle_run(o, s, 100, x0=ctx.sites())
+    ctx.step(100)
+    assert ctx.timing_read(_lib.KID_STEP)[1] == 0     # (timing off) ...
+    ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
+    print(f"resident step {sysname} {mode} {precision}: pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= TOL and ev <= TOL and ctx.check() == 0
+    ctx.close()
+
+
+def test_resident_step_is_the_deferred_integrator():
+    """Same trajectory as the multi-launch deferred structure (row sums in a different order: 1e-11), per-step KE and
+    scale factors equal to the oracle's, the step kernel really is what ran, queries between steps settle the pending
+    half the classic way and stepping goes on, and a hipGraph replay is bitwise the eager run."""
+    ref = make("mixed", "TGNH", "double", flags=FLAG_DEFER_SCALE, chains=1, hardwall=0.02)
+    alt = make("mixed", "TGNH", "double", flags=RESIDENT, chains=1, hardwall=0.02)
+    gra = make("mixed", "TGNH", "double", flags=RESIDENT, chains=1, hardwall=0.02)
+    alt[4].timing(True)
+    ref[4].step(30); alt[4].step(30); gra[4].step(30)
+    alt[4].torch.cuda.synchronize()
+    alt[4].timing(False)
+    assert alt[4].timing_read(_lib.KID_STEP)[1] == 29 and alt[4].timing_read(_lib.KID_KICK_KE)[1] == 0
+    # a query between steps (thermostat state, velocities) ...
+    e_ref, e_alt = ref[4].thermostat_state(1), alt[4].thermostat_state(1)
+    assert np.allclose(e_alt, e_ref, rtol=1e-9, atol=1e-13)
+    assert rel_err(alt[4].getVelocities(), ref[4].getVelocities()) < 1e-10
+    ke_alt = alt[4].last_kinetic_energies()
+    assert np.allclose(ke_alt, ref[4].last_kinetic_energies(), rtol=1e-11)
+    # ... and on it goes
+    ref[4].step(20); alt[4].step(20)
+    assert rel_err(alt[4].getPositions(), ref[4].getPositions()) < 1e-11
+    assert rel_err(alt[4].getVelocities(), ref[4].getVelocities()) < 1e-10
+    assert alt[4].time() == ref[4].time()
+    # graph replay: 4 x 5 steps; the eager twin never had a query in between, so compare with a fresh eager run
+    eag = make("mixed", "TGNH", "double", flags=RESIDENT, chains=1, hardwall=0.02)
+    eag[4].step(50)
+    replay = gra[4].capture_steps(5)
+    for _ in range(4):
+        replay()
+    assert np.array_equal(gra[4].getPositions(), eag[4].getPositions())
+    assert np.array_equal(gra[4].getVelocities(), eag[4].getVelocities())
+    assert np.array_equal(gra[4].thermostat_state(1), eag[4].thermostat_state(1))
+    for c in (ref, alt, gra, eag):
+        c[4].close()
+
+
+def test_resident_step_falls_back_where_it_cannot_run():
+    """Three-link chains (the chain kernel) and more than 8 temperature groups are not step_kernel's: the flag is
+    accepted and the handle steps the deferred way."""
+    for sysname, chains in (("mixed", 3), ("groups12", 1)):
+        ref = make(sysname, "TGNH", "double", flags=FLAG_DEFER_SCALE, chains=chains)
+        alt = make(sysname, "TGNH", "double", flags=RESIDENT, chains=chains)
+        alt[4].timing(True)
+        ref[4].step(20); alt[4].step(20)
+        alt[4].torch.cuda.synchronize(); alt[4].timing(False)
+        assert alt[4].timing_read(_lib.KID_STEP)[1] == 0
+        assert np.array_equal(alt[4].getVelocities(), ref[4].getVelocities())
+        ref[4].close(); alt[4].close()
+    s, g, ng = SYSTEMS["mixed"]()
+    it = integ(chains=1)
+    bind_groups(it, g, ng)
+    with pytest.raises(TgnhError):
+        HipContext(s, it, mode="TGNH", precision="double", flags=FLAG_RESIDENT_STEP)     # needs DEFER_SCALE
+
+
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_resident_step_with_mailbox_exchange(nranks):
+    """step_kernel's sharded form: work-group 0 sums the rows and sends them to every rank's mailbox, every work-group
+    waits for all ranks' sums there.  One rank (its own mailbox), and two ranks as two handles on this GPU that share
+    its resident work-group slots (tgnh_set_resident_share) on two hardware queues."""
+    from openmm_drudenose_amd.system import shard_bounds
+    s, g, ng = synth.mixed(400, 30)
+    it = integ(chains=1, hardwall=0.02)
+    bind_groups(it, g, ng)
+    ref = HipContext(s, it, mode="TGNH", precision="double", flags=FLAG_DEFER_SCALE)
+    torch = ref.torch
+    b = shard_bounds(s, nranks)
+    parts, terms, streams = [], [], []
+    for r in range(nranks):
+        loc, lg = s.slice_molecules(b[r], b[r + 1]), g[b[r]:b[r + 1]]
+        itr = integ(chains=1, hardwall=0.02)
+        bind_groups(itr, lg, ng)
+        parts.append(HipContext(loc, itr, mode="TGNH", precision="double", flags=RESIDENT))
+        parts[-1].set_resident_share(nranks)
+        terms.append(parts[-1].local_dof_terms())
+        streams.append(torch.cuda.Stream(priority=-r))
+    total = sum(terms)
+    boxes = [c.exchange_create(nranks, r)[1] for r, c in enumerate(parts)]
+    for c in parts:
+        c.set_global_dof_terms(total)
+        c.exchange_attach_pointers(boxes)
+        c.timing(True)
+    torch.cuda.synchronize()
+    for _ in range(40):
+        ref.step_begin(); ref.compute_forces(); ref.step_end()
+        for c, st in zip(parts, streams):
+            with torch.cuda.stream(st):
+                c.step_begin(); c.compute_forces(); c.step_end()
+    torch.cuda.synchronize()
+    for c in parts:
+        c.timing(False)
+        assert c.timing_read(_lib.KID_STEP)[1] == 39
+    # settle every rank's pending half before any rank waits on a query (queries are collective here)
+    for c, st in zip(parts, streams):
+        with torch.cuda.stream(st):
+            _check_ok = c.lib.tgnh_flush(c.h, c._stream())
+            assert _check_ok == 0
+    torch.cuda.synchronize()
+    for c in parts:
+        assert c.check() == 0
+    pos = np.concatenate([c.getPositions() for c in parts])
+    vel = np.concatenate([c.getVelocities() for c in parts])
+    assert rel_err(pos, ref.getPositions()) < 1e-12 and rel_err(vel, ref.getVelocities()) < 1e-10
+    for c in parts[1:]:
+        for which in (0, 1):
+            assert np.array_equal(parts[0].thermostat_state(which), c.thermostat_state(which))   # rank-order sums: bitwise
+    assert np.allclose(parts[0].thermostat_state(1), ref.thermostat_state(1), rtol=1e-9, atol=1e-13)
+    for c in parts:
+        c.exchange_detach()
+    for c in parts + [ref]:
+        c.close()
 
 
 @pytest.mark.parametrize("mode", ["TGNH", "dualNH"])
