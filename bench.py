@@ -48,8 +48,9 @@ def parse():
     p.add_argument("--mode", default="TGNH", choices=["TGNH", "dualNH"])
     p.add_argument("--variant", default="auto", choices=["auto", "plain", "defer", "resident"],
                    help="defer = end-of-step rescale and second half kick folded into the next step's first pass; resident = "
-                        "defer with the whole step in ONE launch whose work-groups meet on the device (step_kernel); plain = "
-                        "the reference's pass structure (what the OpenMM glue runs); auto = resident (DESIGN.md)")
+                        "defer with the whole step in ONE launch whose work-groups meet on the device (step_kernel; with the "
+                        "RCCL hook it steps the defer way); plain = the reference's pass structure (what the OpenMM glue "
+                        "runs); auto = resident below 2 M slots per GPU, else defer (DESIGN.md)")
     p.add_argument("--chains", type=int, default=1)
     p.add_argument("--drude-steps", type=int, default=20, help="drudeStepsPerRealStep (reference default 20)")
     p.add_argument("--hardwall", type=float, default=0.02, help="maxDrudeDistance nm (example/nacl_tg.py:22); 0 = off")
@@ -395,8 +396,6 @@ def step_model_bytes(num_slots, precision, variant):
 
 def main():
     args = parse()
-    if args.variant == "auto":
-        args.variant = "resident"
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
         self_launch(args, sys.argv[1:])                # does not return
@@ -439,6 +438,11 @@ def main():
 
     from openmm_drudenose_amd import synth, _lib
     system, group, ngroups = synth.water_box(args.molecules)
+    if args.variant == "auto":
+        # One launch per step (step_kernel) pays where a work-group walks a handful of tiles: +5-8 % below ~2 M slots per
+        # GPU, i.e. for the shards of a 4- or 8-GPU run.  At 5 M slots it is level with the three-launch structure
+        # (+-1 %, run-to-run spread 2.5 %; its first pass runs at the occupancy of the second), which is kept there.
+        args.variant = "resident" if system.num_particles / world < 2_000_000 else "defer"
 
     use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
     gsteps = args.graph_steps if use_graph else 0
@@ -508,7 +512,7 @@ def main():
     if mailbox_info:
         extra["mailbox"] = dict(extra.get("mailbox", {}), **mailbox_info)
     if world == 1 and not args.no_extra:
-        for prec, var in ((args.precision, "plain"), (args.precision, "defer"), ("single", args.variant)):
+        for prec, var in ((args.precision, "plain"), (args.precision, "resident"), ("single", args.variant)):
             if (prec, var) == (args.precision, args.variant):
                 continue
             c2 = build_context(args, system, group, ngroups, rank, world, prec, var)
@@ -541,7 +545,9 @@ def main():
                             f"{system.num_pairs} Drude pairs, 1 temperature group (+ molecular-COM and Drude thermostats), "
                             f"{args.mode} mode, {args.precision} precision, numNHChains={args.chains}, hard wall "
                             f"{args.hardwall} nm, harness force call-out inside the timed region",
-                "precision": args.precision, "variant": args.variant, "hipgraph": graph_used,
+                "precision": args.precision, "variant": args.variant,
+                "variant_ran": "resident" if dkid == _lib.KID_STEP else args.variant.replace("resident", "defer"),
+                "hipgraph": graph_used,
                 "parallelism": f"particle-sharded x{world} (whole molecules), one KE all-reduce per step",
                 "exchange": exchange_used, "rccl_ranks": ranks_met if use_dist else None,
                 "slots_per_gpu": local_slots,

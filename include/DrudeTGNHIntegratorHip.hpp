@@ -8,6 +8,8 @@
 #ifndef DRUDE_TGNH_INTEGRATOR_HIP_HPP_
 #define DRUDE_TGNH_INTEGRATOR_HIP_HPP_
 
+#include <cstdint>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -146,6 +148,48 @@ public:
             check(tgnh_step_end(handle, stream));
             isKESumValid = true;                                    // .cpp:192
         }
+    }
+    /** The platform's device arrays and its call-outs, as IntegrateDrudeTGNHStepKernel::execute sees them. */
+    struct Buffers { void *posq, *posqCorrection, *velm; const void* force; void* posDelta; };
+    struct CallOuts {
+        std::function<void()> applyConstraints;          // integration.applyConstraints(tol)           Cu :363
+        std::function<void()> computeVirtualSites;       // integration.computeVirtualSites()           Cu :377
+        std::function<void()> calcForcesAndEnergy;       // context.calcForcesAndEnergy(true, false)    Cu :380
+        std::function<void()> applyVelocityConstraints;  // integration.applyVelocityConstraints(tol)   Cu :391
+    };
+    /** One time step exactly as the OpenMM-HIP glue issues it (openmm_glue/HipDrudeTGNHKernels.cpp::execute, which
+     *  replaces CudaDrudeTGNHKernels.cpp:284-408): the scalars the reference re-reads every step, the buffers bound
+     *  again, then the fused sequence or -- with constraints -- the split one around the four call-outs. */
+    void execute(void* stream, const Buffers& b, const CallOuts& co, bool hasConstraints) {
+        bound();
+        check(tgnh_set_step_size(handle, stepSize));                                  // Cu :292
+        check(tgnh_set_drude_steps_per_real_step(handle, drudeStepsPerRealStep));     // Cu :437
+        check(tgnh_set_max_drude_distance(handle, maxDrudeDistance));                 // Cu :298
+        check(tgnh_bind_buffers(handle, b.posq, b.posqCorrection, b.velm, b.force, b.posDelta));
+        if (!hasConstraints) {
+            check(tgnh_step_begin(handle, stream));
+            if (co.computeVirtualSites) co.computeVirtualSites();
+            co.calcForcesAndEnergy();
+            check(tgnh_step_end(handle, stream));
+        }
+        else {
+            check(tgnh_step_begin_kick(handle, stream));                              // Cu :336-360
+            co.applyConstraints();
+            check(tgnh_step_begin_move(handle, stream));                              // Cu :366-376
+            if (co.computeVirtualSites) co.computeVirtualSites();
+            co.calcForcesAndEnergy();
+            check(tgnh_step_end_kick(handle, stream));                                // Cu :384-388
+            co.applyVelocityConstraints();
+            check(tgnh_step_end_thermo(handle, stream));                              // Cu :394-406
+        }
+        isKESumValid = true;                                                          // .cpp:192
+    }
+    /** The device's status word; throws for what the library treats as a failure (see tgnh_get_status_flags). */
+    uint32_t checkStatus(void* stream) {
+        bound();
+        uint32_t flags = 0;
+        check(tgnh_get_status_flags(handle, stream, &flags));
+        return flags;
     }
     void stateChanged() { isKESumValid = false; if (handle) check(tgnh_state_changed(handle)); }             // .cpp:166-170
     double computeKineticEnergy(void* stream) {                                                              // .cpp:178-180

@@ -34,53 +34,69 @@ def build_oracle(force=False):
 
 
 _lib = None
+_mut = None
+
+
+def load_mutants():
+    """libtgnh_oracle_mut.so: the oracle with its deliberate, switchable mis-restatements (tgo_set_mutant).  Only
+    tests/pin_sensitivity.py uses it -- to measure what the reference's own checks can and cannot see."""
+    global _mut
+    if _mut is None:
+        path = os.path.join(HERE, "libtgnh_oracle_mut.so")
+        subprocess.run(["make", "-C", HERE, "-s", "libtgnh_oracle_mut.so"], check=True, stdout=subprocess.DEVNULL)
+        _mut = _bind(C.CDLL(path))
+        _mut.tgo_set_mutant.argtypes = [C.c_int]
+    return _mut
 
 
 def _load():
     global _lib
     if _lib is None:
         build_oracle()
-        L = C.CDLL(LIB)
-        L.tgo_last_error.restype = C.c_char_p
-        L.tgo_create.argtypes = [C.POINTER(_Desc), C.POINTER(C.c_void_p)]
-        L.tgo_destroy.argtypes = [C.c_void_p]
-        L.tgo_set_step_size.argtypes = [C.c_void_p, C.c_double]
-        L.tgo_set_drude_steps.argtypes = [C.c_void_p, C.c_int]
-        L.tgo_set_max_drude_distance.argtypes = [C.c_void_p, C.c_double]
-        L.tgo_num_normal.argtypes = [C.c_void_p]
-        L.tgo_get_normal.argtypes = [C.c_void_p, _i32p]
-        L.tgo_num_thermostats.argtypes = [C.c_void_p]
-        L.tgo_get_dof.argtypes = [C.c_void_p, _f64p, _f64p]
-        L.tgo_chain_len.argtypes = [C.c_void_p, C.c_int]
-        L.tgo_get_chain.argtypes = [C.c_void_p, C.c_int, _f64p]
-        L.tgo_set_chain.argtypes = [C.c_void_p, C.c_int, _f64p]
-        L.tgo_kinetic_energies.argtypes = [C.c_void_p, _f64p, _f64p]
-        L.tgo_propagate_nhc.argtypes = [C.c_void_p, _f64p, _f64p, _f64p]
-        L.tgo_chain_only.argtypes = [C.c_void_p, _f64p, _f64p]
-        L.tgo_scale_velocities.argtypes = [C.c_void_p, _f64p, _f64p]
-        L.tgo_half_kick.argtypes = [C.c_void_p, _f64p, _f64p]
-        L.tgo_drift.argtypes = [C.c_void_p, _f64p, _f64p]
-        L.tgo_hardwall.argtypes = [C.c_void_p, _f64p, _f64p]
-        L.tgo_step_begin.argtypes = [C.c_void_p, _f64p, _f64p, _f64p]
-        L.tgo_step_end.argtypes = [C.c_void_p, _f64p, _f64p]
-        L.tgo_kinetic_energy_query.argtypes = [C.c_void_p, _f64p, _f64p, C.c_int]
-        L.tgo_kinetic_energy_query.restype = C.c_double
-        L.tgo_harness_force.argtypes = [C.c_void_p, _f64p, _f64p, C.c_double, C.c_double, _f64p]
-        L.tgo_run_harness.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_int]
-        L.tgo_set_clusters.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, _i32p, _f64p]
-        L.tgo_shake_positions.argtypes = [C.c_void_p, _f64p, _f64p, C.c_double]
-        L.tgo_shake_velocities.argtypes = [C.c_void_p, _f64p, _f64p, C.c_double]
-        L.tgo_set_virtual_sites.argtypes = [C.c_void_p, C.c_int, _i32p, _f64p]
-        L.tgo_virtual_sites.argtypes = [C.c_void_p, _f64p]
-        L.tgo_run_harness_constrained.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_double, C.c_int]
-        L.tgo_water_forces.argtypes = [C.c_int, _f64p, C.c_double, C.c_double, _f64p]
-        L.tgo_water_forces.restype = C.c_double
-        L.tgo_time.argtypes = [C.c_void_p]
-        L.tgo_time.restype = C.c_double
-        L.tgo_step_count.argtypes = [C.c_void_p]
-        L.tgo_step_count.restype = C.c_long
-        _lib = L
+        _lib = _bind(C.CDLL(LIB))
     return _lib
+
+
+def _bind(L):
+    L.tgo_last_error.restype = C.c_char_p
+    L.tgo_create.argtypes = [C.POINTER(_Desc), C.POINTER(C.c_void_p)]
+    L.tgo_destroy.argtypes = [C.c_void_p]
+    L.tgo_set_step_size.argtypes = [C.c_void_p, C.c_double]
+    L.tgo_set_drude_steps.argtypes = [C.c_void_p, C.c_int]
+    L.tgo_set_max_drude_distance.argtypes = [C.c_void_p, C.c_double]
+    L.tgo_num_normal.argtypes = [C.c_void_p]
+    L.tgo_get_normal.argtypes = [C.c_void_p, _i32p]
+    L.tgo_num_thermostats.argtypes = [C.c_void_p]
+    L.tgo_get_dof.argtypes = [C.c_void_p, _f64p, _f64p]
+    L.tgo_chain_len.argtypes = [C.c_void_p, C.c_int]
+    L.tgo_get_chain.argtypes = [C.c_void_p, C.c_int, _f64p]
+    L.tgo_set_chain.argtypes = [C.c_void_p, C.c_int, _f64p]
+    L.tgo_kinetic_energies.argtypes = [C.c_void_p, _f64p, _f64p]
+    L.tgo_propagate_nhc.argtypes = [C.c_void_p, _f64p, _f64p, _f64p]
+    L.tgo_chain_only.argtypes = [C.c_void_p, _f64p, _f64p]
+    L.tgo_scale_velocities.argtypes = [C.c_void_p, _f64p, _f64p]
+    L.tgo_half_kick.argtypes = [C.c_void_p, _f64p, _f64p]
+    L.tgo_drift.argtypes = [C.c_void_p, _f64p, _f64p]
+    L.tgo_hardwall.argtypes = [C.c_void_p, _f64p, _f64p]
+    L.tgo_step_begin.argtypes = [C.c_void_p, _f64p, _f64p, _f64p]
+    L.tgo_step_end.argtypes = [C.c_void_p, _f64p, _f64p]
+    L.tgo_kinetic_energy_query.argtypes = [C.c_void_p, _f64p, _f64p, C.c_int]
+    L.tgo_kinetic_energy_query.restype = C.c_double
+    L.tgo_harness_force.argtypes = [C.c_void_p, _f64p, _f64p, C.c_double, C.c_double, _f64p]
+    L.tgo_run_harness.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_int]
+    L.tgo_set_clusters.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, _i32p, _f64p]
+    L.tgo_shake_positions.argtypes = [C.c_void_p, _f64p, _f64p, C.c_double]
+    L.tgo_shake_velocities.argtypes = [C.c_void_p, _f64p, _f64p, C.c_double]
+    L.tgo_set_virtual_sites.argtypes = [C.c_void_p, C.c_int, _i32p, _f64p]
+    L.tgo_virtual_sites.argtypes = [C.c_void_p, _f64p]
+    L.tgo_run_harness_constrained.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, C.c_double, C.c_double, C.c_double, C.c_int]
+    L.tgo_water_forces.argtypes = [C.c_int, _f64p, C.c_double, C.c_double, _f64p]
+    L.tgo_water_forces.restype = C.c_double
+    L.tgo_time.argtypes = [C.c_void_p]
+    L.tgo_time.restype = C.c_double
+    L.tgo_step_count.argtypes = [C.c_void_p]
+    L.tgo_step_count.restype = C.c_long
+    return L
 
 
 class OracleError(RuntimeError):
@@ -98,8 +114,8 @@ class Oracle:
 
     def __init__(self, system, group, num_groups, mode, temperature, coupling_time, drude_temperature,
                  drude_coupling_time, step_size, drude_steps=20, num_nh_chains=1, use_drude_nh_chains=False,
-                 use_com_temp_group=True, max_drude_distance=0.0, kB=8.31446261815324e-3):
-        L = _load()
+                 use_com_temp_group=True, max_drude_distance=0.0, kB=8.31446261815324e-3, lib=None):
+        L = lib if lib is not None else _load()
         self.L = L
         self._keep = [np.ascontiguousarray(system.mass, np.float64),
                       np.ascontiguousarray(system.pair_drude, np.int32),

@@ -17,6 +17,16 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Deliberate mis-restatements, for tests/pin_sensitivity.py only ("which of the reference's own checks would notice?").
+ * They exist in libtgnh_oracle_mut.so (-DTGO_MUTANTS); in the oracle proper MUT(k) is the constant 0. */
+#ifdef TGO_MUTANTS
+static int g_mutant = 0;
+void tgo_set_mutant(int k) { g_mutant = k; }
+#define MUT(k) (g_mutant == (k))
+#else
+#define MUT(k) 0
+#endif
+
 static char g_err[512] = "";
 const char* tgo_last_error(void) { return g_err; }
 static int fail(int code, const char* msg) {
@@ -91,7 +101,8 @@ static void init_dualnh(tgo_state* s) {
         s->iNumNHChains = C * 1 + 1;
     }
     s->realDof -= s->ncons;                             /* Ref :157 */
-    if (s->has_cmm) s->realDof -= 3;                    /* Ref :158-165 */
+    if (s->has_cmm && !MUT(1)) s->realDof -= 3;         /* Ref :158-165 */
+    if (MUT(2)) s->realDof -= 3;
     s->realNkbT = s->realDof * s->realkbT;              /* Ref :168-171 */
     s->drudeNkbT = s->drudeDof * s->drudekbT;
 
@@ -145,7 +156,7 @@ static int init_tgnh(tgo_state* s, const tgo_desc* d) {
         if (prevRes != resid) { s->res_first[resid] = i; prevRes = resid; }
         if (s->mass[i] != 0.0) {
             s->tgDof[tg] += 3;
-            if (s->use_com) s->tgRed[tg] += 3 * s->mass[i] * s->res_inv_mass[resid];
+            if (s->use_com && !MUT(3)) s->tgRed[tg] += 3 * s->mass[i] * s->res_inv_mass[resid];
         }
     }
     double drudeDof = 0;
@@ -168,7 +179,8 @@ static int init_tgnh(tgo_state* s, const tgo_desc* d) {
     }
     if (s->use_com) s->tgDof[G] = 3 * R;                /* Cu :197-199 */
     s->tgDof[G + 1] = drudeDof;                         /* Cu :201 */
-    if (s->use_com && s->has_cmm) s->tgDof[G] -= 3;     /* Cu :204-212 */
+    if (s->use_com && s->has_cmm && !MUT(1)) s->tgDof[G] -= 3;     /* Cu :204-212 */
+    if (MUT(2)) s->tgDof[0] -= 3;
     s->drudeDof = drudeDof;
     s->drudeNkbT = drudeDof * s->drudekbT;              /* Cu :215 */
     double drudeUnit = s->drudekbT * pow(s->tauD, 2);   /* Cu :216-217 */
@@ -367,7 +379,7 @@ static void com_and_norm(const tgo_state* s, const double* vel, double* comv, do
     }
     for (int i = 0; i < s->n; i++) {                    /* K :123-129 */
         const double* c = comv + 4 * (size_t)s->resid[i];
-        for (int j = 0; j < 3; j++) V(normv, i, j) = V(vel, i, j) - c[j];
+        for (int j = 0; j < 3; j++) V(normv, i, j) = V(vel, i, j) - (MUT(8) ? 0.0 : c[j]);
     }
 }
 
@@ -421,13 +433,13 @@ static void chain_dualnh(tgo_state* s, const double* ke_in, double* scale) {
     etaDotDot[1] = (drudeKE - s->drudeNkbT) / etaMass[1];
     for (int iter = 0; iter < s->S; iter++) {           /* Ref :474 */
         for (int i = s->idxMaxNHChains; i >= 0; i--) {  /* Ref :476-481 */
-            expfac = exp(-dtc8 * etaDot[i + s->numTempGroup]);
+            expfac = exp(-dtc8 * etaDot[i + (MUT(5) ? 2 : s->numTempGroup)]);
             etaDot[i] *= expfac;
             etaDot[i] += etaDotDot[i] * dtc4;
             etaDot[i] *= expfac;
         }
-        scaleReal *= exp(-dtc2 * etaDot[0]);            /* Ref :483-486 */
-        scaleDrude *= exp(-dtc2 * etaDot[1]);
+        scaleReal *= exp(-(MUT(9) ? dtc : dtc2) * etaDot[0]);   /* Ref :483-486 */
+        scaleDrude *= exp(-(MUT(9) ? dtc : dtc2) * etaDot[1]);
         realKE *= exp(-dtc * etaDot[0]);
         drudeKE *= exp(-dtc * etaDot[1]);
         for (int i = 0; i < s->iNumNHChains; i++)       /* Ref :487-489 */
@@ -435,10 +447,10 @@ static void chain_dualnh(tgo_state* s, const double* ke_in, double* scale) {
         etaDotDot[0] = (realKE - s->realNkbT) / etaMass[0];     /* Ref :491-492 */
         etaDotDot[1] = (drudeKE - s->drudeNkbT) / etaMass[1];
         for (int i = 0; i < s->iNumNHChains; i++) {     /* Ref :494-503 */
-            expfac = exp(-dtc8 * etaDot[i + 2]);
+            expfac = exp(-dtc8 * etaDot[i + (MUT(4) ? s->numTempGroup : 2)]);
             etaDot[i] *= expfac;
             if (i > 1) {
-                double dofkbT = (i % 2 == 0 ? s->realkbT : s->drudekbT);
+                double dofkbT = ((i % 2 == 0) != MUT(6) ? s->realkbT : s->drudekbT);
                 etaDotDot[i] = (etaMass[i - 2] * etaDot[i - 2] * etaDot[i - 2] - dofkbT) / etaMass[i];
             }
             etaDot[i] += etaDotDot[i] * dtc4;
@@ -471,19 +483,20 @@ static void chain_tgnh(tgo_state* s, const double* ke_in, double* scale) {
                 ED(itg, i) += EDD(itg, i) * dtc4;
                 ED(itg, i) *= expfac;
             }
-            scale[itg] *= exp(-dtc2 * ED(itg, 0));      /* Cu :573-574 */
+            scale[itg] *= exp(-(MUT(9) ? dtc : dtc2) * ED(itg, 0));      /* Cu :573-574 */
             ke[itg] *= exp(-dtc * ED(itg, 0));
             for (int i = 0; i < C; i++)                 /* Cu :575-577 */
                 ETA(itg, i) += dtc2 * ED(itg, i);
             if (EM(itg, 0) > 0)                         /* Cu :579-581 */
                 EDD(itg, 0) = (ke[itg] - s->tgNkbT[itg]) / EM(itg, 0);
+            if (MUT(7)) expfac = 1.0;
             ED(itg, 0) *= expfac;                       /* Cu :583-585 (expfac reused) */
             ED(itg, 0) += EDD(itg, 0) * dtc4;
             ED(itg, 0) *= expfac;
             for (int i = 1; i < C; i++) {               /* Cu :586-592 */
                 expfac = exp(-dtc8 * ED(itg, i + 1));
                 ED(itg, i) *= expfac;
-                EDD(itg, i) = (EM(itg, i - 1) * ED(itg, i - 1) * ED(itg, i - 1) - s->realkbT) / EM(itg, i);
+                EDD(itg, i) = (EM(itg, i - 1) * ED(itg, i - 1) * ED(itg, i - 1) - (MUT(6) ? s->drudekbT : s->realkbT)) / EM(itg, i);
                 ED(itg, i) += EDD(itg, i) * dtc4;
                 ED(itg, i) *= expfac;
             }
@@ -505,7 +518,7 @@ static void chain_tgnh(tgo_state* s, const double* ke_in, double* scale) {
         ED(itg, 0) *= expfac;
         ED(itg, 0) += EDD(itg, 0) * dtc4;
         ED(itg, 0) *= expfac;
-        scale[itg] *= exp(-dtc2 * ED(itg, 0));
+        scale[itg] *= exp(-(MUT(9) ? dtc : dtc2) * ED(itg, 0));
         ke[itg] *= exp(-dtc * ED(itg, 0));
         ETA(itg, 0) += dtc2 * ED(itg, 0);
         if (s->use_drude_chains)

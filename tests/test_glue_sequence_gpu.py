@@ -1,0 +1,88 @@
+"""The OpenMM-HIP glue's call sequence on the device.  The glue itself
+(openmm_drudenose_amd/csrc/openmm_glue/HipDrudeTGNHKernels.cpp) needs OpenMM headers and cannot be compiled here; what it
+does per step is `DrudeTGNHIntegrator::execute` of include/DrudeTGNHIntegratorHip.hpp, and tests/cpp/test_glue_sequence.cpp
+drives exactly that in C++ on device arrays in OpenMM's layouts: per-step tgnh_set_* + tgnh_bind_buffers, plain pass
+structure, fused or split path with the call-outs, velocities changed between steps + stateChanged(), the status word read
+every step.  Checked against tests/golden/oracle_regression.npz (case nacl_tgnh) and against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from openmm_drudenose_amd import synth, _lib
+from helpers import make_oracle, oracle_run, rel_err
+from openmm_drudenose_amd.drudetgnhplugin import DrudeTGNHIntegrator
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    _lib.load()
+    out = tmp_path_factory.mktemp("glue") / "test_glue_sequence"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                    os.path.join(ROOT, "tests", "cpp", "test_glue_sequence.cpp"), "-o", str(out),
+                    "-L", libdir, "-ldrudetgnh_hip", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True)
+    return str(out)
+
+
+def run_glue(exe, tmp_path, s, group, ngroups, nsteps, perturb, chains, drude_chains, com, dt, hardwall, tol):
+    n = s.num_particles
+    ncl = 0 if s.cluster_atoms is None else len(s.cluster_atoms)
+    ns = 0 if s.site_atoms is None else len(s.site_atoms)
+    ints = [np.array([n, s.num_pairs, s.num_residues, ngroups, ncl, ns, nsteps, int(perturb), chains, int(drude_chains), int(com)], np.int32),
+            np.stack([s.pair_drude, s.pair_parent], 1).astype(np.int32).ravel(), s.resid.astype(np.int32), np.asarray(group, np.int32)]
+    dbl = [np.array([dt, hardwall, synth.K_DRUDE, synth.K_TETHER, tol]), s.mass, s.positions.ravel(), s.velocities.ravel(), s.positions.ravel()]
+    if ncl:
+        ints.append(s.cluster_atoms.astype(np.int32).ravel()); dbl.append(s.cluster_dist.ravel())
+    if ns:
+        ints.append(s.site_atoms.astype(np.int32).ravel()); dbl.append(s.site_weights.ravel())
+    fi, fd, fo = (str(tmp_path / x) for x in ("ints.bin", "doubles.bin", "out.bin"))
+    np.concatenate(ints).astype(np.int32).tofile(fi)
+    np.concatenate([np.asarray(d, np.float64).ravel() for d in dbl]).tofile(fd)
+    r = subprocess.run([exe, fi, fd, fo], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+    out = np.fromfile(fo)
+    return out[:3 * n].reshape(n, 3), out[3 * n:6 * n].reshape(n, 3), out[6 * n:-1], out[-1]
+
+
+def test_fused_sequence_against_the_committed_vectors(exe, tmp_path):
+    """No constraints: tgnh_step_begin / force call-out / tgnh_step_end per step -- the case nacl_tgnh of
+    tests/golden/oracle_regression.npz (512 pairs, hard wall 0.02 nm, one-link chains, 40 steps), mixed precision."""
+    frozen = np.load(os.path.join(ROOT, "tests", "golden", "oracle_regression.npz"))
+    s, g, ng = synth.nacl()
+    pos, vel, eta_dot, ke = run_glue(exe, tmp_path, s, g, ng, 40, False, 1, True, True, 0.001, 0.02, 1e-5)
+    assert rel_err(pos[:64], frozen["nacl_tgnh/pos64"]) <= 1e-6
+    assert rel_err(vel[:64], frozen["nacl_tgnh/vel64"]) <= 1e-6
+    assert np.allclose(eta_dot, frozen["nacl_tgnh/etaDot"], rtol=1e-6, atol=1e-9)
+    # computeKineticEnergy with isKESumValid = the cached half sum of the last thermostat half step (Cu :654-658)
+    assert ke == pytest.approx(0.5 * frozen["nacl_tgnh/ke"][-1].sum(), rel=1e-6)
+
+
+@pytest.mark.parametrize("name", ["rigid water", "ionic liquid"])
+def test_split_sequence_with_call_outs_and_state_changes(exe, tmp_path, name):
+    """Constraints present: begin_kick / applyConstraints / begin_move / computeVirtualSites / calcForcesAndEnergy /
+    end_kick / applyVelocityConstraints / end_thermo, and between steps a CMMotionRemover changes the velocities behind
+    the integrator's back (stateChanged()).  Against the oracle doing the same, 1e-6."""
+    s, g, ng = synth.water_box(64, rigid=True) if name == "rigid water" else synth.ionic_liquid(12, constrained=True)
+    tol, nsteps = 1e-10, 40
+    pos, vel, eta_dot, ke = run_glue(exe, tmp_path, s, g, ng, nsteps, True, 2, True, True, 0.001, 0.02, tol)
+    it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, 2, True, True)
+    it.setMaxDrudeDistance(0.02)
+    o = make_oracle(s, g, ng, "TGNH", it)
+    x0 = s.positions.astype(np.float32).astype(np.float64)          # the harness keeps the tether sites in the position type
+    po, vo = s.positions.copy(), s.velocities.copy()
+    m = s.mass
+    massive = m > 0
+    f = o.harness_force(po, x0, synth.K_DRUDE, synth.K_TETHER)
+    for _ in range(nsteps):
+        vo[massive] -= (m[massive, None] * vo[massive]).sum(0) / m[massive].sum()
+        o.run_harness_constrained(po, vo, f, x0, synth.K_DRUDE, synth.K_TETHER, tol, 1)
+    ep, ev = rel_err(pos, po), rel_err(vel, vo)
+    print(f"glue sequence, split path, {name}: pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= 1e-6 and ev <= 1e-6
+    assert np.allclose(eta_dot, o.chain(1), rtol=1e-6, atol=1e-9)
