@@ -96,6 +96,8 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
         kw = dict(allreduce=lambda t: dist.all_reduce(t), global_dof_sum=dof_sum)
     ctx = HipContext(local, it, mode=args.mode, precision=precision, device=dev, flags=flags, **kw)
     ctx.exchange = "rccl" if kw else None
+    if world > 1 and "TGNH_BENCH_DEVICE" in os.environ:
+        ctx.set_resident_share(world)      # rehearsal: the ranks share ONE device, so each gets 1/world of its work-group slots
     return ctx
 
 
@@ -453,7 +455,9 @@ def main():
         if exchange == "mailbox" and not attach_mailbox(ctx, rank, world):
             close_sharded(ctx)
             return None, None
-        dt = timed_run(ctx, args.steps, args.warmup, world, gsteps, dominant_kid(args.variant))
+        # (rehearsals over gloo: its all_reduce cannot be captured into a hipGraph, RCCL's can)
+        g = 0 if (exchange == "rccl" and BACKEND != "nccl") else gsteps
+        dt = timed_run(ctx, args.steps, args.warmup, world, g, dominant_kid(args.variant))
         return ctx, dt
 
     headline_exchange = args.exchange if use_dist else None
@@ -484,7 +488,8 @@ def main():
         ms, n = ctx.dominant_in_timed_region
         dom = {"avg_us": round(ms / n * 1e3, 3), "launches": n, "where": "HIP events inside the timed region"}
     else:
-        dom = dict(rows.get(dom_name), where="HIP events in the instrumented repeat (timed region was a hipGraph replay)")
+        dom = dict(rows.get(dom_name), where="HIP events in the instrumented repeat right after the timed region "
+                                             "(the region itself was a hipGraph replay, or ran another launch structure than asked for)")
     achieved = bytes_dom / (dom["avg_us"] * 1e-6) / 1e9
     local_slots = ctx.n
     close_sharded(ctx)

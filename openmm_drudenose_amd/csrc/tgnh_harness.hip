@@ -151,9 +151,9 @@ template <bool VEL>
 static hipError_t launch_shake(int precision, const ClusterArgs& a, hipStream_t s) {
     const int g = grid_of(a.n);
     switch (precision) {
-        case TGNH_PREC_SINGLE: hipLaunchKernelGGL((shake_kernel<TGNH_PREC_SINGLE, VEL>), dim3(g), dim3(BLOCK), 0, s, a); break;
-        case TGNH_PREC_MIXED: hipLaunchKernelGGL((shake_kernel<TGNH_PREC_MIXED, VEL>), dim3(g), dim3(BLOCK), 0, s, a); break;
-        case TGNH_PREC_DOUBLE: hipLaunchKernelGGL((shake_kernel<TGNH_PREC_DOUBLE, VEL>), dim3(g), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_SINGLE: TGNH_LAUNCH((shake_kernel<TGNH_PREC_SINGLE, VEL>), dim3(g), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_MIXED: TGNH_LAUNCH((shake_kernel<TGNH_PREC_MIXED, VEL>), dim3(g), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_DOUBLE: TGNH_LAUNCH((shake_kernel<TGNH_PREC_DOUBLE, VEL>), dim3(g), dim3(BLOCK), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -162,9 +162,9 @@ static hipError_t launch_shake(int precision, const ClusterArgs& a, hipStream_t 
 static hipError_t launch_sites(int precision, const SiteArgs& a, hipStream_t s) {
     const int g = grid_of(a.n);
     switch (precision) {
-        case TGNH_PREC_SINGLE: hipLaunchKernelGGL((site_kernel<TGNH_PREC_SINGLE>), dim3(g), dim3(BLOCK), 0, s, a); break;
-        case TGNH_PREC_MIXED: hipLaunchKernelGGL((site_kernel<TGNH_PREC_MIXED>), dim3(g), dim3(BLOCK), 0, s, a); break;
-        case TGNH_PREC_DOUBLE: hipLaunchKernelGGL((site_kernel<TGNH_PREC_DOUBLE>), dim3(g), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_SINGLE: TGNH_LAUNCH((site_kernel<TGNH_PREC_SINGLE>), dim3(g), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_MIXED: TGNH_LAUNCH((site_kernel<TGNH_PREC_MIXED>), dim3(g), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_DOUBLE: TGNH_LAUNCH((site_kernel<TGNH_PREC_DOUBLE>), dim3(g), dim3(BLOCK), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

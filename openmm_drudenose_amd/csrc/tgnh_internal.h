@@ -195,6 +195,10 @@ struct ForceArgs {
     double k_drude, k_tether;
 };
 
+// A launcher reports THIS launch's error: whatever an earlier call left behind (e.g. a stream capture the caller
+// abandoned) is read off first.
+#define TGNH_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 // launchers (tgnh_kernels.hip)
 hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s);
 int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds);   // occupancy of that instantiation

@@ -1062,9 +1062,9 @@ __global__ __launch_bounds__(BLOCK) void big_com_kernel(const BigComArgs a) {
 hipError_t launch_big_com(int precision, const BigComArgs& a, hipStream_t s) {
     int grid = a.n < 1 ? 1 : (a.n > 1024 ? 1024 : a.n);
     switch (precision) {
-        case TGNH_PREC_SINGLE: hipLaunchKernelGGL((big_com_kernel<TGNH_PREC_SINGLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
-        case TGNH_PREC_MIXED: hipLaunchKernelGGL((big_com_kernel<TGNH_PREC_MIXED>), dim3(grid), dim3(BLOCK), 0, s, a); break;
-        case TGNH_PREC_DOUBLE: hipLaunchKernelGGL((big_com_kernel<TGNH_PREC_DOUBLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_SINGLE: TGNH_LAUNCH((big_com_kernel<TGNH_PREC_SINGLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_MIXED: TGNH_LAUNCH((big_com_kernel<TGNH_PREC_MIXED>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_DOUBLE: TGNH_LAUNCH((big_com_kernel<TGNH_PREC_DOUBLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1210,7 +1210,7 @@ static tile_fn_t tile_fn(int precision, int ops, int gb) {
 hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s) {
     tile_fn_t fn = tile_fn(precision, ops, gb);
     if (!fn) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(TBLOCK), lds, s, a);
+    TGNH_LAUNCH(fn, dim3(grid), dim3(TBLOCK), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1232,7 +1232,7 @@ static step_fn_t step_fn(int precision, int gb) {
 hipError_t launch_step(int precision, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s) {
     step_fn_t fn = step_fn(precision, gb);
     if (!fn) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(TBLOCK), lds, s, a);
+    TGNH_LAUNCH(fn, dim3(grid), dim3(TBLOCK), lds, s, a);
     return hipGetLastError();
 }
 int step_blocks_per_cu(int precision, int gb, size_t lds) {
@@ -1250,7 +1250,7 @@ int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds) {
 }
 
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(BLOCK), 0, s, a);
+    TGNH_LAUNCH(chain_kernel, dim3(1), dim3(BLOCK), 0, s, a);
     return hipGetLastError();
 }
 
@@ -1259,9 +1259,9 @@ hipError_t launch_force(int precision, const ForceArgs& a, hipStream_t s) {
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
     switch (precision) {
-        case TGNH_PREC_SINGLE: hipLaunchKernelGGL((force_kernel<TGNH_PREC_SINGLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
-        case TGNH_PREC_MIXED: hipLaunchKernelGGL((force_kernel<TGNH_PREC_MIXED>), dim3(grid), dim3(BLOCK), 0, s, a); break;
-        case TGNH_PREC_DOUBLE: hipLaunchKernelGGL((force_kernel<TGNH_PREC_DOUBLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_SINGLE: TGNH_LAUNCH((force_kernel<TGNH_PREC_SINGLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_MIXED: TGNH_LAUNCH((force_kernel<TGNH_PREC_MIXED>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_DOUBLE: TGNH_LAUNCH((force_kernel<TGNH_PREC_DOUBLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1275,9 +1275,9 @@ hipError_t launch_plain_ke(int precision, const void* velm, const long long* for
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;
     switch (precision) {
-        case TGNH_PREC_SINGLE: hipLaunchKernelGGL((plain_ke_kernel<TGNH_PREC_SINGLE>), dim3(grid), dim3(BLOCK), 0, s, velm, force, n, padded, time_shift, out); break;
-        case TGNH_PREC_MIXED: hipLaunchKernelGGL((plain_ke_kernel<TGNH_PREC_MIXED>), dim3(grid), dim3(BLOCK), 0, s, velm, force, n, padded, time_shift, out); break;
-        case TGNH_PREC_DOUBLE: hipLaunchKernelGGL((plain_ke_kernel<TGNH_PREC_DOUBLE>), dim3(grid), dim3(BLOCK), 0, s, velm, force, n, padded, time_shift, out); break;
+        case TGNH_PREC_SINGLE: TGNH_LAUNCH((plain_ke_kernel<TGNH_PREC_SINGLE>), dim3(grid), dim3(BLOCK), 0, s, velm, force, n, padded, time_shift, out); break;
+        case TGNH_PREC_MIXED: TGNH_LAUNCH((plain_ke_kernel<TGNH_PREC_MIXED>), dim3(grid), dim3(BLOCK), 0, s, velm, force, n, padded, time_shift, out); break;
+        case TGNH_PREC_DOUBLE: TGNH_LAUNCH((plain_ke_kernel<TGNH_PREC_DOUBLE>), dim3(grid), dim3(BLOCK), 0, s, velm, force, n, padded, time_shift, out); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

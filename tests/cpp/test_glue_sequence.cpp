@@ -7,7 +7,7 @@
 // against tests/golden/oracle_regression.npz and against the oracle.
 //
 //   test_glue_sequence ints.bin doubles.bin out.bin
-//   ints:    N P R G nclusters nsites nsteps perturb chains useDrudeChains useCOM | pairs[P][2] | resid[N] | group[N] |
+//   ints:    N P R G nclusters nsites nsteps perturb chains useDrudeChains useCOM precision | pairs[P][2] | resid[N] | group[N] |
 //            cluster atoms[ncl][4] | site atoms[ns][4]
 //   doubles: dt hardwall kDrude kTether tol | mass[N] | pos[N][3] | vel[N][3] | x0[N][3] | cluster dist[ncl][6] | site w[ns][3]
 //   out:     pos[N][3] vel[N][3] etaDot[...]   (doubles)
@@ -39,10 +39,11 @@ int main(int argc, char** argv) {
     if (argc != 4) return 1;
     std::vector<int> I = slurp<int>(argv[1]);
     std::vector<double> D = slurp<double>(argv[2]);
-    if (I.size() < 11 || D.size() < 5) { std::printf("bad input files\n"); return 1; }
+    if (I.size() < 12 || D.size() < 5) { std::printf("bad input files\n"); return 1; }
     const int N = I[0], P = I[1], R = I[2], G = I[3], ncl = I[4], ns = I[5], nsteps = I[6], perturb = I[7];
-    const int chains = I[8], useDrudeChains = I[9], useCOM = I[10];
-    const int* pairs = &I[11]; const int* resid = pairs + 2 * P; const int* group = resid + N;
+    const int chains = I[8], useDrudeChains = I[9], useCOM = I[10], precision = I[11];    // TGNH_PREC_MIXED or _DOUBLE
+    const bool dbl = precision == TGNH_PREC_DOUBLE;
+    const int* pairs = &I[12]; const int* resid = pairs + 2 * P; const int* group = resid + N;
     const int* clAtoms = group + N; const int* siteAtoms = clAtoms + 4 * ncl;
     const double dt = D[0], hardwall = D[1], kDrude = D[2], kTether = D[3], tol = D[4];
     const double* mass = &D[5]; const double* pos0 = mass + N; const double* vel0 = pos0 + 3 * N; const double* x0h = vel0 + 3 * N;
@@ -62,39 +63,41 @@ int main(int argc, char** argv) {
     integ.setMaxDrudeDistance(hardwall);
     for (int g = 0; g < G; g++) integ.addTempGroup();
     for (int i = 0; i < N; i++) integ.addParticleTempGroup(group[i]);
-    integ.initialize(sys, 0, TGNH_MODE_TGNH, TGNH_PREC_MIXED, 0);          // flags 0: the glue keeps the plain pass structure
+    integ.initialize(sys, 0, TGNH_MODE_TGNH, precision, 0);                // flags 0: the glue keeps the plain pass structure
     tgnh_handle h = integ.getHandle();
     const int padded = integ.getPaddedNumParticles();
 
-    // ---- the platform's arrays, OpenMM layouts, mixed precision
+    // ---- the platform's arrays, OpenMM layouts: mixed (float4 posq + float4 correction) or double (double4 posq)
     std::vector<float> posq(4 * N), corr(4 * N, 0.f), x0(4 * N);
-    std::vector<double> velm(4 * N);
+    std::vector<double> posqd(4 * N), x0d(4 * N), velm(4 * N);
+    std::vector<char> isDrude(N, 0);
+    for (int i = 0; i < P; i++) isDrude[pairs[2 * i]] = 1;
     for (int i = 0; i < N; i++) {
         for (int k = 0; k < 3; k++) {
             const double p = pos0[3 * i + k];
             posq[4 * i + k] = (float)p; corr[4 * i + k] = (float)(p - (double)posq[4 * i + k]);
+            posqd[4 * i + k] = p;
             velm[4 * i + k] = vel0[3 * i + k];
-            x0[4 * i + k] = (float)x0h[3 * i + k];
+            x0[4 * i + k] = (float)x0h[3 * i + k]; x0d[4 * i + k] = x0h[3 * i + k];
         }
-        posq[4 * i + 3] = 0.f;
+        posq[4 * i + 3] = 0.f; posqd[4 * i + 3] = 0.0;
         velm[4 * i + 3] = mass[i] == 0.0 ? 0.0 : 1.0 / mass[i];
-        x0[4 * i + 3] = 0.f;
+        const bool tether = mass[i] > 0 && !isDrude[i];                  // harness: tether every massive non-Drude site
+        x0[4 * i + 3] = tether ? 1.f : 0.f; x0d[4 * i + 3] = tether ? 1.0 : 0.0;
     }
-    std::vector<char> isDrude(N, 0);
-    for (int i = 0; i < P; i++) isDrude[pairs[2 * i]] = 1;
-    for (int i = 0; i < N; i++) if (mass[i] > 0 && !isDrude[i]) x0[4 * i + 3] = 1.f;   // harness: tether every massive non-Drude site
+    const size_t rb = dbl ? 32 : 16;                                       // bytes of a real4
     void *d_posq, *d_corr, *d_velm, *d_force, *d_pd, *d_x0;
-    HIPCHK(hipMalloc(&d_posq, 16 * N)); HIPCHK(hipMalloc(&d_corr, 16 * N)); HIPCHK(hipMalloc(&d_velm, 32 * N));
-    HIPCHK(hipMalloc(&d_force, 8 * 3 * (size_t)padded)); HIPCHK(hipMalloc(&d_pd, 32 * N)); HIPCHK(hipMalloc(&d_x0, 16 * N));
-    HIPCHK(hipMemcpy(d_posq, posq.data(), 16 * N, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&d_posq, rb * N)); HIPCHK(hipMalloc(&d_corr, 16 * N)); HIPCHK(hipMalloc(&d_velm, 32 * N));
+    HIPCHK(hipMalloc(&d_force, 8 * 3 * (size_t)padded)); HIPCHK(hipMalloc(&d_pd, 32 * N)); HIPCHK(hipMalloc(&d_x0, rb * N));
+    HIPCHK(hipMemcpy(d_posq, dbl ? (const void*)posqd.data() : (const void*)posq.data(), rb * N, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_corr, corr.data(), 16 * N, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_velm, velm.data(), 32 * N, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_x0, x0.data(), 16 * N, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_x0, dbl ? (const void*)x0d.data() : (const void*)x0.data(), rb * N, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(d_force, 0, 8 * 3 * (size_t)padded)); HIPCHK(hipMemset(d_pd, 0, 32 * N));
     hipStream_t stream;
     HIPCHK(hipStreamCreate(&stream));
-    DrudeTGNHIntegrator::Buffers buf{d_posq, d_corr, d_velm, d_force, d_pd};
-    TG(tgnh_bind_buffers(h, d_posq, d_corr, d_velm, d_force, d_pd));
+    DrudeTGNHIntegrator::Buffers buf{d_posq, dbl ? nullptr : d_corr, d_velm, d_force, d_pd};
+    TG(tgnh_bind_buffers(h, buf.posq, buf.posqCorrection, buf.velm, buf.force, buf.posDelta));
     const bool constrained = ncl > 0 || ns > 0;
     if (ncl > 0) TG(tgnh_harness_set_clusters(h, ncl, clAtoms, clDist));
     if (ns > 0) TG(tgnh_harness_set_virtual_sites(h, ns, siteAtoms, siteW));
@@ -134,14 +137,14 @@ int main(int argc, char** argv) {
 
     // ---- results
     HIPCHK(hipStreamSynchronize(stream));
-    HIPCHK(hipMemcpy(posq.data(), d_posq, 16 * N, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dbl ? (void*)posqd.data() : (void*)posq.data(), d_posq, rb * N, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(corr.data(), d_corr, 16 * N, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(velm.data(), d_velm, 32 * N, hipMemcpyDeviceToHost));
     int nEtaDot = 0;
     TG(tgnh_get_thermostat_len(h, 1, &nEtaDot));
     std::vector<double> etaDot(nEtaDot), out;
     TG(tgnh_get_thermostat_state(h, 1, stream, etaDot.data()));
-    for (int i = 0; i < N; i++) for (int k = 0; k < 3; k++) out.push_back((double)posq[4 * i + k] + (double)corr[4 * i + k]);
+    for (int i = 0; i < N; i++) for (int k = 0; k < 3; k++) out.push_back(dbl ? posqd[4 * i + k] : (double)posq[4 * i + k] + (double)corr[4 * i + k]);
     for (int i = 0; i < N; i++) for (int k = 0; k < 3; k++) out.push_back(velm[4 * i + k]);
     out.insert(out.end(), etaDot.begin(), etaDot.end());
     out.push_back(ke);

@@ -127,3 +127,23 @@ def test_cpp_mirror_class(tmp_path):
                    check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_plugin_tree_configures_without_openmm(tmp_path):
+    """openmm_glue/CMakeLists.txt: without OPENMM_DIR the project still configures (the C-ABI library target only) and
+    says so; with OpenMM it adds platforms/hip and python/ (not available in this image)."""
+    import shutil
+    import subprocess
+    if shutil.which("cmake") is None or shutil.which("ninja") is None:
+        pytest.skip("cmake / ninja not installed")
+    src = os.path.join(ROOT, "openmm_drudenose_amd", "csrc", "openmm_glue")
+    r = subprocess.run(["cmake", "-S", src, "-B", str(tmp_path / "b"), "-G", "Ninja"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "building libdrudetgnh_hip only" in r.stdout
+    for f in ("platforms/hip/CMakeLists.txt", "platforms/hip/src/HipDrudeTGNHKernels.cpp", "python/drudetgnhplugin.i", "python/setup.py.in"):
+        assert os.path.exists(os.path.join(src, f)), f
+    # the SWIG interface declares the reference's surface: the class, its Python-side default, the OUTPUT typemap
+    text = open(os.path.join(src, "python", "drudetgnhplugin.i")).read()
+    for needle in ("%module drudetgnhplugin", "class DrudeTGNHIntegrator : public Integrator", "int useDrudeNHChains = True",
+                   "int addParticleTempGroup(int tempGroup);", "%apply int& OUTPUT { int& tempGroup };", "virtual void step(int steps);"):
+        assert needle in text, needle

@@ -30,11 +30,12 @@ def exe(tmp_path_factory):
     return str(out)
 
 
-def run_glue(exe, tmp_path, s, group, ngroups, nsteps, perturb, chains, drude_chains, com, dt, hardwall, tol):
+def run_glue(exe, tmp_path, s, group, ngroups, nsteps, perturb, chains, drude_chains, com, dt, hardwall, tol, precision="mixed"):
     n = s.num_particles
     ncl = 0 if s.cluster_atoms is None else len(s.cluster_atoms)
     ns = 0 if s.site_atoms is None else len(s.site_atoms)
-    ints = [np.array([n, s.num_pairs, s.num_residues, ngroups, ncl, ns, nsteps, int(perturb), chains, int(drude_chains), int(com)], np.int32),
+    ints = [np.array([n, s.num_pairs, s.num_residues, ngroups, ncl, ns, nsteps, int(perturb), chains, int(drude_chains), int(com),
+                      {"mixed": _lib.PREC_MIXED, "double": _lib.PREC_DOUBLE}[precision]], np.int32),
             np.stack([s.pair_drude, s.pair_parent], 1).astype(np.int32).ravel(), s.resid.astype(np.int32), np.asarray(group, np.int32)]
     dbl = [np.array([dt, hardwall, synth.K_DRUDE, synth.K_TETHER, tol]), s.mass, s.positions.ravel(), s.velocities.ravel(), s.positions.ravel()]
     if ncl:
@@ -52,10 +53,11 @@ def run_glue(exe, tmp_path, s, group, ngroups, nsteps, perturb, chains, drude_ch
 
 def test_fused_sequence_against_the_committed_vectors(exe, tmp_path):
     """No constraints: tgnh_step_begin / force call-out / tgnh_step_end per step -- the case nacl_tgnh of
-    tests/golden/oracle_regression.npz (512 pairs, hard wall 0.02 nm, one-link chains, 40 steps), mixed precision."""
+    tests/golden/oracle_regression.npz (512 pairs, hard wall 0.02 nm, one-link chains, 40 steps).  Double precision:
+    the vectors were made with the tether sites as doubles, and the harness keeps them in the position type."""
     frozen = np.load(os.path.join(ROOT, "tests", "golden", "oracle_regression.npz"))
     s, g, ng = synth.nacl()
-    pos, vel, eta_dot, ke = run_glue(exe, tmp_path, s, g, ng, 40, False, 1, True, True, 0.001, 0.02, 1e-5)
+    pos, vel, eta_dot, ke = run_glue(exe, tmp_path, s, g, ng, 40, False, 1, True, True, 0.001, 0.02, 1e-5, "double")
     assert rel_err(pos[:64], frozen["nacl_tgnh/pos64"]) <= 1e-6
     assert rel_err(vel[:64], frozen["nacl_tgnh/vel64"]) <= 1e-6
     assert np.allclose(eta_dot, frozen["nacl_tgnh/etaDot"], rtol=1e-6, atol=1e-9)

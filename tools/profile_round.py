@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Takes the round's profile evidence in one go, on the GPU box, and stamps it with the hash of the kernel sources:
 
-    python3 tools/profile_round.py r02 [--molecules M] [--variant V]        (run from the repo root; ~3 GPU-minutes)
+    python3 tools/profile_round.py r02 [--molecules M] [--variant V]        (run from the repo root; ~2 GPU-minutes)
+    cp gpurun_out/profiles_out/r02_* profiles/                              (afterwards, where the repository is tracked)
 
-  1. rocprofv3 --kernel-trace --stats   of `bench.py` (the driver's command shape)   -> profiles/<tag>_bench.json,
+  1. rocprofv3 --kernel-trace --stats   of `bench.py` (the driver's command shape)   -> <tag>_bench.json,
                                                                                          <tag>_kernel_stats.csv, <tag>_summary.md
   2. rocprofv3 --pmc FETCH_SIZE  and  --pmc WRITE_SIZE  (separate passes, kernel trace only; MI355X_MICROARCH.md "HBM":
      on gfx950 FETCH_SIZE counts half of a wide streaming read, so bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB)
-                                                                                      -> profiles/<tag>_pmc_traffic.json
-  3. rocprofv3 --pmc <SQ counters> (LDS bank conflicts, wait / issue cycles)        -> profiles/<tag>_pmc_sq.json
+                                                                                      -> <tag>_pmc_traffic.json
+  3. rocprofv3 --pmc <SQ counters> (LDS bank conflicts, wait / issue cycles)        -> <tag>_pmc_sq.json
 
 Every file carries `csrc_sha` (openmm_drudenose_amd/build.py::source_sha) and the step variant; bench.py quotes
 `roofline.traffic` from <tag>_pmc_traffic.json only when both match the binary and the variant it is running.
@@ -77,7 +78,9 @@ def main():
     scratch = os.path.join(ROOT, "gpurun_out", f"prof_{a.tag}")
     shutil.rmtree(scratch, ignore_errors=True)
     os.makedirs(scratch)
-    prof = os.path.join(ROOT, "profiles")
+    # on the GPU box only gpurun_out/ travels back: the files are written there and copied into profiles/ (tracked) afterwards
+    prof = os.path.join(ROOT, "gpurun_out", "profiles_out")
+    os.makedirs(prof, exist_ok=True)
     bench = ["python3", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(a.steps), "--warmup", str(a.warmup),
              "--molecules", str(a.molecules), "--variant", a.variant]
     lean = bench + ["--no-extra", "--no-cpu-baseline"]
@@ -94,7 +97,8 @@ def main():
     stats = glob.glob(os.path.join(scratch, "trace", "**", "*_kernel_stats.csv"), recursive=True)[0]
     shutil.copy(stats, os.path.join(prof, f"{a.tag}_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats)))
-    dom_name = max((r for r in rows if "tgnh" in r["Name"]), key=lambda r: float(r["AverageNs"]))["Name"]
+    prec = line["config"]["precision"]
+    dom = f"step_kernel<{prec}>" if line["roofline"]["kernel"] == "step_kernel" else f"tile<{prec},prekick+rescale+kick+drift>"
     with open(os.path.join(prof, f"{a.tag}_summary.md"), "w") as f:
         f.write(f"`rocprofv3 --kernel-trace --stats -- {' '.join(bench)}`  \ncsrc_sha `{sha}`, variant `{variant}`, {slots} slots; "
                 f"bench line: {line['value']} steps/s, roofline.avg_launch_us {line['roofline']['avg_launch_us']} (HIP events)\n\n")
@@ -116,7 +120,7 @@ def main():
             res[k]["launches"] = cs[c][1]
     for k, v in res.items():
         v["hbm_bytes_per_launch"] = int((2 * v.get("FETCH_SIZE_KiB", 0) + v.get("WRITE_SIZE_KiB", 0)) * 1024)
-    res["dominant"] = dict(res[pretty(dom_name)], kernel=pretty(dom_name))
+    res["dominant"] = dict(res[dom], kernel=dom)
     json.dump(dict(stamp, note="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes with --kernel-trace only; raw counters in KiB; "
                                "gfx950: FETCH_SIZE counts half of a wide streaming read (MI355X_MICROARCH.md, HBM) -> "
                                "hbm_bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024; Infinity-Cache hits are counted, not excluded",
