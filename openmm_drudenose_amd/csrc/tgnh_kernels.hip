@@ -200,9 +200,10 @@ __device__ __forceinline__ void tile_load(const TileArgs& a, const int t, TileIn
 }
 
 // One tile, loaded into `cur`, through the operations OPS (A3/A4, A6, A7, A8, A10).  Ends with the LDS images free.
-// REUSE_IMG (step_kernel): the velocity image and the COM table of this very tile are still in LDS from the pass before.
-template <int PREC, int OPS, int GB, bool REUSE_IMG = false>
-__device__ __forceinline__ void tile_body(const TileArgs& a, TileEnv<PREC, GB>& e, const TileIn<PREC>& cur, const int trace_tile) {
+// reuse_img (step_kernel): the velocity image and the COM table of this very tile are still in LDS from the pass before.
+template <int PREC, int OPS, int GB>
+__device__ __forceinline__ void tile_body(const TileArgs& a, TileEnv<PREC, GB>& e, const TileIn<PREC>& cur, const int trace_tile,
+                                          const bool reuse_img = false) {
     typedef typename Prec<PREC>::real real;
     typedef typename Prec<PREC>::mixed mixed;
     typedef typename Prec<PREC>::real4 real4;
@@ -276,7 +277,7 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, TileEnv<PREC, GB>& 
 
     // ---------------- A6: rescale (K :249-301 ; Ref :516-541) ----------------
     if (DO_SCALE) {
-      if (!REUSE_IMG) {
+      if (!reuse_img) {
 #pragma unroll
         for (int k = 0; k < SPT; k++) st_img(sv, k * TBLOCK + tid, img(k));
         __syncthreads();
@@ -801,26 +802,28 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
     __syncthreads();
     const unsigned long long want = (unsigned long long)(s_gen + 1u);
     if (leader) {
-        double acc[CHAIN_INLINE_SUM_NT];
+        constexpr int NTM = GB + 2;                        // NT = G + 2 <= GB + 2: the register arrays follow the instantiation
+        double acc[NTM];
 #pragma unroll
-        for (int b = 0; b < CHAIN_INLINE_SUM_NT; b++) acc[b] = 0.0;
+        for (int b = 0; b < NTM; b++) acc[b] = 0.0;
         bool ok = true;
+#pragma unroll 1
         for (int r = tid; r < grid && ok; r += TBLOCK) {
             const unsigned long long* cell = a.rows + (size_t)r * NT * 2;
-            unsigned long long w[2 * CHAIN_INLINE_SUM_NT];
+            unsigned long long w[2 * NTM];
             unsigned n = 0;
             for (;;) {                                     // a row's cells in one batch of loads; again until all carry the tag
                 bool all = true;
 #pragma unroll
-                for (int b = 0; b < 2 * CHAIN_INLINE_SUM_NT; b++) if (b < 2 * NT) w[b] = xchg_ld(cell + b);
+                for (int b = 0; b < 2 * NTM; b++) if (b < 2 * NT) w[b] = xchg_ld(cell + b);
 #pragma unroll
-                for (int b = 0; b < 2 * CHAIN_INLINE_SUM_NT; b++) if (b < 2 * NT) all = all && (w[b] >> 32) == want;
+                for (int b = 0; b < 2 * NTM; b++) if (b < 2 * NT) all = all && (w[b] >> 32) == want;
                 if (all) break;
                 if (++n > XCHG_SPIN_LIMIT) { ok = false; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
 #pragma unroll
-            for (int b = 0; b < CHAIN_INLINE_SUM_NT; b++)
+            for (int b = 0; b < NTM; b++)
                 if (b < NT) acc[b] += __longlong_as_double((long long)((w[2 * b + 1] << 32) | (w[2 * b] & 0xffffffffull)));
         }
         if (!ok) {                                         // a work-group never handed in its row: nobody goes on
@@ -830,9 +833,9 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
         const double* big = a.partials + (size_t)GRID_CAP * NT;               // rows of big_com_kernel (an earlier launch)
         for (int r = tid; r < a.chain.nbig; r += TBLOCK)
 #pragma unroll
-            for (int b = 0; b < CHAIN_INLINE_SUM_NT; b++) if (b < NT) acc[b] += big[(size_t)r * NT + b];
+            for (int b = 0; b < NTM; b++) if (b < NT) acc[b] += big[(size_t)r * NT + b];
 #pragma unroll
-        for (int b = 0; b < CHAIN_INLINE_SUM_NT; b++) {
+        for (int b = 0; b < NTM; b++) {
             if (b < NT) {
                 const double t = wave_sum(acc[b]);
                 if ((tid & 63) == 0) s_part[tid >> 6][b] = t;
@@ -874,11 +877,11 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
 
     // ---- pass 2, backwards from the held tile
     tt = tt_last;
-    tile_body<PREC, STEP_OPS2, GB, true>(a, e, cur, 0);    // image and COM table of pass 1
-    while (tt - grid >= 0) {
+    for (bool held = true;; held = false) {                // (one call site: two cost 40 VGPRs and a work-group per CU)
+        tile_body<PREC, STEP_OPS2, GB>(a, e, cur, 0, held);  // the held tile: image and COM table of pass 1
+        if (tt - grid < 0) break;
         tt -= grid;
         tile_load<PREC, STEP_OPS2>(a, tile_of(tt), cur);
-        tile_body<PREC, STEP_OPS2, GB>(a, e, cur, 0);
     }
     TRACE(15);
 }

@@ -1,0 +1,28 @@
+"""Register budgets of the hot kernels (CPU: hipcc cross-compiles gfx950 and reports resource usage).  The streaming
+kernels live at a chosen occupancy -- rescale+kick+drift and step_kernel at 3 work-groups per CU (<= 168 VGPRs), the
+read-only kick+KE pass at 5 (<= 96) -- and nothing may spill; a harmless-looking edit (a second call site of the tile body,
+a register array sized for the largest case) has cost a work-group per CU before without any test failing."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_hot_kernels_keep_their_occupancy():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = {}
+    for line in out.stdout.splitlines():
+        m = re.match(r"(\S+<[^>]*>)\s+VGPR\s+(\d+)\s+AGPR\s+\d+\s+SGPR\s+\S+\s+scratch\s+(\d+)\s+occ\s+(\d+)", line)
+        if m:
+            rows[m.group(1).replace(" ", "")] = (int(m.group(2)), int(m.group(3)), int(m.group(4)))
+    assert len(rows) > 40, out.stdout[-2000:]
+    spills = {k: v for k, v in rows.items() if v[1] != 0}
+    assert not spills, spills
+    for prec in (0, 1, 2):
+        for gb in (1, 4):
+            assert rows[f"step_kernel<{prec},{gb}>"][0] <= 168, rows[f"step_kernel<{prec},{gb}>"]          # 3 work-groups per CU
+            assert rows[f"tile_kernel<{prec},71,1>"][0] <= 168 and rows[f"tile_kernel<{prec},7,1>"][0] <= 168      # (no KE bins: one instantiation)
+            assert rows[f"tile_kernel<{prec},138,{gb}>"][0] <= 96, rows[f"tile_kernel<{prec},138,{gb}>"]   # 5 work-groups per CU
