@@ -426,7 +426,7 @@ __device__ __forceinline__ void xchg_send(const XchgArgs& x, const int NT, const
 // Returns the all-rank sum of thermostat `lane` (lanes < NT).  seq_expected != 0: the exchange to wait for when this
 // rank's own send may not have happened yet (step_kernel: sender and waiters are work-groups of one launch).
 __device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT, const int lane, double* s_val,
-                                                const unsigned long long seq_expected = 0ull) {
+                                                const unsigned long long seq_expected = 0ull, bool* failed = nullptr) {
     const int cells = x.world * NT;
     // first batch: counter, latch and both parities of this lane's first cell, all in flight together
     const unsigned long long seq_raw = seq_expected ? seq_expected : __hip_atomic_load(x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -459,6 +459,7 @@ __device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT,
         atomicOr(x.status, 4u);
         __hip_atomic_store(x.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (failed) *failed = __any(timed_out) || dead != 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -748,8 +748,10 @@ constexpr int STEP_OPS1 = OP_KICK | OP_KE | OP_NOSTORE;
 constexpr int STEP_OPS2 = OP_PREKICK | OP_SCALE | OP_KICK | OP_DRIFT;
 
 // (Measured and dropped, profiles/r02_resident_tuning.md: a second register image to load a work-group's next tile under
-// the current one -- 198 VGPRs, occupancy 2 -- and tiles cut to N / (k x work-groups) slots for equal walks: both a few
-// per cent slower at 625 k slots.  Pass 2 already moves its 73 MB at the 6.6 TB/s the Infinity Cache gives.)
+// the current one -- in both passes: 198 VGPRs, occupancy 2; in pass 1 alone: free in registers, no gain -- and tiles cut
+// to N / (k x work-groups) slots for equal walks.  A pass costs ~2 us of a compute unit's time per tile whether a
+// work-group walks one tile or two: it is the unit's three resident work-groups that overlap each other, not a
+// work-group its own tiles.  Pass 2 already moves its 73 MB at the 6.6 TB/s the Infinity Cache gives.)
 template <int PREC, int GB>
 __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileArgs a) {
     typedef typename Prec<PREC>::mixed mixed;
@@ -853,11 +855,11 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
         __syncthreads();
     }
     if (chain_wave) {
-        const double mine = xchg_wait_sum(a.chain.x, NT, itg, s_x + 64, seq0 + 1ull);
+        bool dead = false;                                 // an exchange has timed out, now or earlier (the latch)
+        const double mine = xchg_wait_sum(a.chain.x, NT, itg, s_x + 64, seq0 + 1ull, &dead);
         TRACE(8);
         double kesum = 0.0;
         for (int i = 0; i < NT; i++) kesum += __shfl(mine, i, 64);
-        const bool dead = __hip_atomic_load(a.chain.x.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
         if (itg == 0) s_go = dead ? 0 : 1;
         if (!dead) {
             const bool write = leader;
