@@ -983,6 +983,88 @@ CONFIGS = {
 }
 
 
+def test_config3_with_shake_at_its_stated_size():
+    """BASELINE config 3 as worded: [BMIM][BF4]-like ionic liquid, 100 k atoms, 2 temperature groups **+ SHAKE** (the 15 X-H
+    bonds per cation): the split path with the harness SHAKE / velocity stage as call-outs, against the oracle's constrained
+    loop (solver tolerance 1e-10 on both sides)."""
+    s, g, ng = synth.ionic_liquid(2222, constrained=True)
+    it = integ(chains=1, hardwall=0.0)
+    it.setConstraintTolerance(1e-10)
+    bind_groups(it, g, ng)
+    ctx = HipContext(s, it, mode="TGNH", precision="mixed")
+    assert ctx.constrained and len(s.constraints) == 15 * 2222
+    o = make_oracle(s, g, ng, "TGNH", it)
+    pos, vel, x0 = s.positions.copy(), s.velocities.copy(), ctx.sites()
+    f = o.harness_force(pos, x0, synth.K_DRUDE, synth.K_TETHER)
+    o.run_harness_constrained(pos, vel, f, x0, synth.K_DRUDE, synth.K_TETHER, 1e-10, 30)
+    ctx.step(30)
+    ep, ev = rel_err(ctx.getPositions(), pos), rel_err(ctx.getVelocities(), vel)
+    print(f"C3 with SHAKE: N={s.num_particles} constraints={len(s.constraints)} pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= TOL and ev <= TOL and ctx.check() == 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,nranks,nsteps", [("C4 mixed 500k atoms, 4 groups, hard wall", 4, 10), ("C5 SWM4 2M atoms", 8, 6)])
+def test_configs_4_and_5_particle_sharded_at_their_stated_size(name, nranks, nsteps):
+    """BASELINE configs 4 and 5 as worded -- particle-sharded 4x and 8x -- as far as one GPU goes: the shards are handles on
+    this GPU, each handle's all-reduce hook adds the other shards' kinetic-energy sums (what RCCL does across GPUs), dof
+    terms summed over the shards.  Against the unsharded HIP run of the same system (which test_config_sizes_parity holds
+    against the oracle): positions 1e-12, velocities 1e-10, thermostats bitwise over the shards."""
+    from openmm_drudenose_amd.system import shard_bounds
+    build, hardwall, _ = CONFIGS[name]
+    s, g, ng = build()
+    it = integ(chains=1, hardwall=hardwall)
+    bind_groups(it, g, ng)
+    ref = HipContext(s, it, mode="TGNH", precision="mixed")
+    torch = ref.torch
+    b = shard_bounds(s, nranks)
+    parts, terms = [], []
+    for r in range(nranks):
+        loc, lg = s.slice_molecules(b[r], b[r + 1]), g[b[r]:b[r + 1]]
+        itr = integ(chains=1, hardwall=hardwall)
+        bind_groups(itr, lg, ng)
+        parts.append(HipContext(loc, itr, mode="TGNH", precision="mixed"))
+        terms.append(parts[-1].local_dof_terms())
+    total = sum(terms)
+    assert np.allclose(total, ref.local_dof_terms(), rtol=1e-11)       # red_g is a sum over 10^5..10^6 particles
+    ref.set_global_dof_terms(total)                                    # the very same N kT and Q on both sides
+    reduced = [None]                        # what the all-reduce delivers: the shards' sums added in rank order, same bits everywhere
+    for r, ctx in enumerate(parts):
+        ctx.set_global_dof_terms(total)
+        ctx.set_allreduce(lambda t: t.copy_(reduced[0]) if reduced[0] is not None else None)
+
+    def exchange():
+        reduced[0] = None
+        ke = [torch.from_numpy(c.compute_kinetic_energies()).to(c.dev) for c in parts]
+        tot = ke[0].clone()
+        for k in ke[1:]:
+            tot += k
+        reduced[0] = tot
+    lib = ref.lib
+    for _ in range(nsteps):
+        ref.step_begin(); ref.compute_forces(); ref.step_end()
+        exchange()
+        for c in parts:
+            c.step_begin()
+        for c in parts:
+            c.compute_forces()
+        for c in parts:
+            assert lib.tgnh_step_end_kick(c.h, c._stream()) == 0
+        exchange()
+        for c in parts:
+            assert lib.tgnh_step_end_thermo(c.h, c._stream()) == 0
+    pos = np.concatenate([c.getPositions() for c in parts])
+    vel = np.concatenate([c.getVelocities() for c in parts])
+    ep, ev = rel_err(pos, ref.getPositions()), rel_err(vel, ref.getVelocities())
+    print(f"{name}, {nranks} shards of {[c.n for c in parts]} slots: pos {ep:.2e} vel {ev:.2e}")
+    assert ep < 1e-12 and ev < 1e-10
+    for c in parts[1:]:
+        assert np.array_equal(parts[0].thermostat_state(1), c.thermostat_state(1))
+    assert np.allclose(parts[0].thermostat_state(1), ref.thermostat_state(1), rtol=1e-9, atol=1e-13)
+    for c in parts + [ref]:
+        c.close()
+
+
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_config_sizes_parity(name):
     build, hardwall, nsteps = CONFIGS[name]
