@@ -406,11 +406,12 @@ __device__ __forceinline__ unsigned long long xchg_ld(const unsigned long long* 
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // Called by one work-group with `mine` = this rank's sum in thread tid < NT, handed over through s_val (LDS, NT doubles).
-// Contains __syncthreads().
+// Contains __syncthreads().  seq_new != 0 (thread 0): the number of this exchange, when the caller has read the counter
+// already (step_kernel reads it at kernel entry: no load on the path between the last row and the send).
 __device__ __forceinline__ void xchg_send(const XchgArgs& x, const int NT, const int tid, const int nthreads, double* s_val,
-                                          const double mine) {
+                                          const double mine, const unsigned long long seq_new = 0ull) {
     __shared__ unsigned long long s_seq;
-    if (tid == 0) { const unsigned long long s = *x.seq + 1ull; *x.seq = s; s_seq = s; }
+    if (tid == 0) { const unsigned long long s = seq_new ? seq_new : *x.seq + 1ull; *x.seq = s; s_seq = s; }
     if (tid < NT) s_val[tid] = mine;
     __syncthreads();
     const unsigned long long seq = s_seq, tag = (seq & 0xffffffffull) << 32;

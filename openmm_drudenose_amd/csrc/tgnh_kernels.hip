@@ -809,24 +809,37 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
 #pragma unroll
         for (int b = 0; b < NTM; b++) acc[b] = 0.0;
         bool ok = true;
+        // RB rows of this thread per batch of loads (all of them for the resident grid of 768 when G = 1): once the last row
+        // is there, one more round trip sees everything -- polled row after row, a thread whose first row came last paid
+        // a round trip for each of the others behind it
+        constexpr int RB = GB == 1 ? 3 : 1;
 #pragma unroll 1
-        for (int r = tid; r < grid && ok; r += TBLOCK) {
-            const unsigned long long* cell = a.rows + (size_t)r * NT * 2;
-            unsigned long long w[2 * NTM];
+        for (int r0 = tid; r0 < grid && ok; r0 += RB * TBLOCK) {
+            unsigned long long w[RB][2 * NTM];
             unsigned n = 0;
-            for (;;) {                                     // a row's cells in one batch of loads; again until all carry the tag
+            for (;;) {
                 bool all = true;
 #pragma unroll
-                for (int b = 0; b < 2 * NTM; b++) if (b < 2 * NT) w[b] = xchg_ld(cell + b);
+                for (int k = 0; k < RB; k++) {
+                    const int r = r0 + k * TBLOCK;
+                    const unsigned long long* cell = a.rows + (size_t)r * NT * 2;
 #pragma unroll
-                for (int b = 0; b < 2 * NTM; b++) if (b < 2 * NT) all = all && (w[b] >> 32) == want;
+                    for (int b = 0; b < 2 * NTM; b++) if (b < 2 * NT && r < grid) w[k][b] = xchg_ld(cell + b);
+                }
+#pragma unroll
+                for (int k = 0; k < RB; k++)
+#pragma unroll
+                    for (int b = 0; b < 2 * NTM; b++) if (b < 2 * NT && r0 + k * TBLOCK < grid) all = all && (w[k][b] >> 32) == want;
                 if (all) break;
                 if (++n > XCHG_SPIN_LIMIT) { ok = false; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
 #pragma unroll
-            for (int b = 0; b < NTM; b++)
-                if (b < NT) acc[b] += __longlong_as_double((long long)((w[2 * b + 1] << 32) | (w[2 * b] & 0xffffffffull)));
+            for (int k = 0; k < RB; k++)                    // row order: r0, r0 + 256, ...
+#pragma unroll
+                for (int b = 0; b < NTM; b++)
+                    if (b < NT && r0 + k * TBLOCK < grid)
+                        acc[b] += __longlong_as_double((long long)((w[k][2 * b + 1] << 32) | (w[k][2 * b] & 0xffffffffull)));
         }
         if (!ok) {                                         // a work-group never handed in its row: nobody goes on
             atomicOr(a.status, 8u);
@@ -851,7 +864,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
         }
         TRACE(7);
         if (tid == 0) a.sync[1] = s_gen + 1u;              // the next launch's rows carry the next tag
-        xchg_send(a.chain.x, NT, tid, TBLOCK, s_x, mine);
+        xchg_send(a.chain.x, NT, tid, TBLOCK, s_x, mine, seq0 + 1ull);
         __syncthreads();
     }
     if (chain_wave) {
