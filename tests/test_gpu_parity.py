@@ -926,6 +926,32 @@ def test_bridge_identity_on_the_gpu():
         t.close(); d.close()
 
 
+def test_10000_steps_all_pass_structures_track_the_oracle():
+    """Ten picoseconds, 1000 waters, double precision: the reference's pass structure, the deferred one and the one-launch
+    step all stay on the oracle's trajectory (the thermostats swing the group temperature between 30 and 1200 K on this
+    harmonic workload -- every branch of the on-device chain arithmetic gets exercised, not only its first 100 steps)."""
+    s, g, ng = SYSTEMS["water1000"]()
+    ctxs = {}
+    for name, flags in (("plain", 0), ("deferred", FLAG_DEFER_SCALE), ("resident", RESIDENT)):
+        it = integ(chains=1, hardwall=0.02)
+        bind_groups(it, g, ng)
+        ctxs[name] = HipContext(s, it, mode="TGNH", precision="double", flags=flags)
+    it = integ(chains=1, hardwall=0.02)
+    o = make_oracle(s, g, ng, "TGNH", it)
+    pos, vel, x0 = s.positions.copy(), s.velocities.copy(), ctxs["plain"].sites()
+    f = o.harness_force(pos, x0, synth.K_DRUDE, synth.K_TETHER)
+    worst = {n: 0.0 for n in ctxs}
+    for _ in range(10):
+        o.run_harness(pos, vel, f, x0, synth.K_DRUDE, synth.K_TETHER, 1000)
+        for n, c in ctxs.items():
+            c.step(1000)
+            worst[n] = max(worst[n], rel_err(c.getVelocities(), vel), rel_err(c.getPositions(), pos))
+    print("10000 steps, max rel err over the run:", {n: f"{w:.1e}" for n, w in worst.items()})
+    for n, c in ctxs.items():
+        assert worst[n] <= 1e-7 and c.check() == 0, (n, worst[n])
+        c.close()
+
+
 @pytest.mark.parametrize("flags", [0, FLAG_DEFER_SCALE])
 def test_1000_step_mixed_precision_gate(flags):
     """north_star's tolerance is stated over 100 steps; mixed precision keeps positions as float + float correction,

@@ -11,6 +11,7 @@
   probe.py placement [molecules] [pools]                     does a launch's speed go with where the driver put the buffers?
   probe.py drift [molecules]                                 does the dominant launch drift in time (clock ramp, idle gaps)?
   probe.py soak [steps] [waters] [lag]                       two-process mailbox exchange on one GPU, many thousand exchanges
+  probe.py resident-soak                                     step_kernel for 10^5 launches at three sizes: no meeting may time out
 """
 import json
 import os
@@ -235,8 +236,36 @@ def soak(argv):
               f"finite {all(np.isfinite(v).all() for v in vel)}", flush=True)
 
 
+def resident_soak(argv):
+    import numpy as np
+    import torch
+    from openmm_drudenose_amd import synth
+    from openmm_drudenose_amd.drudetgnhplugin import DrudeTGNHIntegrator, HipContext, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP
+    for mol, steps in ((125000, 150000), (20000, 300000), (1000000, 4000)):
+        s, g, ng = synth.water_box(mol)
+        it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, 1, True, True)
+        it.setMaxDrudeDistance(0.02)
+        ctx = HipContext(s, it, mode="TGNH", precision="mixed", flags=FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP)
+        ctx.step(20)
+        torch.cuda.synchronize()
+        rep = ctx.capture_steps(10)
+        rep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps // 10):
+            rep()
+            if i % 5000 == 4999:
+                torch.cuda.synchronize()
+                print(mol, "steps", (i + 1) * 10, "status word", ctx.status_flags(), flush=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"{mol} molecules: {steps} steps in {dt:.1f} s = {steps / dt:.0f} steps/s, status word {ctx.status_flags()}, "
+              f"velocities finite {np.isfinite(ctx.getVelocities()).all()}", flush=True)
+        ctx.close()
+
+
 if __name__ == "__main__":
-    cmds = {"knob": knob, "variants": variants, "chain": chain, "copy": copy, "stream": stream, "placement": placement,
+    cmds = {"resident-soak": resident_soak, "knob": knob, "variants": variants, "chain": chain, "copy": copy, "stream": stream, "placement": placement,
             "drift": drift, "soak": soak}
     if len(sys.argv) < 2 or sys.argv[1] not in cmds:
         raise SystemExit(__doc__)
