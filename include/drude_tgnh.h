@@ -136,6 +136,9 @@ tgnh_status tgnh_set_allreduce(tgnh_handle h, tgnh_allreduce_fn fn, void* user);
  * them).  Several handles that step concurrently on one device (replicas, or the ranks of a rehearsal on one GPU) must
  * share it, or their launches wait for each other's work-groups until the meeting times out (status bit 3). */
 tgnh_status tgnh_set_resident_share(tgnh_handle h, int share);
+/* Work-groups of the resident step kernel per compute unit that tgnh_create found resident together (a census launch checks
+ * the occupancy query); 0 = the handle steps the DEFER_SCALE way (flag not set, or nothing passed the census). */
+tgnh_status tgnh_get_resident_work_groups(tgnh_handle h, int* per_compute_unit);
 
 /* Mailbox exchange: the same all-reduce of the NT kinetic-energy sums, done by the integrator's own kernels with
  * plain stores into every peer's mailbox over xGMI (no collective launch on the step's critical path).  Optional;

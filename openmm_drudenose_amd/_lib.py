@@ -50,6 +50,7 @@ SIGNATURES = {
     "tgnh_set_global_dof_terms": (C.c_int, [C.c_void_p, c_f64p, C.c_int]),
     "tgnh_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "tgnh_set_resident_share": (C.c_int, [C.c_void_p, C.c_int]),
+    "tgnh_get_resident_work_groups": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "tgnh_exchange_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "tgnh_exchange_attach": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tgnh_exchange_attach_pointers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -42,6 +42,7 @@ static tgnh_status entry(tgnh_handle h, bool need_bufs);
 static tgnh_status flush_impl(tgnh_handle h, hipStream_t s);
 static tgnh_status settle_kick(tgnh_handle h, hipStream_t s);
 static tgnh_status settle_end(tgnh_handle h, hipStream_t s);
+static bool resident_now(tgnh_handle h);
 
 // ---------------------------------------------------------------------------
 // A1: topology + tiles
@@ -525,8 +526,8 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         *c->h_status_seen = 0;
 
         HIP_OK(hipMalloc(&c->d_scalar, sizeof(double)));
-        HIP_OK(hipMalloc(&c->d_sync, 2 * sizeof(unsigned int)));
-        HIP_OK(hipMemset(c->d_sync, 0, 2 * sizeof(unsigned int)));
+        HIP_OK(hipMalloc(&c->d_sync, 4 * sizeof(unsigned int)));
+        HIP_OK(hipMemset(c->d_sync, 0, 4 * sizeof(unsigned int)));
         if (c->d.flags & TGNH_FLAG_RESIDENT_STEP) {
             // step_kernel's meeting place: the work-groups' tagged rows, and a private one-rank mailbox that carries the
             // sums from work-group 0 to all the others when no sharded exchange is attached (uncached, like the mailboxes)
@@ -548,6 +549,22 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
             c->self_x.seq = c->d_self_misc;
             c->self_x.dead = reinterpret_cast<unsigned int*>(c->d_self_misc + 1);
             c->self_x.status = c->d_status;
+            // How many work-groups of step_kernel per compute unit are resident TOGETHER?  The occupancy API's answer is
+            // checked by a census launch (every work-group checks in and waits for all the others, bounded); one fewer per
+            // unit is tried until a grid passes.  0 = none did: the handle steps the DEFER_SCALE way.
+            if (c->gb != 0 && c->L.C == 1 && c->L.NT <= CHAIN_INLINE_SUM_NT) {
+                const size_t lds = tile_lds_bytes(c->d.precision, OP_PREKICK | OP_SCALE | OP_KICK | OP_DRIFT, true, true);
+                for (int per_cu = std::min(step_blocks_per_cu(c->d.precision, c->gb, lds), 8); per_cu >= 1 && !c->resident_per_cu; per_cu--) {
+                    TileArgs a{};
+                    a.census = 1; a.sync = c->d_sync;
+                    HIP_OK(hipMemset(c->d_sync + 2, 0, 2 * sizeof(unsigned int)));
+                    const int grid = std::min(per_cu * c->num_cus, GRID_CAP);
+                    HIP_OK(launch_step(c->d.precision, c->gb, a, grid, lds, (hipStream_t)0));
+                    unsigned int res[2] = {0, 1};
+                    HIP_OK(hipMemcpy(res, c->d_sync + 2, sizeof(res), hipMemcpyDeviceToHost));
+                    if (res[0] == (unsigned)grid && res[1] == 0) c->resident_per_cu = per_cu;
+                }
+            }
         }
         return TGNH_OK;
     };
@@ -723,6 +740,13 @@ extern "C" tgnh_status tgnh_set_allreduce(tgnh_handle h, tgnh_allreduce_fn fn, v
     CHECK_H(h);
     tgnh_status rc = deferred_guard(h, "tgnh_set_allreduce"); if (rc) return rc;
     h->allreduce = fn; h->allreduce_user = user;
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_get_resident_work_groups(tgnh_handle h, int* per_compute_unit) {
+    CHECK_H(h);
+    if (!per_compute_unit) return fail(TGNH_ERR_ARG, "null out");
+    *per_compute_unit = resident_now(h) ? h->resident_per_cu : 0;
     return TGNH_OK;
 }
 
@@ -962,7 +986,7 @@ static tgnh_status materialize_chain(tgnh_handle h, hipStream_t s) {
 // Eligible: deferred pass structure, one-link chains (the chain runs inside the launch), at most 8 temperature groups,
 // and an exchange the kernel can do itself (none, or the mailboxes -- a collective hook is a launch of its own).
 static bool resident_now(tgnh_handle h) {
-    return (h->d.flags & TGNH_FLAG_RESIDENT_STEP) && (h->d.flags & TGNH_FLAG_DEFER_SCALE) && h->d_rows && h->inline_chain && h->gb != 0 &&
+    return (h->d.flags & TGNH_FLAG_RESIDENT_STEP) && (h->d.flags & TGNH_FLAG_DEFER_SCALE) && h->resident_per_cu > 0 && h->inline_chain && h->gb != 0 &&
            h->L.NT <= CHAIN_INLINE_SUM_NT && (h->xchg_on || !h->allreduce);
 }
 
@@ -972,11 +996,8 @@ static tgnh_status run_resident_step(tgnh_handle h, hipStream_t s) {
     const bool hw = a.hardwall != 0;
     const size_t lds = tile_lds_bytes(h->d.precision, OP_PREKICK | OP_SCALE | OP_KICK | OP_DRIFT, hw, a.use_com != 0);
     int& grid = hw ? h->resident_grid_hw : h->resident_grid;
-    if (grid == 0) {       // the work-groups that are resident at once -- all of them meet inside the launch
-        int per_cu = step_blocks_per_cu(h->d.precision, h->gb, lds);
-        if (per_cu < 1) return fail(TGNH_ERR_HIP, "step_kernel: occupancy query failed");
-        grid = std::max(1, std::min(std::min(h->num_tiles, per_cu * h->num_cus / h->resident_share), GRID_CAP));
-    }
+    if (grid == 0)         // the work-groups that are resident at once (counted at create) -- all of them meet inside the launch
+        grid = std::max(1, std::min(std::min(h->num_tiles, h->resident_per_cu * h->num_cus / h->resident_share), GRID_CAP));
     a.chain_on = 1;
     a.chain = chain_args(h);
     a.chain.chain_twice = 1;

@@ -97,6 +97,7 @@ constexpr int XCHG_NT_PAD = 40;             // cells per source rank (NT <= 34)
 constexpr int XCHG_CELL_U64 = 2;            // 8-byte words per cell
 constexpr int XCHG_MAX_WORLD = 16;
 constexpr unsigned XCHG_SPIN_LIMIT = 1000000u;  // polls (each a round trip to memory, ~2 us) before giving up: seconds
+constexpr unsigned CENSUS_SPIN_LIMIT = 20000u;  // the residency census of step_kernel: tens of milliseconds
 constexpr size_t XCHG_MAILBOX_BYTES(int world) { return sizeof(unsigned long long) * 2 * (size_t)world * XCHG_NT_PAD * XCHG_CELL_U64; }
 
 struct XchgArgs {
@@ -144,7 +145,8 @@ struct TileArgs {
     const double* scale;       // [NT] velocity scale factors (device)
     double* partials;          // [grid][NT] per-work-group KE partial sums
     uint32_t* status;          // bit0: Drude beyond 2x hard wall; bit2: exchange time-out; bit3: step_kernel's meeting timed out
-    unsigned int* sync;        // step_kernel: [1] number of the last launch (its rows' tag)
+    unsigned int* sync;        // step_kernel: [1] number of the last launch (its rows' tag); census: [2] work-groups checked in, [3] one gave up
+    int census;                // step_kernel: residency check only (tgnh_create)
     unsigned long long* rows;  // step_kernel: [grid][NT] tagged cells (2 words each), uncached
     int num_tiles;
     int reverse;               // walk the tiles last-to-first: start where the previous launch ended (its lines are still in the Infinity Cache)
@@ -276,6 +278,7 @@ struct tgnh_context {
     unsigned long long* d_self_misc = nullptr;   // ... its counter, latch and peer table
     tgnh::XchgArgs self_x{};
     int resident_grid = 0, resident_grid_hw = 0, resident_share = 1;
+    int resident_per_cu = 0;          // work-groups of step_kernel per compute unit that the census at create found resident together (0: none -- the handle steps the DEFER_SCALE way)
     bool first_half_done = false;     // DEFER_SCALE: chain for the coming step's first half already run
     double time = 0;
     int64_t step_count = 0;

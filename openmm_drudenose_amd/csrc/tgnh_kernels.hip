@@ -765,6 +765,19 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
     const int grid = (int)gridDim.x;
     const bool chain_wave = tid < 64, leader = blockIdx.x == 0;
     const int itg = tid & 63;
+    if (a.census) {
+        // One-time check at tgnh_create that a grid of this size really is resident all at once (the occupancy API can be
+        // one work-group per compute unit high, MI355X_MICROARCH.md "Correctness boundaries"): every work-group checks in
+        // at a counter and waits, bounded, until all have; one that gives up says so.  Nothing else is touched.
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&a.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned n = 0;
+            while (__hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && ++n < CENSUS_SPIN_LIMIT)
+                __builtin_amdgcn_s_sleep(16);
+            if (__hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) atomicOr(&a.sync[3], 1u);
+        }
+        return;
+    }
     TileEnv<PREC, GB> e;
     e.init(a, smem, s_scale, a.hardwall != 0);
     auto tile_of = [&](int tt) { return a.reverse ? a.num_tiles - 1 - tt : tt; };

@@ -380,6 +380,12 @@ class HipContext(_HandleQueries):
         """FLAG_RESIDENT_STEP: this context may fill 1/share of the device (several contexts stepping concurrently)."""
         _check(self.lib.tgnh_set_resident_share(self.h, int(share)))
 
+    def resident_work_groups(self):
+        """Work-groups of step_kernel per compute unit found resident together at create (0: the deferred launches run)."""
+        n = C.c_int()
+        _check(self.lib.tgnh_get_resident_work_groups(self.h, C.byref(n)))
+        return n.value
+
     def exchange_detach(self):
         _check(self.lib.tgnh_exchange_detach(self.h))
 

@@ -430,6 +430,7 @@ def test_resident_step_is_the_deferred_integrator():
     ref = make("mixed", "TGNH", "double", flags=FLAG_DEFER_SCALE, chains=1, hardwall=0.02)
     alt = make("mixed", "TGNH", "double", flags=RESIDENT, chains=1, hardwall=0.02)
     gra = make("mixed", "TGNH", "double", flags=RESIDENT, chains=1, hardwall=0.02)
+    assert 1 <= alt[4].resident_work_groups() <= 8 and ref[4].resident_work_groups() == 0     # the census at create passed
     alt[4].timing(True)
     ref[4].step(30); alt[4].step(30); gra[4].step(30)
     alt[4].torch.cuda.synchronize()
