@@ -824,35 +824,42 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
         bool ok = true;
         // RB rows of this thread per batch of loads (all of them for the resident grid of 768 when G = 1): once the last row
         // is there, one more round trip sees everything -- polled row after row, a thread whose first row came last paid
-        // a round trip for each of the others behind it
-        constexpr int RB = GB == 1 ? 3 : 1;
+        // a round trip for each of the others behind it.  CH thermostats of a row per batch: the registers a batch takes
+        // (2 x CH x RB words) do not grow with the number of temperature groups.
+        constexpr int RB = GB == 1 ? 3 : 1, CH = 3;
 #pragma unroll 1
         for (int r0 = tid; r0 < grid && ok; r0 += RB * TBLOCK) {
-            unsigned long long w[RB][2 * NTM];
-            unsigned n = 0;
-            for (;;) {
-                bool all = true;
+#pragma unroll 1
+            for (int b0 = 0; b0 < NT && ok; b0 += CH) {
+                unsigned long long w[RB][2 * CH];
+                unsigned n = 0;
+                for (;;) {
+                    bool all = true;
 #pragma unroll
-                for (int k = 0; k < RB; k++) {
-                    const int r = r0 + k * TBLOCK;
-                    const unsigned long long* cell = a.rows + (size_t)r * NT * 2;
+                    for (int k = 0; k < RB; k++) {
+                        const int r = r0 + k * TBLOCK;
+                        const unsigned long long* cell = a.rows + ((size_t)r * NT + b0) * 2;
 #pragma unroll
-                    for (int b = 0; b < 2 * NTM; b++) if (b < 2 * NT && r < grid) w[k][b] = xchg_ld(cell + b);
+                        for (int b = 0; b < 2 * CH; b++) if (b0 + b / 2 < NT && r < grid) w[k][b] = xchg_ld(cell + b);
+                    }
+#pragma unroll
+                    for (int k = 0; k < RB; k++)
+#pragma unroll
+                        for (int b = 0; b < 2 * CH; b++) if (b0 + b / 2 < NT && r0 + k * TBLOCK < grid) all = all && (w[k][b] >> 32) == want;
+                    if (all) break;
+                    if (++n > XCHG_SPIN_LIMIT) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(2);
                 }
 #pragma unroll
-                for (int k = 0; k < RB; k++)
+                for (int k = 0; k < RB; k++)                // row order: r0, r0 + 256, ...
 #pragma unroll
-                    for (int b = 0; b < 2 * NTM; b++) if (b < 2 * NT && r0 + k * TBLOCK < grid) all = all && (w[k][b] >> 32) == want;
-                if (all) break;
-                if (++n > XCHG_SPIN_LIMIT) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(2);
+                    for (int b = 0; b < CH; b++)
+                        if (b0 + b < NT && r0 + k * TBLOCK < grid) {
+                            const double v = __longlong_as_double((long long)((w[k][2 * b + 1] << 32) | (w[k][2 * b] & 0xffffffffull)));
+#pragma unroll
+                            for (int t = 0; t < NTM; t++) acc[t] += (t == b0 + b) ? v : 0.0;
+                        }
             }
-#pragma unroll
-            for (int k = 0; k < RB; k++)                    // row order: r0, r0 + 256, ...
-#pragma unroll
-                for (int b = 0; b < NTM; b++)
-                    if (b < NT && r0 + k * TBLOCK < grid)
-                        acc[b] += __longlong_as_double((long long)((w[k][2 * b + 1] << 32) | (w[k][2 * b] & 0xffffffffull)));
         }
         if (!ok) {                                         // a work-group never handed in its row: nobody goes on
             atomicOr(a.status, 8u);

@@ -22,7 +22,7 @@ def test_hot_kernels_keep_their_occupancy():
     spills = {k: v for k, v in rows.items() if v[1] != 0}
     assert not spills, spills
     for prec in (0, 1, 2):
-        for gb in (1, 4):
+        for gb in (1, 4, 8):
             assert rows[f"step_kernel<{prec},{gb}>"][0] <= 168, rows[f"step_kernel<{prec},{gb}>"]          # 3 work-groups per CU
             assert rows[f"tile_kernel<{prec},71,1>"][0] <= 168 and rows[f"tile_kernel<{prec},7,1>"][0] <= 168      # (no KE bins: one instantiation)
             assert rows[f"tile_kernel<{prec},138,{gb}>"][0] <= 96, rows[f"tile_kernel<{prec},138,{gb}>"]   # 5 work-groups per CU
