@@ -46,11 +46,12 @@ def parse():
     p.add_argument("--molecules", type=int, default=1_000_000, help="SWM4 molecules = Drude pairs (metric: 1,000,000)")
     p.add_argument("--precision", default="mixed", choices=["single", "mixed", "double"])
     p.add_argument("--mode", default="TGNH", choices=["TGNH", "dualNH"])
-    p.add_argument("--variant", default="auto", choices=["auto", "plain", "defer", "resident"],
+    p.add_argument("--variant", default="auto", choices=["auto", "plain", "plain-resident", "defer", "resident"],
                    help="defer = end-of-step rescale and second half kick folded into the next step's first pass; resident = "
                         "defer with the whole step in ONE launch whose work-groups meet on the device (step_kernel; with the "
                         "RCCL hook it steps the defer way); plain = the reference's pass structure (what the OpenMM glue "
-                        "runs); auto = resident below 2 M slots per GPU, else defer (DESIGN.md)")
+                        "runs); plain-resident = that structure with each thermostat half one step_kernel launch; "
+                        "auto = resident below 2 M slots per GPU, else defer (DESIGN.md)")
     p.add_argument("--chains", type=int, default=1)
     p.add_argument("--drude-steps", type=int, default=20, help="drudeStepsPerRealStep (reference default 20)")
     p.add_argument("--hardwall", type=float, default=0.02, help="maxDrudeDistance nm (example/nacl_tg.py:22); 0 = off")
@@ -76,7 +77,8 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
     from openmm_drudenose_amd.system import shard_bounds
     it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, args.drude_steps, args.chains, True, True)
     it.setMaxDrudeDistance(args.hardwall)
-    flags = {"plain": 0, "defer": FLAG_DEFER_SCALE, "resident": FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP}[variant]
+    flags = {"plain": 0, "plain-resident": FLAG_RESIDENT_STEP, "defer": FLAG_DEFER_SCALE,
+             "resident": FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP}[variant]
     local, lgroup = system, group
     if world > 1:
         b = shard_bounds(system, world)
@@ -174,7 +176,7 @@ def validate_mailbox(args, rank, world):
 def dominant_kid(variant):
     """the launch that carries most of a step: step_kernel (resident) or the fused rescale + half kick + drift pass"""
     from openmm_drudenose_amd import _lib
-    return _lib.KID_STEP if variant == "resident" else _lib.KID_SKD
+    return _lib.KID_STEP if variant in ("resident", "plain-resident") else _lib.KID_SKD
 
 
 def timed_run(ctx, steps, warmup, world, graph_steps=0, dom_kid=0):
@@ -392,7 +394,8 @@ def step_model_bytes(num_slots, precision, variant):
     V = 16 if precision == "single" else 32
     X = 16 if precision == "single" else 32
     F = 24
-    per = {"plain": 7 * V + 2 * F + 2 * X, "defer": 3 * V + 2 * F + 2 * X, "resident": 3 * V + 2 * F + 2 * X}[variant]
+    per = {"plain": 7 * V + 2 * F + 2 * X, "plain-resident": 6 * V + 3 * F + 2 * X, "defer": 3 * V + 2 * F + 2 * X,
+           "resident": 3 * V + 2 * F + 2 * X}[variant]
     return num_slots * per
 
 
@@ -517,7 +520,7 @@ def main():
     if mailbox_info:
         extra["mailbox"] = dict(extra.get("mailbox", {}), **mailbox_info)
     if world == 1 and not args.no_extra:
-        for prec, var in ((args.precision, "plain"), (args.precision, "resident"), ("single", args.variant)):
+        for prec, var in ((args.precision, "plain"), (args.precision, "plain-resident"), (args.precision, "resident"), ("single", args.variant)):
             if (prec, var) == (args.precision, args.variant):
                 continue
             c2 = build_context(args, system, group, ngroups, rank, world, prec, var)
@@ -551,7 +554,7 @@ def main():
                             f"{args.mode} mode, {args.precision} precision, numNHChains={args.chains}, hard wall "
                             f"{args.hardwall} nm, harness force call-out inside the timed region",
                 "precision": args.precision, "variant": args.variant,
-                "variant_ran": "resident" if dkid == _lib.KID_STEP else args.variant.replace("resident", "defer"),
+                "variant_ran": args.variant if dkid == dominant_kid(args.variant) else {"resident": "defer", "plain-resident": "plain"}.get(args.variant, args.variant),
                 "hipgraph": graph_used,
                 "parallelism": f"particle-sharded x{world} (whole molecules), one KE all-reduce per step",
                 "exchange": exchange_used, "rccl_ranks": ranks_met if use_dist else None,

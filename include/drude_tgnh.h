@@ -60,12 +60,16 @@ enum { TGNH_FLAG_DEFER_SCALE = 2 };    /* the end-of-step rescale AND the second
                                         * into the next step's first pass: between tgnh_step_end and the next
                                         * tgnh_step_begin velm lags and the force buffer must stay as it is; tgnh_flush
                                         * makes velm the reference's end-of-step state.  (1 is reserved.) */
-enum { TGNH_FLAG_RESIDENT_STEP = 4 };  /* with DEFER_SCALE: tgnh_step_end launches nothing and the next tgnh_step_begin runs
-                                        * that end half and its own begin half in ONE launch whose work-groups meet on the
-                                        * device.  The handle needs the device to itself while stepping (see
-                                        * tgnh_set_resident_share); one-link chains, <= 8 temperature groups, no collective
-                                        * hook -- otherwise the handle quietly steps the DEFER_SCALE way.  With a mailbox
-                                        * exchange attached, state queries between steps are collective over the ranks. */
+enum { TGNH_FLAG_RESIDENT_STEP = 4 };  /* whole thermostat halves in ONE launch whose work-groups meet on the device
+                                        * (step_kernel).  Alone: the reference's pass structure, two launches per
+                                        * step (KE + chain + rescale, kick, drift | kick + KE + chain + rescale), velocities
+                                        * never lag -- usable wherever the plain structure is.  With DEFER_SCALE:
+                                        * tgnh_step_end launches nothing and the next tgnh_step_begin runs that end half and
+                                        * its own begin half in one launch.  Either way the handle needs the device to itself
+                                        * while stepping (see tgnh_set_resident_share); one-link chains, <= 8 temperature
+                                        * groups, no collective hook -- otherwise it quietly steps with the tile launches.
+                                        * With a mailbox exchange attached and DEFER_SCALE, state queries between steps are
+                                        * collective over the ranks. */
 
 typedef struct tgnh_desc {
     uint32_t struct_size;         /* sizeof(tgnh_desc), ABI check */

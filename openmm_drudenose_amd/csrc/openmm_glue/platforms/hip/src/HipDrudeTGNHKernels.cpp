@@ -60,6 +60,11 @@ void HipIntegrateDrudeTGNHStepKernel::initialize(const System& system, const Dru
     d.mode = TGNH_MODE_TGNH;                               // the GPU platform's semantics (temperature groups + COM)
     d.precision = cu.getUseDoublePrecision() ? TGNH_PREC_DOUBLE : (cu.getUseMixedPrecision() ? TGNH_PREC_MIXED : TGNH_PREC_SINGLE);
     d.flags = 0;                                           // OpenMM may touch velocities between steps: keep the plain pass structure
+#ifdef DRUDETGNH_RESIDENT_STEP
+    // ... with each thermostat half as one launch (velocities still never lag).  Needs this context to have the device to
+    // itself while it steps: off by default (CMake option DRUDETGNH_RESIDENT_STEP), because several OpenMM contexts may share a GPU
+    d.flags = TGNH_FLAG_RESIDENT_STEP;
+#endif
     d.device = cu.getDeviceIndex();
     d.num_particles = numParticles;
     d.padded_num_particles = cu.getPaddedNumAtoms();

@@ -470,10 +470,6 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     }
     tgnh_status rc = build_topology(c, d);
     if (rc != TGNH_OK) { free_device(c); delete c; return rc; }
-    if ((d->flags & TGNH_FLAG_RESIDENT_STEP) && !(d->flags & TGNH_FLAG_DEFER_SCALE)) {
-        free_device(c); delete c;
-        return fail(TGNH_ERR_ARG, "TGNH_FLAG_RESIDENT_STEP needs TGNH_FLAG_DEFER_SCALE");
-    }
     if ((d->flags & TGNH_FLAG_DEFER_SCALE) && d->mode == TGNH_MODE_TGNH && d->use_com_temp_group) {
         // s^2 KE is the exact post-rescale KE only if no molecule spans two temperature groups
         for (int r = 0; r < d->num_residues; r++) {
@@ -553,13 +549,15 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
             // checked by a census launch (every work-group checks in and waits for all the others, bounded); one fewer per
             // unit is tried until a grid passes.  0 = none did: the handle steps the DEFER_SCALE way.
             if (c->gb != 0 && c->L.C == 1 && c->L.NT <= CHAIN_INLINE_SUM_NT) {
-                const size_t lds = tile_lds_bytes(c->d.precision, OP_PREKICK | OP_SCALE | OP_KICK | OP_DRIFT, true, true);
-                for (int per_cu = std::min(step_blocks_per_cu(c->d.precision, c->gb, lds), 8); per_cu >= 1 && !c->resident_per_cu; per_cu--) {
+                // (the kind with the largest footprint this handle will launch: a whole deferred step, or the plain begin half)
+                const int kind = (c->d.flags & TGNH_FLAG_DEFER_SCALE) ? 0 : 1;
+                const size_t lds = tile_lds_bytes(c->d.precision, step_kind_ops2(kind), true, true);
+                for (int per_cu = std::min(step_blocks_per_cu(c->d.precision, c->gb, kind, lds), 8); per_cu >= 1 && !c->resident_per_cu; per_cu--) {
                     TileArgs a{};
                     a.census = 1; a.sync = c->d_sync;
                     HIP_OK(hipMemset(c->d_sync + 2, 0, 2 * sizeof(unsigned int)));
                     const int grid = std::min(per_cu * c->num_cus, GRID_CAP);
-                    HIP_OK(launch_step(c->d.precision, c->gb, a, grid, lds, (hipStream_t)0));
+                    HIP_OK(launch_step(c->d.precision, c->gb, kind, a, grid, lds, (hipStream_t)0));
                     unsigned int res[2] = {0, 1};
                     HIP_OK(hipMemcpy(res, c->d_sync + 2, sizeof(res), hipMemcpyDeviceToHost));
                     if (res[0] == (unsigned)grid && res[1] == 0) c->resident_per_cu = per_cu;
@@ -754,7 +752,7 @@ extern "C" tgnh_status tgnh_set_resident_share(tgnh_handle h, int share) {
     CHECK_H(h);
     if (share < 1 || share > 64) return fail(TGNH_ERR_ARG, "resident share must be 1..64");
     h->resident_share = share;
-    h->resident_grid = h->resident_grid_hw = 0;
+    for (auto& g : h->resident_grid) g[0] = g[1] = 0;
     return TGNH_OK;
 }
 
@@ -986,31 +984,39 @@ static tgnh_status materialize_chain(tgnh_handle h, hipStream_t s) {
 // Eligible: deferred pass structure, one-link chains (the chain runs inside the launch), at most 8 temperature groups,
 // and an exchange the kernel can do itself (none, or the mailboxes -- a collective hook is a launch of its own).
 static bool resident_now(tgnh_handle h) {
-    return (h->d.flags & TGNH_FLAG_RESIDENT_STEP) && (h->d.flags & TGNH_FLAG_DEFER_SCALE) && h->resident_per_cu > 0 && h->inline_chain && h->gb != 0 &&
+    return (h->d.flags & TGNH_FLAG_RESIDENT_STEP) && h->resident_per_cu > 0 && h->inline_chain && h->gb != 0 &&
            h->L.NT <= CHAIN_INLINE_SUM_NT && (h->xchg_on || !h->allreduce);
 }
 
-static tgnh_status run_resident_step(tgnh_handle h, hipStream_t s) {
+// One launch of step_kernel.  kind 0: a whole deferred step (the last step's end half + this step's begin half, both chain
+// halves); 1 / 2: the begin / end half of the reference's pass structure; 3 / 4: the same around the constraint call-outs.
+static tgnh_status run_resident(tgnh_handle h, hipStream_t s, int kind) {
     if (h->stage_pending) { tgnh_status rc = commit_stage(h, s); if (rc) return rc; }
     TileArgs a = tile_args(h, nullptr);
-    const bool hw = a.hardwall != 0;
-    const size_t lds = tile_lds_bytes(h->d.precision, OP_PREKICK | OP_SCALE | OP_KICK | OP_DRIFT, hw, a.use_com != 0);
-    int& grid = hw ? h->resident_grid_hw : h->resident_grid;
-    if (grid == 0)         // the work-groups that are resident at once (counted at create) -- all of them meet inside the launch
-        grid = std::max(1, std::min(std::min(h->num_tiles, h->resident_per_cu * h->num_cus / h->resident_share), GRID_CAP));
+    const int ops2 = step_kind_ops2(kind);
+    if ((ops2 & OP_POSDELTA) && !h->pos_delta) return fail(TGNH_ERR_STATE, "posDelta buffer not bound");
+    const bool hw = a.hardwall != 0 && (ops2 & (OP_DRIFT | OP_MOVE));
+    const size_t lds = tile_lds_bytes(h->d.precision, ops2, hw, a.use_com != 0);
+    int& grid = h->resident_grid[kind][hw ? 1 : 0];
+    if (grid == 0) {       // the work-groups that are resident at once (counted at create; never more than this kind's own occupancy)
+        int per_cu = std::min(h->resident_per_cu, step_blocks_per_cu(h->d.precision, h->gb, kind, lds));
+        if (per_cu < 1) return fail(TGNH_ERR_HIP, "step_kernel: occupancy query failed");
+        grid = std::max(1, std::min(std::min(h->num_tiles, per_cu * h->num_cus / h->resident_share), GRID_CAP));
+    }
     a.chain_on = 1;
     a.chain = chain_args(h);
-    a.chain.chain_twice = 1;
+    a.chain.chain_twice = kind == 0 ? 1 : 0;
     a.chain.nparts = grid;
     a.x_wait = 1;
     if (!h->xchg_on) a.chain.x = h->self_x;            // unsharded: the private one-rank mailbox
     a.st_in = h->d_state; a.st_out = h->d_state;       // advanced in place by work-group 0 after everybody has read it
     a.sync = h->d_sync; a.rows = h->d_rows;
-    if (h->num_big && a.use_com) { tgnh_status rc = run_big_com(h, true, s); if (rc) return rc; }
+    if (h->num_big && a.use_com) { tgnh_status rc = run_big_com(h, kind == 0 || kind == 2, s); if (rc) return rc; }
     h->ke_parts = grid;
+    h->last_step_kind = kind;
     {
         Timed t(h, s, KID_STEP);
-        HIP_OK(launch_step(h->d.precision, h->gb, a, grid, lds, s));
+        HIP_OK(launch_step(h->d.precision, h->gb, kind, a, grid, lds, s));
     }
     // the first pass walked the tiles in direction sweep_reverse, the second one back: the next launch starts here
     h->end_pending = false; h->scale_pending = false; h->kick_pending = false; h->first_half_done = false;
@@ -1053,9 +1059,11 @@ extern "C" tgnh_status tgnh_step_begin(tgnh_handle h, void* stream) {
     tgnh_status rc = entry(h, true); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (h->end_pending) {
-        if (resident_now(h)) return run_resident_step(h, s);         // the last step's end half and this begin half: one launch
+        if (resident_now(h)) return run_resident(h, s, 0);           // the last step's end half and this begin half: one launch
         rc = settle_end(h, s); if (rc) return rc;
     }
+    if (!(h->d.flags & TGNH_FLAG_DEFER_SCALE) && resident_now(h))
+        return run_resident(h, s, 1);                                // reference pass structure: KE, chain, rescale+kick+drift in one launch
     rc = first_half(h, s); if (rc) return rc;
     // Cu :351-376 fused; with a half kick still pending from the last step_end (DEFER_SCALE) that kick comes first
     rc = run_tile(h, (h->kick_pending ? OP_PREKICK : 0) | OP_SCALE | OP_KICK | OP_DRIFT, KID_SKD, s); if (rc) return rc;
@@ -1067,6 +1075,13 @@ static tgnh_status second_half(tgnh_handle h, hipStream_t s, int kick_ops) {
     tgnh_status rc;
     const bool defer = (h->d.flags & TGNH_FLAG_DEFER_SCALE) != 0;
     if (h->scale_pending || h->kick_pending || h->end_pending) { rc = flush_impl(h, s); if (rc) return rc; }   // two end halves in a row
+    if (!defer && resident_now(h)) {
+        // reference pass structure: kick, KE, chain, rescale (Cu :384-402) in one launch; velocities are final when it ends
+        rc = run_resident(h, s, kick_ops ? 2 : 4); if (rc) return rc;
+        h->time += h->d.step_size;
+        h->step_count += 1;
+        return poll_status_async(h, s);
+    }
     if (kick_ops && resident_now(h)) {
         // TGNH_FLAG_RESIDENT_STEP: nothing is launched here -- the next tgnh_step_begin runs this end half and its own
         // begin half in one launch (step_kernel); anything that needs the state earlier settles it the classic way
@@ -1116,6 +1131,7 @@ extern "C" tgnh_status tgnh_step_begin_kick(tgnh_handle h, void* stream) {
     tgnh_status rc = entry(h, true); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     rc = settle_kick(h, s); if (rc) return rc;
+    if (!(h->d.flags & TGNH_FLAG_DEFER_SCALE) && resident_now(h)) return run_resident(h, s, 3);
     rc = first_half(h, s); if (rc) return rc;
     rc = run_tile(h, OP_SCALE | OP_KICK | OP_POSDELTA, KID_OTHER, s); if (rc) return rc;   // Cu :351-360
     h->scale_pending = false; h->first_half_done = false;
@@ -1423,7 +1439,9 @@ extern "C" tgnh_status tgnh_algorithmic_bytes(tgnh_handle h, int kernel, double*
         case KID_SCALE: b = N * (2 * V); break;                 // rescale (+KE): V r/w
         case KID_KE: b = N * V; break;                          // KE: V r
         case KID_FORCE: b = N * (X + F); break;                 // harness: X r, F w (x0 excluded)
-        case KID_STEP: b = N * (3 * V + 2 * F + 2 * X); break;  // step_kernel: its two passes (V r, F r) + (V r/w, F r, X r/w)
+        case KID_STEP:       // step_kernel: its two passes.  Deferred: (V r, F r) + (V r/w, F r, X r/w); the reference's pass
+                             // structure: begin (V r) + (V r/w, F r, X r/w) and end (V r, F r) + (V r/w, F r), averaged per launch
+            b = (h->d.flags & TGNH_FLAG_DEFER_SCALE) ? N * (3 * V + 2 * F + 2 * X) : N * (6 * V + 3 * F + 2 * X) / 2; break;
         default: b = 0;
     }
     *bytes = b;

@@ -204,8 +204,11 @@ struct ForceArgs {
 // launchers (tgnh_kernels.hip)
 hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s);
 int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds);   // occupancy of that instantiation
-hipError_t launch_step(int precision, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s);   // step_kernel
-int step_blocks_per_cu(int precision, int gb, size_t lds);
+// step_kernel; kind: 0 a whole deferred step, 1 / 2 the begin / end half of the reference's pass structure, 3 / 4 the same
+// around the constraint call-outs (tgnh_kernels.hip: STEP_*)
+hipError_t launch_step(int precision, int gb, int kind, const TileArgs& a, int grid, size_t lds, hipStream_t s);
+int step_blocks_per_cu(int precision, int gb, int kind, size_t lds);
+int step_kind_ops2(int kind);       // operations of the kind's second pass (its LDS needs)
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s);
 hipError_t launch_big_com(int precision, const BigComArgs& a, hipStream_t s);
 hipError_t launch_force(int precision, const ForceArgs& a, hipStream_t s);
@@ -277,7 +280,8 @@ struct tgnh_context {
     unsigned long long* self_box = nullptr;      // RESIDENT_STEP without a sharded exchange: a private one-rank mailbox
     unsigned long long* d_self_misc = nullptr;   // ... its counter, latch and peer table
     tgnh::XchgArgs self_x{};
-    int resident_grid = 0, resident_grid_hw = 0, resident_share = 1;
+    int resident_grid[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};   // step_kernel's grid by kind and hard wall
+    int resident_share = 1, last_step_kind = 0;
     int resident_per_cu = 0;          // work-groups of step_kernel per compute unit that the census at create found resident together (0: none -- the handle steps the DEFER_SCALE way)
     bool first_half_done = false;     // DEFER_SCALE: chain for the coming step's first half already run
     double time = 0;

@@ -157,9 +157,12 @@ template <int OPS> struct OpsOf {
     static constexpr bool VEL_W = (DO_SCALE || DO_KICK || DO_MOVE) && !NOSTORE;   // velocities are written
 };
 
-// issue the global loads of tile t for a pass with operations OPS (KEEP_VF: velocities, meta and forces are already in `in`)
-template <int PREC, int OPS, bool KEEP_VF = false>
+// issue the global loads of tile t for a pass with operations OPS.  HAVE != 0: `in` already holds what a pass with
+// operations HAVE loaded for this very tile (velocities, index words, and its forces if it needed them): fetch the rest.
+template <int PREC, int OPS, int HAVE = 0>
 __device__ __forceinline__ void tile_load(const TileArgs& a, const int t, TileIn<PREC>& in) {
+    constexpr bool KEEP_VF = HAVE != 0;
+    constexpr bool LOAD_F = OpsOf<OPS>::NEED_F && !(KEEP_VF && OpsOf<HAVE>::NEED_F);
     typedef typename Prec<PREC>::mixed mixed;
     typedef typename Prec<PREC>::real4 real4;
     typedef typename Prec<PREC>::mixed4 mixed4;
@@ -181,11 +184,11 @@ __device__ __forceinline__ void tile_load(const TileArgs& a, const int t, TileIn
             if (!KEEP_VF) {
                 in.v[k] = velm[idx];
                 in.meta[k] = a.meta[idx];
-                if (O::NEED_F) {
-                    in.fx[k] = a.force[idx];
-                    in.fy[k] = a.force[idx + a.padded];
-                    in.fz[k] = a.force[idx + 2 * a.padded];
-                }
+            }
+            if (LOAD_F) {
+                in.fx[k] = a.force[idx];
+                in.fy[k] = a.force[idx + a.padded];
+                in.fz[k] = a.force[idx + 2 * a.padded];
             }
             if (O::POS) {
                 in.p[k] = posq[idx];
@@ -744,17 +747,34 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
 // leaves the chip between the passes.  The thermostat block is advanced in place by work-group 0: every work-group
 // reads it before it hands in its row, and work-group 0 writes only after it has everybody's.
 // ---------------------------------------------------------------------------
-constexpr int STEP_OPS1 = OP_KICK | OP_KE | OP_NOSTORE;
-constexpr int STEP_OPS2 = OP_PREKICK | OP_SCALE | OP_KICK | OP_DRIFT;
+// The two passes are template parameters, so the same kernel also runs the thermostat halves of the reference's own pass
+// structure (velocities never lag: what the OpenMM glue may use) as one launch each:
+//   STEP_DEFER        kick+KE (unstored)  |  kick again, rescale, kick, drift     both chain halves   a whole deferred step
+//   STEP_PLAIN_BEGIN  KE                  |  rescale, kick, drift                 one half            Cu :336-376
+//   STEP_PLAIN_END    kick+KE (unstored)  |  kick again, rescale                  one half            Cu :384-402
+//   STEP_SPLIT_BEGIN  KE                  |  rescale, kick, posDelta              one half            Cu :336-360 (constraints)
+//   STEP_SPLIT_END    KE                  |  rescale                              one half            Cu :394-402 (constraints)
+enum : int { STEP_DEFER = 0, STEP_PLAIN_BEGIN = 1, STEP_PLAIN_END = 2, STEP_SPLIT_BEGIN = 3, STEP_SPLIT_END = 4, STEP_KINDS = 5 };
+constexpr int step_ops1(int kind) {
+    return (kind == STEP_DEFER || kind == STEP_PLAIN_END) ? (OP_KICK | OP_KE | OP_NOSTORE) : OP_KE;
+}
+constexpr int step_ops2(int kind) {
+    return kind == STEP_DEFER ? (OP_PREKICK | OP_SCALE | OP_KICK | OP_DRIFT)
+         : kind == STEP_PLAIN_BEGIN ? (OP_SCALE | OP_KICK | OP_DRIFT)
+         : kind == STEP_PLAIN_END ? (OP_PREKICK | OP_SCALE)
+         : kind == STEP_SPLIT_BEGIN ? (OP_SCALE | OP_KICK | OP_POSDELTA)
+         : OP_SCALE;
+}
 
 // (Measured and dropped, profiles/r02_resident_tuning.md: a second register image to load a work-group's next tile under
 // the current one -- in both passes: 198 VGPRs, occupancy 2; in pass 1 alone: free in registers, no gain -- and tiles cut
 // to N / (k x work-groups) slots for equal walks.  A pass costs ~2 us of a compute unit's time per tile whether a
 // work-group walks one tile or two: it is the unit's three resident work-groups that overlap each other, not a
 // work-group its own tiles.  Pass 2 already moves its 73 MB at the 6.6 TB/s the Infinity Cache gives.)
-template <int PREC, int GB>
+template <int PREC, int GB, int KIND>
 __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileArgs a) {
     typedef typename Prec<PREC>::mixed mixed;
+    constexpr int STEP_OPS1 = step_ops1(KIND), STEP_OPS2 = step_ops2(KIND);
     __shared__ double s_scale[MAX_GROUPS + 2];
     __shared__ double s_part[TBLOCK / 64][CHAIN_INLINE_SUM_NT];
     __shared__ double s_x[64 + XCHG_MAX_WORLD * CHAIN_INLINE_SUM_NT];      // scratch of the sums and the exchange: the images stay intact
@@ -779,7 +799,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
         return;
     }
     TileEnv<PREC, GB> e;
-    e.init(a, smem, s_scale, a.hardwall != 0);
+    e.init(a, smem, s_scale, OpsOf<STEP_OPS2>::POS && a.hardwall != 0);
     auto tile_of = [&](int tt) { return a.reverse ? a.num_tiles - 1 - tt : tt; };
 
     // this launch's number (the tag of its rows) and the exchange it will wait for: read before anything is handed in
@@ -809,7 +829,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
     const ChainLayout& L = a.chain.L;
     Chain1Regs creg{};
     if (chain_wave && itg < NT) creg = chain1_load(a.chain, a.st_in, itg);
-    tile_load<PREC, STEP_OPS2, true>(a, tile_of(tt_last), cur);
+    tile_load<PREC, STEP_OPS2, STEP_OPS1>(a, tile_of(tt_last), cur);
 
     // ---- meet: work-group 0 collects the rows.  Thread t owns rows t, t + 256, ...: it polls their cells until all
     // carry this launch's tag and adds them in row order; then butterflies and one LDS hop, fixed order throughout.
@@ -1253,28 +1273,39 @@ hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int gr
 }
 
 typedef void (*step_fn_t)(const TileArgs);
-template <int PREC> static step_fn_t step_fn_gb(int gb) {
-    if (gb <= 1) return step_kernel<PREC, 1>;
-    if (gb <= 4) return step_kernel<PREC, 4>;
-    return step_kernel<PREC, 8>;
+template <int PREC, int KIND> static step_fn_t step_fn_gb(int gb) {
+    if (gb <= 1) return step_kernel<PREC, 1, KIND>;
+    if (gb <= 4) return step_kernel<PREC, 4, KIND>;
+    return step_kernel<PREC, 8, KIND>;
 }
-static step_fn_t step_fn(int precision, int gb) {
-    if (gb == 0) return nullptr;                          // more than 8 groups: the tile kernels
-    switch (precision) {
-        case TGNH_PREC_SINGLE: return step_fn_gb<TGNH_PREC_SINGLE>(gb);
-        case TGNH_PREC_MIXED: return step_fn_gb<TGNH_PREC_MIXED>(gb);
-        case TGNH_PREC_DOUBLE: return step_fn_gb<TGNH_PREC_DOUBLE>(gb);
+template <int PREC> static step_fn_t step_fn_kind(int kind, int gb) {
+    switch (kind) {
+        case STEP_DEFER: return step_fn_gb<PREC, STEP_DEFER>(gb);
+        case STEP_PLAIN_BEGIN: return step_fn_gb<PREC, STEP_PLAIN_BEGIN>(gb);
+        case STEP_PLAIN_END: return step_fn_gb<PREC, STEP_PLAIN_END>(gb);
+        case STEP_SPLIT_BEGIN: return step_fn_gb<PREC, STEP_SPLIT_BEGIN>(gb);
+        case STEP_SPLIT_END: return step_fn_gb<PREC, STEP_SPLIT_END>(gb);
         default: return nullptr;
     }
 }
-hipError_t launch_step(int precision, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s) {
-    step_fn_t fn = step_fn(precision, gb);
+static step_fn_t step_fn(int precision, int gb, int kind) {
+    if (gb == 0) return nullptr;                          // more than 8 groups: the tile kernels
+    switch (precision) {
+        case TGNH_PREC_SINGLE: return step_fn_kind<TGNH_PREC_SINGLE>(kind, gb);
+        case TGNH_PREC_MIXED: return step_fn_kind<TGNH_PREC_MIXED>(kind, gb);
+        case TGNH_PREC_DOUBLE: return step_fn_kind<TGNH_PREC_DOUBLE>(kind, gb);
+        default: return nullptr;
+    }
+}
+int step_kind_ops2(int kind) { return step_ops2(kind); }
+hipError_t launch_step(int precision, int gb, int kind, const TileArgs& a, int grid, size_t lds, hipStream_t s) {
+    step_fn_t fn = step_fn(precision, gb, kind);
     if (!fn) return hipErrorInvalidValue;
     TGNH_LAUNCH(fn, dim3(grid), dim3(TBLOCK), lds, s, a);
     return hipGetLastError();
 }
-int step_blocks_per_cu(int precision, int gb, size_t lds) {
-    step_fn_t fn = step_fn(precision, gb);
+int step_blocks_per_cu(int precision, int gb, int kind, size_t lds) {
+    step_fn_t fn = step_fn(precision, gb, kind);
     int n = 0;
     if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(fn), TBLOCK, lds) != hipSuccess) return 0;
     return n;

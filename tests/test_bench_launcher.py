@@ -42,3 +42,4 @@ def test_step_model_bytes_follow_the_variant():
     assert bench.step_model_bytes(n, "mixed", "plain") == n * 336       # 7V + 2F + 2X
     assert bench.step_model_bytes(n, "single", "plain") == n * 192
     assert bench.step_model_bytes(n, "mixed", "defer") == n * 208       # 3V + 2F + 2X
+    assert bench.step_model_bytes(n, "mixed", "plain-resident") == n * 328   # 6V + 3F + 2X

@@ -298,7 +298,7 @@ def test_hardwall_too_far_flag():
     ctx.close()
 
 
-@pytest.mark.parametrize("flags", [0, FLAG_DEFER_SCALE, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP])
+@pytest.mark.parametrize("flags", [0, FLAG_RESIDENT_STEP, FLAG_DEFER_SCALE, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP])
 def test_single_precision_deviation(flags):
     """float4 state: measured, not gated at 1e-6 (see module docstring).  Bound: 2e-3 on velocities,
     5e-6 on positions after 100 steps of a 1000-water box (measured on MI355X: 1.0e-6 and 3.8e-4), in every pass
@@ -424,6 +424,35 @@ def test_100_step_parity_resident_step(sysname, mode, drude_chains, com, precisi
     ctx.close()
 
 
+@pytest.mark.parametrize("precision", ["mixed", "double"])
+@pytest.mark.parametrize("sysname,mode,drude_chains,com", [
+    ("mixed", "TGNH", True, True), ("mixed", "dualNH", True, True), ("mixed", "dualNH", False, True),
+    ("polymer", "TGNH", True, True), ("water1000", "TGNH", True, False), ("groups6", "TGNH", True, True)])
+def test_100_step_parity_resident_halves_of_the_reference_structure(sysname, mode, drude_chains, com, precision):
+    """TGNH_FLAG_RESIDENT_STEP alone: the reference's own pass structure (velocities never lag -- what an OpenMM context
+    needs), each thermostat half one launch of step_kernel: KE | chain | rescale+kick+drift+hard wall, and
+    kick+KE | chain | rescale.  Against the oracle directly; two launches per step, none of the tile launches."""
+    s, g, ng, it, ctx = make(sysname, mode, precision, flags=FLAG_RESIDENT_STEP, chains=1, drude_chains=drude_chains, com=com, hardwall=0.02)
+    assert ctx.resident_work_groups() >= 1
+    o = make_oracle(s, g, ng, mode, it)
+    pos_o, vel_o = oracle_run(o, s, 100, x0=ctx.sites(), record=True)[:2]
+    ctx.timing(True)
+    for i in range(100):
+        ctx.step_begin(); ctx.compute_forces(); ctx.step_end()
+    ctx.torch.cuda.synchronize()
+    ctx.timing(False)
+    nbig = 1 if sysname == "polymer" else 0
+    assert ctx.timing_read(_lib.KID_STEP)[1] == 200
+    assert all(ctx.timing_read(k)[1] == 0 for k in (_lib.KID_SKD, _lib.KID_KICK_KE, _lib.KID_SCALE, _lib.KID_KE, _lib.KID_CHAIN))
+    assert ctx.timing_read(_lib.KID_OTHER)[1] == 200 * nbig            # (the COM of a molecule longer than a tile)
+    # velm is the reference's end-of-step state as it stands: no flush involved
+    vel = ctx.velm[:, :3].to(ctx.torch.float64).cpu().numpy()
+    ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(vel, vel_o)
+    print(f"resident halves {sysname} {mode} {precision}: pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= TOL and ev <= TOL and ctx.check() == 0
+    ctx.close()
+
+
 def test_resident_step_is_the_deferred_integrator():
     """Same trajectory as the multi-launch deferred structure (row sums in a different order: 1e-11), per-step KE and
     scale factors equal to the oracle's, the step kernel really is what ran, queries between steps settle the pending
@@ -473,11 +502,6 @@ def test_resident_step_falls_back_where_it_cannot_run():
         assert alt[4].timing_read(_lib.KID_STEP)[1] == 0
         assert np.array_equal(alt[4].getVelocities(), ref[4].getVelocities())
         ref[4].close(); alt[4].close()
-    s, g, ng = SYSTEMS["mixed"]()
-    it = integ(chains=1)
-    bind_groups(it, g, ng)
-    with pytest.raises(TgnhError):
-        HipContext(s, it, mode="TGNH", precision="double", flags=FLAG_RESIDENT_STEP)     # needs DEFER_SCALE
 
 
 @pytest.mark.parametrize("nranks", [1, 2])
@@ -540,7 +564,7 @@ def test_resident_step_with_mailbox_exchange(nranks):
 
 @pytest.mark.parametrize("mode", ["TGNH", "dualNH"])
 @pytest.mark.parametrize("chains", [1, 3])          # 1: the chain runs inside the rescale launch (staged block + commit)
-@pytest.mark.parametrize("flags", [0, FLAG_DEFER_SCALE])
+@pytest.mark.parametrize("flags", [0, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP])
 def test_graph_replay_matches_eager(flags, chains, mode):
     """hipGraph capture of the step loop (HipContext.capture_steps) replays the very same launches: bitwise equal.
     Five steps per graph on purpose: nothing in the captured launch arguments may alternate between replays."""
@@ -620,6 +644,35 @@ def test_constrained_path_parity(name, mode, precision):
         sa, w = s.site_atoms, s.site_weights
         expect = sum(w[:, [m]] * gp[sa[:, m + 1]] for m in range(3))
         assert np.abs(gp[sa[:, 0]] - expect).max() <= 1e-7
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
+@pytest.mark.parametrize("name", list(CONSTRAINED))
+def test_constrained_path_parity_with_resident_halves(name, mode):
+    """The split step around the constraint call-outs with TGNH_FLAG_RESIDENT_STEP: begin_kick = KE | chain |
+    rescale+kick+posDelta and end_thermo = KE | chain | rescale, each one launch (Cu :336-360, :394-402)."""
+    s, g, ng = CONSTRAINED[name]()
+    it = integ(chains=1, hardwall=0.02)
+    it.setConstraintTolerance(1e-10)
+    if mode == "TGNH":
+        bind_groups(it, g, ng)
+    else:
+        g, ng = np.zeros_like(g), 1
+    ctx = HipContext(s, it, mode=mode, precision="mixed", flags=FLAG_RESIDENT_STEP)
+    assert ctx.constrained and ctx.resident_work_groups() >= 1
+    o = make_oracle(s, g, ng, mode, it)
+    pos, vel, x0 = s.positions.copy(), s.velocities.copy(), ctx.sites()
+    f = o.harness_force(pos, x0, synth.K_DRUDE, synth.K_TETHER)
+    o.run_harness_constrained(pos, vel, f, x0, synth.K_DRUDE, synth.K_TETHER, 1e-10, 50)
+    ctx.timing(True)
+    ctx.step(50)
+    ctx.torch.cuda.synchronize()
+    ctx.timing(False)
+    assert ctx.timing_read(_lib.KID_STEP)[1] == 100 and ctx.timing_read(_lib.KID_CHAIN)[1] == 0
+    ep, ev = rel_err(ctx.getPositions(), pos), rel_err(ctx.getVelocities(), vel)
+    print(f"constrained, resident halves, {name} {mode}: pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= TOL and ev <= TOL and ctx.check() == 0
     ctx.close()
 
 
@@ -936,7 +989,7 @@ def test_10000_steps_all_pass_structures_track_the_oracle():
     harmonic workload -- every branch of the on-device chain arithmetic gets exercised, not only its first 100 steps)."""
     s, g, ng = SYSTEMS["water1000"]()
     ctxs = {}
-    for name, flags in (("plain", 0), ("deferred", FLAG_DEFER_SCALE), ("resident", RESIDENT)):
+    for name, flags in (("plain", 0), ("plain, resident halves", FLAG_RESIDENT_STEP), ("deferred", FLAG_DEFER_SCALE), ("resident", RESIDENT)):
         it = integ(chains=1, hardwall=0.02)
         bind_groups(it, g, ng)
         ctxs[name] = HipContext(s, it, mode="TGNH", precision="double", flags=flags)
