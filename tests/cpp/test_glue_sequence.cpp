@@ -7,7 +7,7 @@
 // against tests/golden/oracle_regression.npz and against the oracle.
 //
 //   test_glue_sequence ints.bin doubles.bin out.bin
-//   ints:    N P R G nclusters nsites nsteps perturb chains useDrudeChains useCOM precision | pairs[P][2] | resid[N] | group[N] |
+//   ints:    N P R G nclusters nsites nsteps perturb chains useDrudeChains useCOM precision flags | pairs[P][2] | resid[N] | group[N] |
 //            cluster atoms[ncl][4] | site atoms[ns][4]
 //   doubles: dt hardwall kDrude kTether tol | mass[N] | pos[N][3] | vel[N][3] | x0[N][3] | cluster dist[ncl][6] | site w[ns][3]
 //   out:     pos[N][3] vel[N][3] etaDot[...]   (doubles)
@@ -39,11 +39,12 @@ int main(int argc, char** argv) {
     if (argc != 4) return 1;
     std::vector<int> I = slurp<int>(argv[1]);
     std::vector<double> D = slurp<double>(argv[2]);
-    if (I.size() < 12 || D.size() < 5) { std::printf("bad input files\n"); return 1; }
+    if (I.size() < 13 || D.size() < 5) { std::printf("bad input files\n"); return 1; }
     const int N = I[0], P = I[1], R = I[2], G = I[3], ncl = I[4], ns = I[5], nsteps = I[6], perturb = I[7];
     const int chains = I[8], useDrudeChains = I[9], useCOM = I[10], precision = I[11];    // TGNH_PREC_MIXED or _DOUBLE
     const bool dbl = precision == TGNH_PREC_DOUBLE;
-    const int* pairs = &I[12]; const int* resid = pairs + 2 * P; const int* group = resid + N;
+    const int flags = I[12];                 // 0, or TGNH_FLAG_RESIDENT_STEP (the glue's -DDRUDETGNH_RESIDENT_STEP build)
+    const int* pairs = &I[13]; const int* resid = pairs + 2 * P; const int* group = resid + N;
     const int* clAtoms = group + N; const int* siteAtoms = clAtoms + 4 * ncl;
     const double dt = D[0], hardwall = D[1], kDrude = D[2], kTether = D[3], tol = D[4];
     const double* mass = &D[5]; const double* pos0 = mass + N; const double* vel0 = pos0 + 3 * N; const double* x0h = vel0 + 3 * N;
@@ -63,7 +64,7 @@ int main(int argc, char** argv) {
     integ.setMaxDrudeDistance(hardwall);
     for (int g = 0; g < G; g++) integ.addTempGroup();
     for (int i = 0; i < N; i++) integ.addParticleTempGroup(group[i]);
-    integ.initialize(sys, 0, TGNH_MODE_TGNH, precision, 0);                // flags 0: the glue keeps the plain pass structure
+    integ.initialize(sys, 0, TGNH_MODE_TGNH, precision, flags);            // the glue keeps the plain pass structure
     tgnh_handle h = integ.getHandle();
     const int padded = integ.getPaddedNumParticles();
 

@@ -30,12 +30,12 @@ def exe(tmp_path_factory):
     return str(out)
 
 
-def run_glue(exe, tmp_path, s, group, ngroups, nsteps, perturb, chains, drude_chains, com, dt, hardwall, tol, precision="mixed"):
+def run_glue(exe, tmp_path, s, group, ngroups, nsteps, perturb, chains, drude_chains, com, dt, hardwall, tol, precision="mixed", flags=0):
     n = s.num_particles
     ncl = 0 if s.cluster_atoms is None else len(s.cluster_atoms)
     ns = 0 if s.site_atoms is None else len(s.site_atoms)
     ints = [np.array([n, s.num_pairs, s.num_residues, ngroups, ncl, ns, nsteps, int(perturb), chains, int(drude_chains), int(com),
-                      {"mixed": _lib.PREC_MIXED, "double": _lib.PREC_DOUBLE}[precision]], np.int32),
+                      {"mixed": _lib.PREC_MIXED, "double": _lib.PREC_DOUBLE}[precision], flags], np.int32),
             np.stack([s.pair_drude, s.pair_parent], 1).astype(np.int32).ravel(), s.resid.astype(np.int32), np.asarray(group, np.int32)]
     dbl = [np.array([dt, hardwall, synth.K_DRUDE, synth.K_TETHER, tol]), s.mass, s.positions.ravel(), s.velocities.ravel(), s.positions.ravel()]
     if ncl:
@@ -51,13 +51,14 @@ def run_glue(exe, tmp_path, s, group, ngroups, nsteps, perturb, chains, drude_ch
     return out[:3 * n].reshape(n, 3), out[3 * n:6 * n].reshape(n, 3), out[6 * n:-1], out[-1]
 
 
-def test_fused_sequence_against_the_committed_vectors(exe, tmp_path):
+@pytest.mark.parametrize("flags", [0, _lib.FLAG_RESIDENT_STEP])
+def test_fused_sequence_against_the_committed_vectors(exe, tmp_path, flags):
     """No constraints: tgnh_step_begin / force call-out / tgnh_step_end per step -- the case nacl_tgnh of
     tests/golden/oracle_regression.npz (512 pairs, hard wall 0.02 nm, one-link chains, 40 steps).  Double precision:
     the vectors were made with the tether sites as doubles, and the harness keeps them in the position type."""
     frozen = np.load(os.path.join(ROOT, "tests", "golden", "oracle_regression.npz"))
     s, g, ng = synth.nacl()
-    pos, vel, eta_dot, ke = run_glue(exe, tmp_path, s, g, ng, 40, False, 1, True, True, 0.001, 0.02, 1e-5, "double")
+    pos, vel, eta_dot, ke = run_glue(exe, tmp_path, s, g, ng, 40, False, 1, True, True, 0.001, 0.02, 1e-5, "double", flags)
     assert rel_err(pos[:64], frozen["nacl_tgnh/pos64"]) <= 1e-6
     assert rel_err(vel[:64], frozen["nacl_tgnh/vel64"]) <= 1e-6
     assert np.allclose(eta_dot, frozen["nacl_tgnh/etaDot"], rtol=1e-6, atol=1e-9)
@@ -65,15 +66,17 @@ def test_fused_sequence_against_the_committed_vectors(exe, tmp_path):
     assert ke == pytest.approx(0.5 * frozen["nacl_tgnh/ke"][-1].sum(), rel=1e-6)
 
 
+@pytest.mark.parametrize("flags", [0, _lib.FLAG_RESIDENT_STEP])
 @pytest.mark.parametrize("name", ["rigid water", "ionic liquid"])
-def test_split_sequence_with_call_outs_and_state_changes(exe, tmp_path, name):
+def test_split_sequence_with_call_outs_and_state_changes(exe, tmp_path, name, flags):
     """Constraints present: begin_kick / applyConstraints / begin_move / computeVirtualSites / calcForcesAndEnergy /
     end_kick / applyVelocityConstraints / end_thermo, and between steps a CMMotionRemover changes the velocities behind
     the integrator's back (stateChanged()).  Against the oracle doing the same, 1e-6."""
     s, g, ng = synth.water_box(64, rigid=True) if name == "rigid water" else synth.ionic_liquid(12, constrained=True)
     tol, nsteps = 1e-10, 40
-    pos, vel, eta_dot, ke = run_glue(exe, tmp_path, s, g, ng, nsteps, True, 2, True, True, 0.001, 0.02, tol)
-    it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, 2, True, True)
+    chains = 2 if flags == 0 else 1          # (step_kernel runs one-link chains; longer ones take the chain launch)
+    pos, vel, eta_dot, ke = run_glue(exe, tmp_path, s, g, ng, nsteps, True, chains, True, True, 0.001, 0.02, tol, "mixed", flags)
+    it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, chains, True, True)
     it.setMaxDrudeDistance(0.02)
     o = make_oracle(s, g, ng, "TGNH", it)
     x0 = s.positions.astype(np.float32).astype(np.float64)          # the harness keeps the tether sites in the position type
