@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OPS = {64: "prekick", 1: "rescale", 2: "kick", 4: "drift", 8: "KE", 16: "posDelta", 32: "move", 128: "unstored"}
 PREC = ["single", "mixed", "double"]
+STEP_KINDS = ["deferred step", "plain begin half", "plain end half", "split begin half", "split end half"]
 SQ = ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
       "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"]
 
@@ -39,9 +40,9 @@ def pretty(n):
     if m:
         ops = int(m.group(2))
         return "tile<%s,%s>" % (PREC[int(m.group(1))], "+".join(v for k, v in OPS.items() if ops & k))
-    m = re.search(r"step_kernel<(\d), (\d)>", n)
+    m = re.search(r"step_kernel<(\d), (\d), (\d)>", n)
     if m:
-        return "step_kernel<%s>" % PREC[int(m.group(1))]
+        return "step_kernel<%s,%s>" % (PREC[int(m.group(1))], STEP_KINDS[int(m.group(3))])
     return re.sub(r"\(.*", "", n).replace("void ", "").replace("tgnh::", "")[:60]
 
 
@@ -98,7 +99,10 @@ def main():
     shutil.copy(stats, os.path.join(prof, f"{a.tag}_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats)))
     prec = line["config"]["precision"]
-    dom = f"step_kernel<{prec}>" if line["roofline"]["kernel"] == "step_kernel" else f"tile<{prec},prekick+rescale+kick+drift>"
+    if line["roofline"]["kernel"] == "step_kernel":
+        dom = f"step_kernel<{prec},{'deferred step' if variant == 'resident' else 'plain begin half'}>"
+    else:
+        dom = f"tile<{prec},{'prekick+' if variant == 'defer' else ''}rescale+kick+drift>"
     with open(os.path.join(prof, f"{a.tag}_summary.md"), "w") as f:
         f.write(f"`rocprofv3 --kernel-trace --stats -- {' '.join(bench)}`  \ncsrc_sha `{sha}`, variant `{variant}`, {slots} slots; "
                 f"bench line: {line['value']} steps/s, roofline.avg_launch_us {line['roofline']['avg_launch_us']} (HIP events)\n\n")
