@@ -1024,9 +1024,10 @@ def test_1000_step_mixed_precision_gate(flags):
     ctx.close()
 
 
+@pytest.mark.parametrize("flags", [0, FLAG_RESIDENT_STEP])
 @pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
-def test_kinetic_energy_query(mode):
-    s, g, ng, it, ctx = make("mixed", mode, "double")
+def test_kinetic_energy_query(mode, flags):
+    s, g, ng, it, ctx = make("mixed", mode, "double", chains=3 if flags == 0 else 1, flags=flags)
     o = make_oracle(s, g, ng, mode, it)
     f = o.harness_force(s.positions, ctx.sites(), synth.K_DRUDE, synth.K_TETHER)
     assert ctx.kinetic_energy() == pytest.approx(o.kinetic_energy_query(s.velocities, f, False), rel=1e-9)
@@ -1037,10 +1038,10 @@ def test_kinetic_energy_query(mode):
     ctx.close()
 
 
-@pytest.mark.parametrize("chains", [1, 3])
-def test_setters_take_effect_mid_run(chains):
+@pytest.mark.parametrize("chains,flags", [(1, 0), (3, 0), (1, FLAG_RESIDENT_STEP)])
+def test_setters_take_effect_mid_run(chains, flags):
     """Step size and drudeStepsPerRealStep are re-read every step (Cu :292, :437)."""
-    s, g, ng, it, ctx = make("water27", "TGNH", "double", chains=chains)
+    s, g, ng, it, ctx = make("water27", "TGNH", "double", chains=chains, flags=flags)
     o = make_oracle(s, g, ng, "TGNH", it)
     pos, vel, x0 = s.positions.copy(), s.velocities.copy(), ctx.sites()
     f = o.harness_force(pos, x0, synth.K_DRUDE, synth.K_TETHER)
