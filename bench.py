@@ -64,6 +64,10 @@ def parse():
                         "mailbox = tgnh_exchange_* (stores over xGMI).  The other one is measured as an extra leg")
     p.add_argument("--dry-launch", action="store_true",
                    help="launcher check only: the ranks rendezvous (gloo), count themselves and rank 0 prints the count; no GPU work")
+    p.add_argument("--side-leg", action="store_true",
+                   help="internal: this process is a child rank that measures the non-headline exchange of a sharded run "
+                        "(--exchange names it) and prints its record; started by the ranks of the main run, see side_leg_in_children")
+    p.add_argument("--side-leg-timeout", type=float, default=420.0, help="seconds the main run gives its side-leg children")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the extra single-precision / variant legs")
     return p.parse_args()
@@ -368,6 +372,54 @@ def self_launch(args, argv):
     raise SystemExit(0)
 
 
+def side_leg_in_children(args, other, rank, world, argv):
+    """The exchange beside the headline one is measured by CHILD processes, one per rank, with a process group of their
+    own: whatever happens to them -- a mapping that fails, a wait that never ends, a device fault that aborts the
+    process -- the headline record of this run is already in hand and still gets printed.  (The mailbox exchange maps
+    every rank's mailbox into every peer with hipIpc and stores across xGMI; on a one-GPU box only its one-device form
+    can be rehearsed.)  The parents have closed their contexts and only wait; the children are ordinary child
+    processes (nothing that has initialised HIP is re-executed).  Returns rank 0's record of the leg."""
+    import subprocess
+    import torch.distributed as dist
+    port = [free_port() if rank == 0 else None]
+    dist.broadcast_object_list(port, src=0)
+    # (under torchrun the ranks' rendezvous is the agent's store; the children make their own on the new port)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]))
+    drop = ("--side-leg", "--exchange", "--no-extra")
+    keep, skip = [], False
+    for a in argv:                                     # the main run's own arguments, minus what the child sets itself
+        if skip:
+            skip = False
+            continue
+        if a in drop:
+            skip = a == "--exchange"
+            continue
+        if a.startswith("--exchange="):
+            continue
+        keep.append(a)
+    cmd = [sys.executable, os.path.abspath(__file__)] + keep + ["--exchange", other, "--side-leg", "--no-cpu-baseline"]
+    info = {"measured_by": "child ranks with a process group of their own"}
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, timeout=args.side_leg_timeout)
+        lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if p.returncode == 0 and lines:
+            info.update(json.loads(lines[-1]))
+        elif p.returncode != 0:
+            info["failed"] = f"child rank {rank} ended with exit code {p.returncode}"
+    except subprocess.TimeoutExpired:
+        info["failed"] = f"child rank {rank} did not finish within {args.side_leg_timeout:.0f} s and was stopped"
+    # one verdict for the run: rank 0 holds the record; any rank's failure marks it
+    fails = [None] * world
+    dist.all_gather_object(fails, info.get("failed"))
+    bad = [f for f in fails if f]
+    if bad:
+        info = {k: v for k, v in info.items() if k in ("measured_by", "validated_against_rccl")}
+        info["failed"] = "; ".join(bad)
+        info["steps_per_s"] = None
+    return info
+
+
 def dry_launch(args, world, rank):
     """Launcher check (CPU, gloo): the ranks meet, count themselves, rank 0 prints the count."""
     import torch
@@ -463,6 +515,34 @@ def main():
         dt = timed_run(ctx, args.steps, args.warmup, world, g, dominant_kid(args.variant))
         return ctx, dt
 
+    def side_leg(other):
+        """the exchange that is not the headline one, same system, same steps -> its record"""
+        info = {}
+        ok = True
+        if other == "mailbox":
+            ok = validate_mailbox(args, rank, world)
+            info["validated_against_rccl"] = ok
+        if ok:
+            c2, d2 = run_leg(other)
+            if c2 is not None:
+                timed_out = other == "mailbox" and not all_ranks_agree((c2.status_flags() & 4) == 0)
+                info.update({"steps_per_s": None if timed_out else round(args.steps / d2, 3),
+                             "ms_per_step": round(d2 / args.steps * 1e3, 5), "hipgraph": c2.graph_used,
+                             "step_kernel_ran": _lib.KERNEL_NAMES[_lib.KID_STEP] in c2.leg["kernels"],
+                             "timed_out": timed_out, "sum_kernels_us_per_step": c2.leg["sum_kernels_us_per_step"]})
+                close_sharded(c2)
+            else:
+                info["attached"] = False
+        return info
+
+    if args.side_leg:                                  # a child rank of side_leg_in_children: measure, report, done
+        info = side_leg(args.exchange)
+        if rank == 0:
+            os.write(real_stdout, (json.dumps(info) + "\n").encode())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
     headline_exchange = args.exchange if use_dist else None
     mailbox_info = None
     if headline_exchange == "mailbox":
@@ -499,24 +579,11 @@ def main():
 
     extra = {}
     if use_dist and world > 1 and not args.no_extra:
-        # the other exchange, same system, same steps: the mailbox exchange beside an RCCL headline (or the reverse)
+        # the other exchange beside the headline one (the mailboxes beside an RCCL headline, or the reverse), measured by
+        # child ranks so that nothing it does can take the headline record with it
         other = "mailbox" if headline_exchange == "rccl" else "rccl"
-        info = {}
-        ok = True
-        if other == "mailbox":
-            ok = validate_mailbox(args, rank, world)
-            info["validated_against_rccl"] = ok
-        if ok:
-            c2, d2 = run_leg(other)
-            if c2 is not None:
-                timed_out = other == "mailbox" and not all_ranks_agree((c2.status_flags() & 4) == 0)
-                info.update({"steps_per_s": None if timed_out else round(args.steps / d2, 3),
-                             "ms_per_step": round(d2 / args.steps * 1e3, 5), "hipgraph": c2.graph_used,
-                             "timed_out": timed_out, "sum_kernels_us_per_step": c2.leg["sum_kernels_us_per_step"]})
-                close_sharded(c2)
-            else:
-                info["attached"] = False
-        extra[other] = info
+        torch.cuda.empty_cache()                       # the children run on this rank's GPU
+        extra[other] = side_leg_in_children(args, other, rank, world, sys.argv[1:])
     if mailbox_info:
         extra["mailbox"] = dict(extra.get("mailbox", {}), **mailbox_info)
     if world == 1 and not args.no_extra:

@@ -1,0 +1,49 @@
+"""bench.py's sharded flow, rehearsed with two ranks on the ONE GPU of the box (gloo for the setup collectives and the
+all-reduce hook; the ranks share the device's work-group slots): its own launcher, whole-molecule shards, the headline leg
+with the collective hook, and -- measured by child ranks with a process group of their own, so that nothing it does can
+cost the headline record -- the mailbox exchange validated against the hook.  What cannot be rehearsed here is the link
+itself (stores crossing xGMI, RCCL between devices)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _bench(argv, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(TGNH_BENCH_BACKEND="gloo", TGNH_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    e.update(env)
+    return subprocess.run([sys.executable, BENCH] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=600)
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_reports_both_exchanges():
+    p = _bench(["--gpus", "2", "--molecules", "20000", "--steps", "100", "--warmup", "10"])
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+    assert j["config"]["exchange"] == "rccl" and j["config"]["rccl_ranks"] == 2       # the headline is the collective hook
+    assert j["config"]["slots_per_gpu"] == 50000
+    mb = j["extra"]["mailbox"]
+    assert "failed" not in mb, mb
+    assert mb["validated_against_rccl"] is True and mb["timed_out"] is False
+    assert mb["steps_per_s"] > 0 and mb["step_kernel_ran"] is True
+    assert "child ranks" in mb["measured_by"]
+
+
+@pytest.mark.gpu
+def test_a_side_leg_that_dies_does_not_take_the_headline_with_it():
+    # the children are told to stop at once (their time limit is zero seconds): the run still ends with its headline line
+    p = _bench(["--gpus", "2", "--molecules", "20000", "--steps", "50", "--warmup", "5", "--side-leg-timeout", "0.001"])
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    j = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["exchange"] == "rccl"
+    mb = j["extra"]["mailbox"]
+    assert mb["steps_per_s"] is None and "stopped" in mb["failed"]
