@@ -399,8 +399,8 @@ __device__ __forceinline__ Chain1Map chain1_map(const ChainLayout& L, const int 
 }
 
 // ---- mailbox exchange (protocol: XchgArgs in tgnh_internal.h) ----
-__device__ __forceinline__ size_t xchg_cell(const XchgArgs& x, const unsigned par, const int src, const int i) {
-    return (((size_t)par * x.world + src) * XCHG_NT_PAD + i) * XCHG_CELL_U64;
+__device__ __forceinline__ size_t xchg_cell(const XchgArgs& x, const unsigned par, const int src, const int i, const int copy = 0) {
+    return (size_t)copy * XCHG_REPLICA_U64(x.world) + (((size_t)par * x.world + src) * XCHG_NT_PAD + i) * XCHG_CELL_U64;
 }
 __device__ __forceinline__ unsigned long long xchg_ld(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -415,10 +415,11 @@ __device__ __forceinline__ void xchg_send(const XchgArgs& x, const int NT, const
     if (tid < NT) s_val[tid] = mine;
     __syncthreads();
     const unsigned long long seq = s_seq, tag = (seq & 0xffffffffull) << 32;
-    for (int k = tid; k < x.world * NT; k += nthreads) {
-        const int p = k / NT, i = k - p * NT;
+    for (int k = tid; k < x.world * NT * XCHG_REPLICAS; k += nthreads) {      // every copy of every rank's mailbox
+        const int copy = k / (x.world * NT), q = k - copy * (x.world * NT);
+        const int p = q / NT, i = q - p * NT;
         const unsigned long long bits = (unsigned long long)__double_as_longlong(s_val[i]);
-        unsigned long long* cell = x.peers[p] + xchg_cell(x, (unsigned)(seq & 1ull), x.rank, i);
+        unsigned long long* cell = x.peers[p] + xchg_cell(x, (unsigned)(seq & 1ull), x.rank, i, copy);
         __hip_atomic_store(cell, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(cell + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -429,14 +430,15 @@ __device__ __forceinline__ void xchg_send(const XchgArgs& x, const int NT, const
 __device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT, const int lane, double* s_val,
                                                 const unsigned long long seq_expected = 0ull, bool* failed = nullptr) {
     const int cells = x.world * NT;
+    const int copy = (int)(blockIdx.x % (unsigned)XCHG_REPLICAS);     // this work-group's copy of the cells
     // first batch: counter, latch and both parities of this lane's first cell, all in flight together
     const unsigned long long seq_raw = seq_expected ? seq_expected : __hip_atomic_load(x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned dead = __hip_atomic_load(x.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long a0 = 0, a1 = 0, b0 = 0, b1 = 0;
     if (lane < cells) {
         const int r = lane / NT, i = lane - r * NT;
-        const unsigned long long* c0 = x.mine + xchg_cell(x, 0u, r, i);
-        const unsigned long long* c1 = x.mine + xchg_cell(x, 1u, r, i);
+        const unsigned long long* c0 = x.mine + xchg_cell(x, 0u, r, i, copy);
+        const unsigned long long* c1 = x.mine + xchg_cell(x, 1u, r, i, copy);
         a0 = xchg_ld(c0); a1 = xchg_ld(c0 + 1); b0 = xchg_ld(c1); b1 = xchg_ld(c1 + 1);
     }
     const unsigned par = (unsigned)(seq_raw & 1ull);
@@ -444,7 +446,7 @@ __device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT,
     bool timed_out = false;
     for (int k = lane; k < cells; k += 64) {
         const int r = k / NT, i = k - r * NT;
-        const unsigned long long* c = x.mine + xchg_cell(x, par, r, i);
+        const unsigned long long* c = x.mine + xchg_cell(x, par, r, i, copy);
         unsigned long long w0, w1;
         if (k == lane) { w0 = par ? b0 : a0; w1 = par ? b1 : a1; }
         else { w0 = xchg_ld(c); w1 = xchg_ld(c + 1); }

@@ -98,7 +98,18 @@ constexpr int XCHG_CELL_U64 = 2;            // 8-byte words per cell
 constexpr int XCHG_MAX_WORLD = 16;
 constexpr unsigned XCHG_SPIN_LIMIT = 1000000u;  // polls (each a round trip to memory, ~2 us) before giving up: seconds
 constexpr unsigned CENSUS_SPIN_LIMIT = 20000u;  // the residency census of step_kernel: tens of milliseconds
-constexpr size_t XCHG_MAILBOX_BYTES(int world) { return sizeof(unsigned long long) * 2 * (size_t)world * XCHG_NT_PAD * XCHG_CELL_U64; }
+// Replicas: a mailbox holds XCHG_REPLICAS copies of its cells, a sender stores into all of them and waiting work-group b
+// polls copy b % XCHG_REPLICAS.  One copy is one 48-byte neighbourhood, i.e. ONE memory channel that all 768 waiting
+// work-groups of a launch poll at once (their requests queue there, and the poll that finally sees the data waits behind
+// everybody else's); the copies lie a page and a channel apart (stride = k x 4096 + 256 bytes).
+#ifndef TGNH_XCHG_REPLICAS
+#define TGNH_XCHG_REPLICAS 32
+#endif
+constexpr int XCHG_REPLICAS = TGNH_XCHG_REPLICAS;
+constexpr size_t XCHG_REPLICA_U64(int world) {      // 8-byte words from one copy to the next
+    return ((sizeof(unsigned long long) * 2 * (size_t)world * XCHG_NT_PAD * XCHG_CELL_U64 + 4095) / 4096 * 4096 + 256) / sizeof(unsigned long long);
+}
+constexpr size_t XCHG_MAILBOX_BYTES(int world) { return sizeof(unsigned long long) * XCHG_REPLICA_U64(world) * XCHG_REPLICAS; }
 
 struct XchgArgs {
     int on;                     // 0 off
