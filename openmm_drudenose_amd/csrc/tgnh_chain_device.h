@@ -400,26 +400,37 @@ __device__ __forceinline__ Chain1Map chain1_map(const ChainLayout& L, const int 
 
 // ---- mailbox exchange (protocol: XchgArgs in tgnh_internal.h) ----
 __device__ __forceinline__ size_t xchg_cell(const XchgArgs& x, const unsigned par, const int src, const int i, const int copy = 0) {
-    return (size_t)copy * XCHG_REPLICA_U64(x.world) + (((size_t)par * x.world + src) * XCHG_NT_PAD + i) * XCHG_CELL_U64;
+    return (size_t)copy * XCHG_REPLICA_U64 + (((size_t)par * x.world + src) * XCHG_NT_PAD + i) * XCHG_CELL_U64;
 }
 __device__ __forceinline__ unsigned long long xchg_ld(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// The mailbox thread tid of a sending work-group stores into: thread tid serves peer tid % world, so every thread needs ONE
+// mailbox pointer, which a caller with time to spare fetches ahead of the send (step_kernel: before it collects the rows).
+__device__ __forceinline__ unsigned long long* xchg_peer_of(const XchgArgs& x, const int tid) {
+    return x.world == 1 ? x.mine : x.peers[tid % x.world];
+}
 // Called by one work-group with `mine` = this rank's sum in thread tid < NT, handed over through s_val (LDS, NT doubles).
 // Contains __syncthreads().  seq_new != 0 (thread 0): the number of this exchange, when the caller has read the counter
 // already (step_kernel reads it at kernel entry: no load on the path between the last row and the send).
+// peer = xchg_peer_of(x, tid) when the caller has fetched it already.
 __device__ __forceinline__ void xchg_send(const XchgArgs& x, const int NT, const int tid, const int nthreads, double* s_val,
-                                          const double mine, const unsigned long long seq_new = 0ull) {
+                                          const double mine, const unsigned long long seq_new = 0ull,
+                                          unsigned long long* peer = nullptr) {
     __shared__ unsigned long long s_seq;
+    if (!peer) peer = xchg_peer_of(x, tid);
     if (tid == 0) { const unsigned long long s = seq_new ? seq_new : *x.seq + 1ull; *x.seq = s; s_seq = s; }
     if (tid < NT) s_val[tid] = mine;
     __syncthreads();
     const unsigned long long seq = s_seq, tag = (seq & 0xffffffffull) << 32;
-    for (int k = tid; k < x.world * NT * XCHG_REPLICAS; k += nthreads) {      // every copy of every rank's mailbox
-        const int copy = k / (x.world * NT), q = k - copy * (x.world * NT);
-        const int p = q / NT, i = q - p * NT;
+    const int tpp = nthreads / x.world;                      // threads per peer
+    if (tid >= tpp * x.world) return;
+    // every copy of the peer's cells [parity][my rank][0 .. NT): copy-major, so copy 0 goes out first
+    unsigned long long* const base = peer + xchg_cell(x, (unsigned)(seq & 1ull), x.rank, 0, 0);
+    for (int q = tid / x.world; q < NT * XCHG_REPLICAS; q += tpp) {
+        const int copy = q / NT, i = q - copy * NT;
         const unsigned long long bits = (unsigned long long)__double_as_longlong(s_val[i]);
-        unsigned long long* cell = x.peers[p] + xchg_cell(x, (unsigned)(seq & 1ull), x.rank, i, copy);
+        unsigned long long* cell = base + (size_t)copy * XCHG_REPLICA_U64 + (size_t)i * XCHG_CELL_U64;
         __hip_atomic_store(cell, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(cell + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -427,18 +438,21 @@ __device__ __forceinline__ void xchg_send(const XchgArgs& x, const int NT, const
 // Called by all 64 lanes of one wavefront, converged; s_val = LDS scratch of world*NT doubles owned by that wavefront.
 // Returns the all-rank sum of thermostat `lane` (lanes < NT).  seq_expected != 0: the exchange to wait for when this
 // rank's own send may not have happened yet (step_kernel: sender and waiters are work-groups of one launch).
+// SPREAD: the work-groups of the launch poll different copies of the cells (step_kernel, where all of them wait at the
+// same moment); otherwise copy 0.
+template <bool SPREAD = false>
 __device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT, const int lane, double* s_val,
                                                 const unsigned long long seq_expected = 0ull, bool* failed = nullptr) {
     const int cells = x.world * NT;
-    const int copy = (int)(blockIdx.x % (unsigned)XCHG_REPLICAS);     // this work-group's copy of the cells
+    const unsigned long long* const box = x.mine + (SPREAD ? (size_t)(blockIdx.x % (unsigned)XCHG_REPLICAS) * XCHG_REPLICA_U64 : 0);
     // first batch: counter, latch and both parities of this lane's first cell, all in flight together
     const unsigned long long seq_raw = seq_expected ? seq_expected : __hip_atomic_load(x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned dead = __hip_atomic_load(x.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long a0 = 0, a1 = 0, b0 = 0, b1 = 0;
     if (lane < cells) {
         const int r = lane / NT, i = lane - r * NT;
-        const unsigned long long* c0 = x.mine + xchg_cell(x, 0u, r, i, copy);
-        const unsigned long long* c1 = x.mine + xchg_cell(x, 1u, r, i, copy);
+        const unsigned long long* c0 = box + xchg_cell(x, 0u, r, i);
+        const unsigned long long* c1 = box + xchg_cell(x, 1u, r, i);
         a0 = xchg_ld(c0); a1 = xchg_ld(c0 + 1); b0 = xchg_ld(c1); b1 = xchg_ld(c1 + 1);
     }
     const unsigned par = (unsigned)(seq_raw & 1ull);
@@ -446,7 +460,7 @@ __device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT,
     bool timed_out = false;
     for (int k = lane; k < cells; k += 64) {
         const int r = k / NT, i = k - r * NT;
-        const unsigned long long* c = x.mine + xchg_cell(x, par, r, i, copy);
+        const unsigned long long* c = box + xchg_cell(x, par, r, i);
         unsigned long long w0, w1;
         if (k == lane) { w0 = par ? b0 : a0; w1 = par ? b1 : a1; }
         else { w0 = xchg_ld(c); w1 = xchg_ld(c + 1); }

@@ -13,6 +13,9 @@
 #include <cstring>
 
 #include "tgnh_internal.h"
+#ifndef TGNH_MEETING_MEM
+#define TGNH_MEETING_MEM hipDeviceMallocFinegrained
+#endif
 
 using namespace tgnh;
 
@@ -526,13 +529,15 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         HIP_OK(hipMemset(c->d_sync, 0, 4 * sizeof(unsigned int)));
         if (c->d.flags & TGNH_FLAG_RESIDENT_STEP) {
             // step_kernel's meeting place: the work-groups' tagged rows, and a private one-rank mailbox that carries the
-            // sums from work-group 0 to all the others when no sharded exchange is attached (uncached, like the mailboxes)
+            // sums from work-group 0 to all the others when no sharded exchange is attached.  Both stay on this device:
+            // fine-grained memory (a flag stored by one work-group is seen by a polling one on another XCD after 0.37-0.39 us,
+            // uncached memory takes 0.58-0.63: tools/micro/hop_probe.hip); the mailboxes peers store into are uncached
             const size_t rb = sizeof(unsigned long long) * 2 * (size_t)GRID_CAP * CHAIN_INLINE_SUM_NT;
             void* p = nullptr;
-            HIP_OK(hipExtMallocWithFlags(&p, rb, hipDeviceMallocUncached));
+            HIP_OK(hipExtMallocWithFlags(&p, rb, TGNH_MEETING_MEM));
             c->d_rows = static_cast<unsigned long long*>(p);
             HIP_OK(hipMemset(c->d_rows, 0, rb));
-            HIP_OK(hipExtMallocWithFlags(&p, XCHG_MAILBOX_BYTES(1), hipDeviceMallocUncached));
+            HIP_OK(hipExtMallocWithFlags(&p, XCHG_MAILBOX_BYTES(1), TGNH_MEETING_MEM));
             c->self_box = static_cast<unsigned long long*>(p);
             HIP_OK(hipMemset(c->self_box, 0, XCHG_MAILBOX_BYTES(1)));
             HIP_OK(hipMalloc(&c->d_self_misc, 4 * sizeof(unsigned long long)));     // [0] seq, [1] dead latch, [2] peers[0]

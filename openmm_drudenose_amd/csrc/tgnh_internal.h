@@ -106,10 +106,10 @@ constexpr unsigned CENSUS_SPIN_LIMIT = 20000u;  // the residency census of step_
 #define TGNH_XCHG_REPLICAS 32
 #endif
 constexpr int XCHG_REPLICAS = TGNH_XCHG_REPLICAS;
-constexpr size_t XCHG_REPLICA_U64(int world) {      // 8-byte words from one copy to the next
-    return ((sizeof(unsigned long long) * 2 * (size_t)world * XCHG_NT_PAD * XCHG_CELL_U64 + 4095) / 4096 * 4096 + 256) / sizeof(unsigned long long);
-}
-constexpr size_t XCHG_MAILBOX_BYTES(int world) { return sizeof(unsigned long long) * XCHG_REPLICA_U64(world) * XCHG_REPLICAS; }
+// (from one copy to the next, in 8-byte words: room for the largest world, so that the stride is a compile-time constant)
+constexpr size_t XCHG_REPLICA_U64 =
+    ((sizeof(unsigned long long) * 2 * (size_t)XCHG_MAX_WORLD * XCHG_NT_PAD * XCHG_CELL_U64 + 4095) / 4096 * 4096 + 256) / sizeof(unsigned long long);
+constexpr size_t XCHG_MAILBOX_BYTES(int /*world*/) { return sizeof(unsigned long long) * XCHG_REPLICA_U64 * XCHG_REPLICAS; }
 
 struct XchgArgs {
     int on;                     // 0 off

@@ -540,6 +540,14 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, TileEnv<PREC, GB>& 
     if (lds_read) __syncthreads();       // LDS image is reused by the next tile
 }
 
+// step_kernel's tagged rows: word j (two per thermostat) of row r.  Rows come in blocks of 64 -- the rows one wavefront of the
+// collecting work-group reads with one load -- and inside a block word-major: the 64 lanes of a load read 512 contiguous
+// bytes (one request per 64-byte line instead of one per lane: the collection is bound by the requests a single compute
+// unit issues), and the words of a row lie 512 bytes apart, within reach of a load's immediate offset (one address per row).
+__device__ __forceinline__ size_t row_word(const int r, const int j) {
+    return ((size_t)(r >> 6) * (2 * CHAIN_INLINE_SUM_NT) + j) * 64 + (r & 63);
+}
+
 // Work-group reduction of the fp64 KE bins: 64-lane butterflies, then one LDS hop; one row of `partials` per work-group.
 // TAGGED: the row is read by another work-group of the SAME launch (step_kernel): every sum goes out as a cell of two
 // 8-byte words {32 bits of the double, tag} into a.rows -- data and "it is there" in one atomic store, as in the mailboxes.
@@ -549,13 +557,14 @@ __device__ __forceinline__ void ke_reduce(const TileArgs& a, TileEnv<PREC, GB>& 
     const int tid = e.tid, G = e.G;
     double (&ke_g)[E::GBR] = e.ke_g;
     double ke_com = e.ke_com, ke_drude = e.ke_drude;
-    auto put = [&](double* p, double v) {
+    // thermostat b of this work-group's row (tagged rows: row_word's layout)
+    auto put = [&](const int b, double v) {
         if (TAGGED) {
-            unsigned long long* cell = a.rows + (size_t)(p - a.partials) * 2;
+            unsigned long long* cell = a.rows + row_word((int)blockIdx.x, 2 * b);
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
             __hip_atomic_store(cell, t | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(cell + 1, t | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        } else *p = v;
+            __hip_atomic_store(cell + 64, t | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else a.partials[(size_t)blockIdx.x * (G + 2) + b] = v;
     };
     double* sred = scratch ? scratch : reinterpret_cast<double*>(e.smem);   // [TBLOCK/64][GB+2]
     const int lane = tid & 63, wv = tid >> 6;
@@ -575,9 +584,8 @@ __device__ __forceinline__ void ke_reduce(const TileArgs& a, TileEnv<PREC, GB>& 
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < TBLOCK / 64; w++) s += sred[w * (GB + 2) + tid];   // fixed order
-        const int NT = G + 2;
-        if (tid < GB) { if (tid < G) put(&a.partials[(size_t)blockIdx.x * NT + tid], s); }
-        else put(&a.partials[(size_t)blockIdx.x * NT + G + (tid - GB)], s);
+        if (tid < GB) { if (tid < G) put(tid, s); }
+        else put(G + (tid - GB), s);
     }
     if (GB == 0) {
         const double* w0 = e.wbins0;
@@ -585,7 +593,7 @@ __device__ __forceinline__ void ke_reduce(const TileArgs& a, TileEnv<PREC, GB>& 
             double s = 0.0;
 #pragma unroll
             for (int w = 0; w < TBLOCK / 64; w++) s += w0[w * G + g];     // fixed order
-            put(&a.partials[(size_t)blockIdx.x * (G + 2) + g], s);
+            put(g, s);
         }
     }
 }
@@ -780,6 +788,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
     __shared__ double s_x[64 + XCHG_MAX_WORLD * CHAIN_INLINE_SUM_NT];      // scratch of the sums and the exchange: the images stay intact
     __shared__ int s_go;
     __shared__ unsigned s_gen;
+    __shared__ unsigned long long s_seq1;                  // the number of the exchange this launch sends and waits for
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, G = a.num_groups, NT = G + 2;
     const int grid = (int)gridDim.x;
@@ -833,19 +842,22 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
 
     // ---- meet: work-group 0 collects the rows.  Thread t owns rows t, t + 256, ...: it polls their cells until all
     // carry this launch's tag and adds them in row order; then butterflies and one LDS hop, fixed order throughout.
-    if (tid == 0) s_gen = gen0;
+    if (tid == 0) { s_gen = gen0; s_seq1 = seq0 + 1ull; }
     __syncthreads();
     const unsigned long long want = (unsigned long long)(s_gen + 1u);
     if (leader) {
+        unsigned long long* const my_peer = xchg_peer_of(a.chain.x, tid);   // for the send: fetched before the collection, not after
         constexpr int NTM = GB + 2;                        // NT = G + 2 <= GB + 2: the register arrays follow the instantiation
         double acc[NTM];
 #pragma unroll
         for (int b = 0; b < NTM; b++) acc[b] = 0.0;
         bool ok = true;
+        TRACE(6);
         // RB rows of this thread per batch of loads (all of them for the resident grid of 768 when G = 1): once the last row
         // is there, one more round trip sees everything -- polled row after row, a thread whose first row came last paid
         // a round trip for each of the others behind it.  CH thermostats of a row per batch: the registers a batch takes
-        // (2 x CH x RB words) do not grow with the number of temperature groups.
+        // (2 x CH x RB words) do not grow with the number of temperature groups.  (Tracking the rows already seen, so that
+        // later rounds poll the stragglers only, took 35 more VGPRs -- a work-group per compute unit -- and was dropped.)
         constexpr int RB = GB == 1 ? 3 : 1, CH = 3;
 #pragma unroll 1
         for (int r0 = tid; r0 < grid && ok; r0 += RB * TBLOCK) {
@@ -858,9 +870,9 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
 #pragma unroll
                     for (int k = 0; k < RB; k++) {
                         const int r = r0 + k * TBLOCK;
-                        const unsigned long long* cell = a.rows + ((size_t)r * NT + b0) * 2;
+                        const unsigned long long* cell = a.rows + row_word(r, 2 * b0);   // the lanes of a load read consecutive words
 #pragma unroll
-                        for (int b = 0; b < 2 * CH; b++) if (b0 + b / 2 < NT && r < grid) w[k][b] = xchg_ld(cell + b);
+                        for (int b = 0; b < 2 * CH; b++) if (b0 + b / 2 < NT && r < grid) w[k][b] = xchg_ld(cell + b * 64);
                     }
 #pragma unroll
                     for (int k = 0; k < RB; k++)
@@ -868,7 +880,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
                         for (int b = 0; b < 2 * CH; b++) if (b0 + b / 2 < NT && r0 + k * TBLOCK < grid) all = all && (w[k][b] >> 32) == want;
                     if (all) break;
                     if (++n > XCHG_SPIN_LIMIT) { ok = false; break; }
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
                 for (int k = 0; k < RB; k++)                // row order: r0, r0 + 256, ...
@@ -881,6 +893,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
                         }
             }
         }
+        TRACE(10);
         if (!ok) {                                         // a work-group never handed in its row: nobody goes on
             atomicOr(a.status, 8u);
             __hip_atomic_store(a.chain.x.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -897,19 +910,31 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
             }
         }
         __syncthreads();
-        double mine = 0.0;
-        if (tid < NT) {
-#pragma unroll
-            for (int w = 0; w < TBLOCK / 64; w++) mine += s_part[w][tid];
-        }
         TRACE(7);
-        if (tid == 0) a.sync[1] = s_gen + 1u;              // the next launch's rows carry the next tag
-        xchg_send(a.chain.x, NT, tid, TBLOCK, s_x, mine, seq0 + 1ull);
-        __syncthreads();
+        // the send (xchg_send's stores, tgnh_chain_device.h), straight from the four wavefronts' partial sums: every storing
+        // thread adds them itself, in wavefront order -- no second hand-over through LDS, no second barrier on this path
+        const XchgArgs& x = a.chain.x;
+        const unsigned long long seq = s_seq1, stag = (seq & 0xffffffffull) << 32;
+        if (tid == 0) { a.sync[1] = s_gen + 1u; *x.seq = seq; }      // the next launch's rows carry the next tag
+        const int tpp = TBLOCK / x.world;
+        if (tid < tpp * x.world) {
+            unsigned long long* const base = my_peer + xchg_cell(x, (unsigned)(seq & 1ull), x.rank, 0, 0);
+            for (int q = tid / x.world; q < NT * XCHG_REPLICAS; q += tpp) {
+                const int copy = q / NT, i = q - copy * NT;
+                double v = 0.0;
+#pragma unroll
+                for (int w = 0; w < TBLOCK / 64; w++) v += s_part[w][i];
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                unsigned long long* cell = base + (size_t)copy * XCHG_REPLICA_U64 + (size_t)i * XCHG_CELL_U64;
+                __hip_atomic_store(cell, stag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(cell + 1, stag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        TRACE(13);
     }
     if (chain_wave) {
         bool dead = false;                                 // an exchange has timed out, now or earlier (the latch)
-        const double mine = xchg_wait_sum(a.chain.x, NT, itg, s_x + 64, seq0 + 1ull, &dead);
+        const double mine = xchg_wait_sum<true>(a.chain.x, NT, itg, s_x + 64, seq0 + 1ull, &dead);
         TRACE(8);
         double kesum = 0.0;
         for (int i = 0; i < NT; i++) kesum += __shfl(mine, i, 64);
