@@ -1163,6 +1163,17 @@ def test_config_sizes_parity(name):
     print(f"{name}: N={s.num_particles} P={s.num_pairs} G={ng} steps={nsteps} pos {ep:.2e} vel {ev:.2e}")
     assert ep <= TOL and ev <= TOL and ctx.check() == 0
     ctx.close()
+    # the same with one launch per step (step_kernel): at these sizes the collecting work-group reads hundreds of rows, in
+    # several blocks of 64, and with four groups a row's thermostats in two batches
+    it2 = integ(chains=1, hardwall=hardwall)
+    bind_groups(it2, g, ng)
+    ctx = HipContext(s, it2, mode="TGNH", precision="mixed", flags=RESIDENT)
+    assert ctx.resident_work_groups() >= 1
+    ctx.step(nsteps)
+    ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
+    print(f"{name}, resident step ({ctx.resident_work_groups()} work-groups per CU): pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= TOL and ev <= TOL and ctx.check() == 0
+    ctx.close()
 
 
 # ---------------------------------------------------------------------------
