@@ -1149,6 +1149,101 @@ def test_configs_4_and_5_particle_sharded_at_their_stated_size(name, nranks, nst
         c.close()
 
 
+@pytest.mark.parametrize("precision", ["mixed", "double"])
+@pytest.mark.parametrize("sysname,mode,drude_chains", [("mixed", "TGNH", True), ("groups6", "TGNH", True), ("mixed", "dualNH", False),
+                                                       ("polymer", "TGNH", True), ("water1000", "TGNH", True)])
+def test_collective_hook_path_against_the_oracle(sysname, mode, drude_chains, precision):
+    """DEFER_SCALE | RESIDENT_STEP with an all-reduce hook (the RCCL path of a sharded run; step_kernel cannot hold a
+    collective, so the handle steps with the deferred launches: rescale+kick+drift with the chain inside, kick+KE, row sum,
+    hook).  One rank (its all-reduce is the identity): 100 steps against the oracle, and the hook is really called once per
+    step."""
+    calls = [0]
+    s, g, ng, it, ctx = make(sysname, mode, precision, flags=RESIDENT, chains=1, drude_chains=drude_chains, hardwall=0.02)
+    ctx.set_allreduce(lambda t: calls.__setitem__(0, calls[0] + 1))
+    o = make_oracle(s, g, ng, mode, it)
+    pos_o, vel_o = oracle_run(o, s, 100, x0=ctx.sites())
+    ctx.timing(True)
+    ctx.step(100)
+    ctx.torch.cuda.synchronize()
+    ctx.timing(False)
+    from openmm_drudenose_amd import _lib
+    launches = {_lib.KERNEL_NAMES[k]: ctx.timing_read(k)[1] for k in _lib.KERNEL_NAMES}
+    ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
+    print(f"hook path {sysname} {mode} {precision}: pos {ep:.2e} vel {ev:.2e}, launches {launches}, hook calls {calls[0]}")
+    assert ep <= TOL and ev <= TOL and ctx.check() == 0
+    assert calls[0] >= 100 and launches["kick+KE"] == 100 and launches["resident step"] == 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("flags", [FLAG_DEFER_SCALE, RESIDENT])
+def test_collective_hook_path_two_shards_on_one_gpu(flags):
+    """The collective-hook path with two shards (two handles on this GPU, one stream), with the deferred launches and with
+    RESIDENT_STEP asked for on top (which a handle with a hook cannot use): the hook of the first shard only notes
+    its buffer, the hook of the second -- called after both passes are enqueued -- leaves the sum in both, as an all-reduce
+    would.  The trajectory is the unsharded one, the thermostats agree bit for bit."""
+    from openmm_drudenose_amd.system import shard_bounds
+    s, g, ng = synth.mixed(400, 30)
+    it = integ(chains=1, hardwall=0.02)
+    bind_groups(it, g, ng)
+    ref = HipContext(s, it, mode="TGNH", precision="double", flags=FLAG_DEFER_SCALE)
+    b = shard_bounds(s, 2)
+    parts, terms = [], []
+    for r in range(2):
+        loc, lg = s.slice_molecules(b[r], b[r + 1]), g[b[r]:b[r + 1]]
+        itr = integ(chains=1, hardwall=0.02)
+        bind_groups(itr, lg, ng)
+        parts.append(HipContext(loc, itr, mode="TGNH", precision="double", flags=flags))
+        terms.append(parts[-1].local_dof_terms())
+    total = terms[0] + terms[1]
+    ref.set_global_dof_terms(total)
+    first, known, quiet = [None], [None], [False]
+
+    def hook0(t):
+        if quiet[0]:
+            return
+        if known[0] is not None:
+            t.copy_(known[0])
+        first[0] = t
+
+    def hook1(t):
+        if quiet[0]:
+            return
+        if known[0] is not None:
+            t.copy_(known[0])
+            return
+        t.add_(first[0])           # rank order: shard 0 + shard 1 (t1 + t0 has the same bits)
+        first[0].copy_(t)
+    for ctx, hook in zip(parts, (hook0, hook1)):
+        ctx.set_global_dof_terms(total)
+        ctx.set_allreduce(hook)
+    torch = ref.torch
+    for step in range(60):
+        ref.step_begin(); ref.compute_forces(); ref.step_end()
+        if step == 0:
+            # the very first half step is a KE pass + hook + rescale inside ONE call per shard (an all-reduce would hold the
+            # stream until the other rank has contributed; two handles on one stream cannot): its total is formed up front
+            quiet[0] = True                  # (the query goes through the hook too: each shard's own sums are wanted here)
+            ke = [torch.from_numpy(c.compute_kinetic_energies()).to(c.dev) for c in parts]
+            quiet[0] = False
+            known[0] = ke[0] + ke[1]
+        for c in parts:
+            c.step_begin()
+        known[0] = None
+        for c in parts:
+            c.compute_forces()
+        for c in parts:
+            c.step_end()
+    pos = np.concatenate([c.getPositions() for c in parts])
+    vel = np.concatenate([c.getVelocities() for c in parts])
+    ep, ev = rel_err(pos, ref.getPositions()), rel_err(vel, ref.getVelocities())
+    print(f"hook path, two shards: pos {ep:.2e} vel {ev:.2e}")
+    assert ep < 1e-12 and ev < 1e-10
+    assert np.array_equal(parts[0].thermostat_state(1), parts[1].thermostat_state(1))
+    assert np.allclose(parts[0].thermostat_state(1), ref.thermostat_state(1), rtol=1e-9, atol=1e-13)
+    for c in parts + [ref]:
+        c.close()
+
+
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_config_sizes_parity(name):
     build, hardwall, nsteps = CONFIGS[name]
