@@ -51,7 +51,7 @@ def parse():
                         "defer with the whole step in ONE launch whose work-groups meet on the device (step_kernel; with the "
                         "RCCL hook it steps the defer way); plain = the reference's pass structure (what the OpenMM glue "
                         "runs); plain-resident = that structure with each thermostat half one step_kernel launch; "
-                        "auto = resident below 2 M slots per GPU, else defer (DESIGN.md)")
+                        "auto = resident below 3 M slots per GPU, else defer (DESIGN.md)")
     p.add_argument("--chains", type=int, default=1)
     p.add_argument("--drude-steps", type=int, default=20, help="drudeStepsPerRealStep (reference default 20)")
     p.add_argument("--hardwall", type=float, default=0.02, help="maxDrudeDistance nm (example/nacl_tg.py:22); 0 = off")
@@ -496,10 +496,10 @@ def main():
     from openmm_drudenose_amd import synth, _lib
     system, group, ngroups = synth.water_box(args.molecules)
     if args.variant == "auto":
-        # One launch per step (step_kernel) pays where a work-group walks a handful of tiles: +5-8 % below ~2 M slots per
-        # GPU, i.e. for the shards of a 4- or 8-GPU run.  At 5 M slots it is level with the three-launch structure
-        # (+-1 %, run-to-run spread 2.5 %; its first pass runs at the occupancy of the second), which is kept there.
-        args.variant = "resident" if system.num_particles / world < 2_000_000 else "defer"
+        # One launch per step (step_kernel) pays where a work-group walks a handful of tiles: +4-5 % from 2.5 M slots per
+        # GPU down, i.e. for the shards of a 2-, 4- or 8-GPU run (profiles/r02_scaling_ceiling.md).  At 5 M slots it is
+        # within 2 % of the three-launch structure (its first pass runs at the occupancy of the second), which is kept there.
+        args.variant = "resident" if system.num_particles / world < 3_000_000 else "defer"
 
     use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
     gsteps = args.graph_steps if use_graph else 0
