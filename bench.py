@@ -67,7 +67,7 @@ def parse():
     p.add_argument("--side-leg", action="store_true",
                    help="internal: this process is a child rank that measures the non-headline exchange of a sharded run "
                         "(--exchange names it) and prints its record; started by the ranks of the main run, see side_leg_in_children")
-    p.add_argument("--side-leg-timeout", type=float, default=420.0, help="seconds the main run gives its side-leg children")
+    p.add_argument("--side-leg-timeout", type=float, default=180.0, help="seconds the main run gives its side-leg children")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the extra single-precision / variant legs")
     return p.parse_args()
