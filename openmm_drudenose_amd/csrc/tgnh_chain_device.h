@@ -70,6 +70,13 @@ __device__ __forceinline__ double chain_exp(double x) {
     return p;
 }
 
+// a * b + c as exactly one v_fma_f64 on three vector registers
+__device__ __forceinline__ double fma3(const double a, const double b, const double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // exp(y) for the fast paths below: Taylor polynomials in Estrin form -- the serial chain there is bound by the
 // latency of dependent fp64 operations (~17 cycles each, measured), so depth counts: degree 7 at depth 3 for
 // |y| < 2^-6 (truncation y^8/8! < 2^-63), degree 12 at depth 4 for |y| < 2^-2 (y^13/13! < 2^-58).
@@ -538,9 +545,8 @@ __device__ __forceinline__ Chain1Regs chain1_load(const ChainArgs& a, const doub
 // and every work-group of a rescale launch waits for S (or 2S) of them in a row, so the loop carries only what it
 // must: with y = -dtc ed1 (the exponent of the KE factor) the next sub-step's y is y - (dtc^2/2) edd, so
 //     KE *= exp(y) ;  edd = (KE - NkT)/Q ;  y -= (dtc^2/2) edd
-// is the whole dependent chain (7 operations with the depth-3 polynomial; the direct transcription has 16), while
-// ed1 (advanced by two quarter-kicks at a time) and sum(y) are carried beside it: scale = exp(sum(y)/2),
-// eta -= sum(y)/2 and ed = ed1 - edd dtc/4 are formed once at the end.
+// is the whole recurrence, with sum(y) carried beside it: scale = exp(sum(y)/2), eta -= sum(y)/2, and etaDot1 = -y/dtc,
+// ed = ed1 - edd dtc/4 are formed once at the end.
 // Same mathematics; the roundings differ from the transcription by a few ulp (parity unchanged at 1e-11).
 __device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs& r, double* st_out, const bool write,
                                            double* s_scale, const int itg) {
@@ -572,29 +578,44 @@ __device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs&
         double scale = 1.0;
         if (live) edd = (ke - r.nkbt) * invQ0;                       // Cu :561-563, :605
         if (all_unit) {
+            // One wavefront issues one fp64 instruction per ~8 cycles whether or not it depends on the one before (a
+            // dependent one after 9.5: tools/micro/issue_probe.hip), so the loop is as FEW instructions as it gets -- 11,
+            // where the direct transcription of Cu :566-585 has 30 and an Estrin polynomial with etaDot carried along 16:
+            //   * exp(y) as the degree-6 Taylor polynomial in Horner form, 6 fmas (truncation y^7/7! < 2^-54 for
+            //     |y| < 2^-6; the largest |y| seen is checked once after the loop);
+            //   * edd = KE/Q + c0 with c0 = hold - NkT/Q: one fma (the etaMass > 0 guard is in the constants: (1/Q, -NkT/Q)
+            //     for a live thermostat, (0, etaDotDot) for an inert one);
+            //   * etaDot is not carried: y = -dtc etaDot1 throughout, so etaDot1 follows from y after the loop.
             const double ky = -0.5 * dtc * dtc;                      // y' = y - dtc * 2 * dtc/4 * edd
-            const double ed1_0 = fma(edd, dtc4, ed), ke_0 = ke, edd_0 = edd;
-            double ed1 = ed1_0, y = -dtc * ed1, sy = 0.0, ymax = 0.0;
-            // a single wavefront issues an instruction every 4+ cycles at best, so the loop is as short as it gets:
-            // the degree-7 polynomial without a range test; the largest |y| seen is checked once after the loop
+            const double c0 = fma(-r.nkbt, invQ0, hold);
+            const double ed1_0 = fma(edd, dtc4, ed), ke_0 = ke;
+            const double y_0 = -dtc * ed1_0;
+            double y = y_0, sy = 0.0;
+            unsigned ymax = 0u;                                      // largest |y| seen, as the high word of the double (monotone in |y|)
+            const double k720 = 1.0 / 720.0, k120 = 1.0 / 120.0, k24 = 1.0 / 24.0, k6 = 1.0 / 6.0;
             for (int iter = 0; iter < a.S; iter++) {
-                ymax = fmax(ymax, fabs(y));
-                ke *= chain_exp7(y);                                 // Cu :574, :621
+                ymax = max(ymax, (unsigned)__double2hiint(y) & 0x7fffffffu);     // two 32-bit operations (fmax on doubles: three fp64 ones)
+                double p = fma3(k720, y, k120);                      // (fma3: exactly one v_fma_f64 each -- left to itself the
+                p = fma3(p, y, k24);                                 //  compiler copies every constant into the accumulator of a
+                p = fma3(p, y, k6);                                  //  two-address fmac first: four more fp64-rate moves per sub-step)
+                p = fma(p, y, 0.5);
+                p = fma(p, y, 1.0);
+                p = fma(p, y, 1.0);
+                ke *= p;                                             // Cu :574, :621
                 sy += y;
-                edd = fma(ke - r.nkbt, invQ0, hold);                 // Cu :579-581, :629
-                y = fma(edd, ky, y);
-                ed1 = fma(edd, 2.0 * dtc4, ed1);                     // Cu :583-585 / :630-632 and the next :568-570
+                edd = fma3(ke, invQ0, c0);                           // Cu :579-581, :629
+                y = fma3(edd, ky, y);                                // Cu :583-585 / :630-632 and the next :568-570
             }
-            if (__builtin_expect(__any(ymax >= 0.015625), 0)) {      // out of the short polynomial's range: again, carefully
-                ke = ke_0; edd = edd_0; ed1 = ed1_0; y = -dtc * ed1; sy = 0.0;
+            if (__builtin_expect(__any(ymax >= 0x3f900000u), 0)) {   // some |y| >= 2^-6, out of the short polynomial's range: again, carefully
+                ke = ke_0; y = y_0; sy = 0.0;
                 for (int iter = 0; iter < a.S; iter++) {
                     ke *= fabs(y) < 0.25 ? chain_exp12(y) : chain_exp<false>(y);
                     sy += y;
-                    edd = fma(ke - r.nkbt, invQ0, hold);
+                    edd = fma(ke, invQ0, c0);
                     y = fma(edd, ky, y);
-                    ed1 = fma(edd, 2.0 * dtc4, ed1);
                 }
             }
+            const double ed1 = fma(y - y_0, -1.0 / dtc, ed1_0);      // etaDot1 advanced by the same kicks as y
             ed = fma(edd, -dtc4, ed1);                               // ed1 is one quarter-kick ahead
             scale = chain_exp<false>(0.5 * sy);                      // prod exp(-dtc/2 ed1)      (Cu :573, :620)
             et = fma(-0.5, sy, et);                                  // sum dtc/2 ed1            (Cu :575-577, :623)

@@ -977,10 +977,9 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
 // ---------------------------------------------------------------------------
 constexpr int CHAIN_LDS_DOUBLES = 2048;
 
-__global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
-    __shared__ double sred[BLOCK / 64][MAX_GROUPS + 2];
-    __shared__ double s_chain[CHAIN_LDS_DOUBLES];
-    __shared__ double s_ke[MAX_GROUPS + 2];
+// The part of chain_kernel before the chain itself: commit of a staged block, fixed-order sum of the partial rows, the
+// exchange's send / wait.  Shared with rowsum_kernel below.
+__device__ __forceinline__ void chain_prologue(const ChainArgs& a, double (*sred)[MAX_GROUPS + 2], double* s_chain, double* s_ke) {
     const ChainLayout& L = a.L;
     const int NT = L.NT, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double* st = a.st;
@@ -1053,6 +1052,27 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
         }
         __syncthreads();
     }
+}
+
+// The row sum alone (do_chain == 0: the chain itself runs inside the next rescale launch): its own small kernel.  A launch
+// starts with a cold instruction cache, and behind a pass that has streamed a gigabyte through the L2 and the Infinity Cache
+// its code comes from HBM: what a one-work-group launch costs is mostly the cache lines of code on its path.  Inside
+// chain_kernel (27 000 lines of ISA with every chain length inlined) that path jumped across the whole kernel.
+__global__ __launch_bounds__(BLOCK) void rowsum_kernel(const ChainArgs a) {
+    __shared__ double sred[BLOCK / 64][MAX_GROUPS + 2];
+    __shared__ double s_chain[2 * XCHG_MAX_WORLD * XCHG_NT_PAD > 64 ? 2 * XCHG_MAX_WORLD * XCHG_NT_PAD : 64];
+    __shared__ double s_ke[MAX_GROUPS + 2];
+    chain_prologue(a, sred, s_chain, s_ke);
+}
+
+__global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
+    __shared__ double sred[BLOCK / 64][MAX_GROUPS + 2];
+    __shared__ double s_chain[CHAIN_LDS_DOUBLES];
+    __shared__ double s_ke[MAX_GROUPS + 2];
+    const ChainLayout& L = a.L;
+    const int NT = L.NT, tid = threadIdx.x;
+    double* st = a.st;
+    chain_prologue(a, sred, s_chain, s_ke);
     if (!a.do_chain) return;
     if (!a.do_sum) __syncthreads();
     if (L.mode == TGNH_MODE_TGNH) {
@@ -1344,7 +1364,8 @@ int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds) {
 }
 
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
-    TGNH_LAUNCH(chain_kernel, dim3(1), dim3(BLOCK), 0, s, a);
+    if (!a.do_chain) TGNH_LAUNCH(rowsum_kernel, dim3(1), dim3(BLOCK), 0, s, a);
+    else TGNH_LAUNCH(chain_kernel, dim3(1), dim3(BLOCK), 0, s, a);
     return hipGetLastError();
 }
 
