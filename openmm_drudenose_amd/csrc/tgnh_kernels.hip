@@ -6,7 +6,7 @@
 // ends never cut a Drude pair or a molecule, loads it with one coalesced 16/32-byte
 // access per lane, keeps the velocity image in LDS so the Drude partner and the
 // molecular centre of mass are LDS look-ups, and leaves with fp64 per-group kinetic
-// energy sums reduced by 64-lane shuffles + one LDS hop.  Which of
+// energy sums reduced over the 64 lanes (wave_sum) + one LDS hop.  Which of
 // {rescale, half kick, drift, hard wall, KE} a launch performs is a compile-time mask,
 // so e.g. rescale+kick+drift touches each array once.  The Nose-Hoover chains run
 // on the device (chain_kernel, fp64), so a step has no host round trip.
@@ -45,10 +45,34 @@ __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
 __device__ __forceinline__ float abs_(float x) { return fabsf(x); }
 __device__ __forceinline__ double abs_(double x) { return fabs(x); }
 
+// Sum over the 64 lanes of a wavefront, the same value (and the same bits) in every lane.  Data-parallel-primitive moves
+// inside the vector ALU -- quads, then rows of 16 (row_shr 4, 8), then row broadcasts; the total lands in lane 63 and is read
+// back as a scalar -- instead of six __shfl_xor butterflies: a shuffle is two ds_bpermute_b32 through the LDS crossbar per
+// double, ~100 cycles of latency per step, and these sums (the kinetic-energy bins at the end of a pass, the rows collected by
+// work-group 0) sit on the path every work-group of a launch waits for.  The order of the additions is fixed.
+#ifndef TGNH_WAVE_SUM_DPP
+#define TGNH_WAVE_SUM_DPP 1
+#endif
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(const double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);   // lanes without a source: +0.0
+    return v + __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
+#if TGNH_WAVE_SUM_DPP
+    v = dpp_add<0xb1, 0xf>(v);       // quad_perm:[1,0,3,2]
+    v = dpp_add<0x4e, 0xf>(v);       // quad_perm:[2,3,0,1]: every lane of a quad holds the quad's sum
+    v = dpp_add<0x114, 0xf>(v);      // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);      // row_shr:8: lane 15 of every row holds the row's sum
+    v = dpp_add<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+#else
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+#endif
 }
 
 size_t tile_lds_bytes(int precision, int ops, bool hardwall, bool use_com) {
@@ -548,7 +572,7 @@ __device__ __forceinline__ size_t row_word(const int r, const int j) {
     return ((size_t)(r >> 6) * (2 * CHAIN_INLINE_SUM_NT) + j) * 64 + (r & 63);
 }
 
-// Work-group reduction of the fp64 KE bins: 64-lane butterflies, then one LDS hop; one row of `partials` per work-group.
+// Work-group reduction of the fp64 KE bins: 64-lane sums (wave_sum), then one LDS hop; one row of `partials` per work-group.
 // TAGGED: the row is read by another work-group of the SAME launch (step_kernel): every sum goes out as a cell of two
 // 8-byte words {32 bits of the double, tag} into a.rows -- data and "it is there" in one atomic store, as in the mailboxes.
 template <int PREC, int GB, bool TAGGED>
@@ -841,7 +865,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
     tile_load<PREC, STEP_OPS2, STEP_OPS1>(a, tile_of(tt_last), cur);
 
     // ---- meet: work-group 0 collects the rows.  Thread t owns rows t, t + 256, ...: it polls their cells until all
-    // carry this launch's tag and adds them in row order; then butterflies and one LDS hop, fixed order throughout.
+    // carry this launch's tag and adds them in row order; then 64-lane sums and one LDS hop, fixed order throughout.
     if (tid == 0) { s_gen = gen0; s_seq1 = seq0 + 1ull; }
     __syncthreads();
     const unsigned long long want = (unsigned long long)(s_gen + 1u);
@@ -990,7 +1014,7 @@ __device__ __forceinline__ void chain_prologue(const ChainArgs& a, double (*sred
     }
     if (a.do_sum) {
         // Fixed-order sum of the work-group partials: lane `tid` owns partials tid, tid+256, ...; every load of a
-        // lane is issued before the first add (one memory latency, not one per partial), then a 64-lane butterfly
+        // lane is issued before the first add (one memory latency, not one per partial), then a 64-lane sum
         // and a 4-wave LDS hop.  The order never depends on timing, so the sums are reproducible bit for bit.
         constexpr int PER = GRID_CAP / BLOCK;
         double acc[MAX_GROUPS + 2];

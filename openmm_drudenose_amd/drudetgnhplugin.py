@@ -535,21 +535,35 @@ class HipContext(_HandleQueries):
         if self.force_fn is not None:
             raise TgnhError(_lib.ERR_STATE, "capture_steps supports the harness force call-out only")
         torch.cuda.synchronize(self.dev)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            _check(self.lib.tgnh_run_harness(self.h, self.x0.data_ptr(), self.k_drude, self.k_tether, int(steps), self._stream()))
-        # the capture itself advanced the host-side counters once without running anything: take that back
-        _check(self.lib.tgnh_note_replayed_steps(self.h, 0))
+        # Consecutive streaming launches sweep the tiles in alternating directions, and a time step holds an odd number
+        # of them: the launches of `steps` steps captured now and the launches of the `steps` steps after them differ in
+        # that direction when `steps` is odd.  Two graphs are therefore captured back to back and replayed in turn, so a
+        # replayed run issues exactly the launches the eager loop would (bitwise the same trajectory, for any `steps`).
+        graphs = []
+        clock = None
+        for _ in range(2):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                _check(self.lib.tgnh_run_harness(self.h, self.x0.data_ptr(), self.k_drude, self.k_tether, int(steps), self._stream()))
+            graphs.append(g)
+            if clock is None:
+                clock = self.time()
+        # a capture advances the host-side clock without running anything: the first one stands for the first replay,
+        # the second one is taken back
+        self.set_time(*clock)
         self._captured_not_run = int(steps)
+        turn = [0]
 
         def replay():
-            g.replay()
+            graphs[turn[0] & 1].replay()
+            turn[0] += 1
             if self._captured_not_run:
                 self._captured_not_run = 0          # first replay is the run the capture already counted
             else:
                 _check(self.lib.tgnh_note_replayed_steps(self.h, int(steps)))
             self.ke_sum_valid = True
-        replay.graph = g
+        replay.graph = graphs[0]
+        replay.graphs = graphs
         return replay
 
     def status_flags(self):

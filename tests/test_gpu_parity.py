@@ -1366,8 +1366,13 @@ def test_full_size_properties():
     m = torch.where(w > 0, 1.0 / torch.where(w > 0, w, torch.ones_like(w)), torch.zeros_like(w))
     total = float((m[:, None] * ctx.velm[:, :3] ** 2).sum())
     assert ke.sum() == pytest.approx(total, rel=1e-10)
-    # (2) determinism: the reduction order is fixed
+    # (2) determinism: the reduction order is fixed.  Consecutive launches sweep the tiles in alternating directions, and the
+    #     order of the additions goes with the direction: the sums of the same sweep are the same bits, those of the opposite
+    #     one agree to rounding
+    ke_back = ctx.compute_kinetic_energies()
+    assert np.allclose(ke_back, ke, rtol=1e-14)
     assert np.array_equal(ctx.compute_kinetic_energies(), ke)
+    assert np.array_equal(ctx.compute_kinetic_energies(), ke_back)
     # (3) rescale: every bin is s^2 times its value before
     ctx.step_begin()
     ke0, sc = ctx.last_kinetic_energies(), ctx.last_scale_factors()
