@@ -552,7 +552,7 @@ __device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs&
                                            double* s_scale, const int itg) {
     const ChainLayout& L = a.L;
     const Chain1Map m = chain1_map(L, itg);
-    const double dtc = a.dt / a.S;                                   // Cu :440-443
+    const double dtc = a.dtc;                                        // dt / S (Cu :440-443), formed on the host
     const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
     double ke = r.ke;
     if (write) st_out[L.off_ke + itg] = ke;                          // KE before the chain (Cu :490)
@@ -615,7 +615,7 @@ __device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs&
                     y = fma(edd, ky, y);
                 }
             }
-            const double ed1 = fma(y - y_0, -1.0 / dtc, ed1_0);      // etaDot1 advanced by the same kicks as y
+            const double ed1 = fma(y - y_0, -a.inv_dtc, ed1_0);      // etaDot1 advanced by the same kicks as y
             ed = fma(edd, -dtc4, ed1);                               // ed1 is one quarter-kick ahead
             scale = chain_exp<false>(0.5 * sy);                      // prod exp(-dtc/2 ed1)      (Cu :573, :620)
             et = fma(-0.5, sy, et);                                  // sum dtc/2 ed1            (Cu :575-577, :623)

@@ -905,6 +905,7 @@ static ChainArgs chain_args(tgnh_handle h) {
     a.L = h->L; a.st = h->d_state; a.partials = h->d_partials; a.nparts = h->ke_parts;
     a.nbig = h->num_big;
     a.dt = h->d.step_size; a.S = h->d.drude_steps_per_real_step;
+    a.dtc = a.dt / a.S; a.inv_dtc = 1.0 / a.dtc;                               // Cu :440-443
     a.realkbT = h->realkbT; a.drudekbT = h->drudekbT;
     a.stage = h->d_stage;
     if (h->xchg_on) a.x = h->x;

@@ -139,6 +139,7 @@ struct ChainArgs {
     int chain_twice;           // DEFER_SCALE: second half of step n and first half of step n+1 back to back
     double dt;
     int S;
+    double dtc, inv_dtc;       // dt / S and its reciprocal, formed on the host (a division is a dozen fp64 instructions of the chain wavefront)
     double realkbT, drudekbT;
 };
 

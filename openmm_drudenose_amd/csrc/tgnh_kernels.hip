@@ -960,14 +960,15 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
         bool dead = false;                                 // an exchange has timed out, now or earlier (the latch)
         const double mine = xchg_wait_sum<true>(a.chain.x, NT, itg, s_x + 64, seq0 + 1ull, &dead);
         TRACE(8);
-        double kesum = 0.0;
-        for (int i = 0; i < NT; i++) kesum += __shfl(mine, i, 64);
         if (itg == 0) s_go = dead ? 0 : 1;
         if (!dead) {
             const bool write = leader;
             creg.ke = mine;
             if (write && itg < NT) a.st_out[L.off_ke_red + itg] = mine;
-            if (write && itg == 63) a.st_out[L.off_kesum] = 0.5 * kesum;              // Cu :493-497
+            if (write) {                                   // Cu :493-497 (work-group 0 only: the others go straight on to the chain)
+                const double kesum = wave_sum(itg < NT ? mine : 0.0);
+                if (itg == 63) a.st_out[L.off_kesum] = 0.5 * kesum;
+            }
             if (itg < NT) {
                 if (L.c1_quirk) chain1q_run(a.chain, creg, a.st_out, write, s_scale, itg);
                 else chain1_run(a.chain, creg, a.st_out, write, s_scale, itg);
