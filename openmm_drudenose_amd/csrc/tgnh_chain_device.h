@@ -548,12 +548,37 @@ __device__ __forceinline__ Chain1Regs chain1_load(const ChainArgs& a, const doub
 // is the whole recurrence, with sum(y) carried beside it: scale = exp(sum(y)/2), eta -= sum(y)/2, and etaDot1 = -y/dtc,
 // ed = ed1 - edd dtc/4 are formed once at the end.
 // Same mathematics; the roundings differ from the transcription by a few ulp (parity unchanged at 1e-11).
-__device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs& r, double* st_out, const bool write,
-                                           double* s_scale, const int itg) {
-    const ChainLayout& L = a.L;
-    const Chain1Map m = chain1_map(L, itg);
+// What of a one-link chain does not depend on the kinetic energy: formed BEFORE the wavefront waits for the sums (step_kernel:
+// the index map and the launch's constants are scalar loads of kernel arguments, 1/Q is a division, expfac an exp -- half a
+// microsecond of the chain wavefront's time that nobody then waits for).
+struct Chain1Pre {
+    Chain1Map m;
+    double dtc2, dtc4, invQ0, expfac, hold, ky, c0;
+    bool live, all_unit;
+};
+__device__ __forceinline__ Chain1Pre chain1_prepare(const ChainArgs& a, const Chain1Regs& r, const int itg) {
+    Chain1Pre p;
+    p.m = chain1_map(a.L, itg);
     const double dtc = a.dtc;                                        // dt / S (Cu :440-443), formed on the host
-    const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
+    p.dtc2 = dtc / 2.0; p.dtc4 = dtc / 4.0;
+    p.live = !p.m.guard || r.etaMass > 0;
+    p.invQ0 = p.live ? 1.0 / r.etaMass : 0.0;
+    p.expfac = p.m.used ? chain_exp<false>(-(dtc / 8.0) * r.etaDot1) : 1.0;   // Cu :615 ; real: exp(-0) = 1
+    p.all_unit = !__any(p.expfac != 1.0);
+    // etaMass > 0 guard without selects: edd = KE * invQ0 + c0, with (invQ0, c0) = (1/Q, -NkT/Q) for a live thermostat
+    // and (0, etaDotDot) for an inert one
+    p.hold = p.live ? 0.0 : r.etaDotDot;
+    p.ky = -0.5 * dtc * dtc;                                         // y' = y - dtc * 2 * dtc/4 * edd
+    p.c0 = fma(-r.nkbt, p.invQ0, p.hold);
+    return p;
+}
+
+__device__ __forceinline__ void chain1_finish(const ChainArgs& a, const Chain1Regs& r, const Chain1Pre& pre, double* st_out,
+                                              const bool write, double* s_scale, const int itg) {
+    const ChainLayout& L = a.L;
+    const Chain1Map& m = pre.m;
+    const double dtc = a.dtc, dtc2 = pre.dtc2, dtc4 = pre.dtc4, invQ0 = pre.invQ0, expfac = pre.expfac, hold = pre.hold;
+    const bool live = pre.live, all_unit = pre.all_unit;
     double ke = r.ke;
     if (write) st_out[L.off_ke + itg] = ke;                          // KE before the chain (Cu :490)
     if (!m.used) {                                                   // dualNH's middle slot: no thermostat, factor 1
@@ -564,16 +589,9 @@ __device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs&
         }
         return;
     }
-    const bool live = !m.guard || r.etaMass > 0;
-    const double invQ0 = live ? 1.0 / r.etaMass : 0.0;
-    const double expfac = chain_exp<false>(-dtc8 * r.etaDot1);       // Cu :615 ; real: exp(-0) = 1
-    const bool all_unit = !__any(expfac != 1.0);
     double ed = r.etaDot0, edd = r.etaDotDot, et = r.eta;
     const int reps = a.chain_twice ? 2 : 1;
     double total = 1.0;
-    // etaMass > 0 guard without selects: edd = (KE - NkT) * invQ0 + hold, with (invQ0, hold) = (1/Q, 0) for a live
-    // thermostat (the fma then rounds exactly like the product) and (0, etaDotDot) for an inert one
-    const double hold = live ? 0.0 : r.etaDotDot;
     for (int rep = 0; rep < reps; rep++) {
         double scale = 1.0;
         if (live) edd = (ke - r.nkbt) * invQ0;                       // Cu :561-563, :605
@@ -586,11 +604,11 @@ __device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs&
             //   * edd = KE/Q + c0 with c0 = hold - NkT/Q: one fma (the etaMass > 0 guard is in the constants: (1/Q, -NkT/Q)
             //     for a live thermostat, (0, etaDotDot) for an inert one);
             //   * etaDot is not carried: y = -dtc etaDot1 throughout, so etaDot1 follows from y after the loop.
-            const double ky = -0.5 * dtc * dtc;                      // y' = y - dtc * 2 * dtc/4 * edd
-            const double c0 = fma(-r.nkbt, invQ0, hold);
+            const double ky = pre.ky, c0 = pre.c0;
             const double ed1_0 = fma(edd, dtc4, ed), ke_0 = ke;
             const double y_0 = -dtc * ed1_0;
             double y = y_0, sy = 0.0;
+            TRACE(rep ? 16 : 14);
             unsigned ymax = 0u;                                      // largest |y| seen, as the high word of the double (monotone in |y|)
             const double k720 = 1.0 / 720.0, k120 = 1.0 / 120.0, k24 = 1.0 / 24.0, k6 = 1.0 / 6.0;
             for (int iter = 0; iter < a.S; iter++) {
@@ -606,6 +624,7 @@ __device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs&
                 edd = fma3(ke, invQ0, c0);                           // Cu :579-581, :629
                 y = fma3(edd, ky, y);                                // Cu :583-585 / :630-632 and the next :568-570
             }
+            TRACE(rep ? 11 : 16);
             if (__builtin_expect(__any(ymax >= 0x3f900000u), 0)) {   // some |y| >= 2^-6, out of the short polynomial's range: again, carefully
                 ke = ke_0; y = y_0; sy = 0.0;
                 for (int iter = 0; iter < a.S; iter++) {
@@ -637,6 +656,7 @@ __device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs&
         total *= scale;
     }
     if (s_scale) s_scale[itg] = total;
+    TRACE(12);
     if (!write) return;
     if (reps == 1) st_out[L.off_scale_b + itg] = 1.0;
     st_out[L.off_scale + itg] = total;
@@ -644,6 +664,11 @@ __device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs&
     st_out[L.off_etaDotDot + m.edd] = edd;
     st_out[L.off_etaDot + m.ed0] = ed;
     st_out[L.off_etaDot + m.ed1] = r.etaDot1;
+}
+
+__device__ __forceinline__ void chain1_run(const ChainArgs& a, const Chain1Regs& r, double* st_out, const bool write,
+                                           double* s_scale, const int itg) {
+    chain1_finish(a, r, chain1_prepare(a, r, itg), st_out, write, s_scale, itg);
 }
 
 // dualNH, one link, useDrudeNHChains = false (the C++ default).  Ref :139-154 then leaves numTempGroup = 1, so the

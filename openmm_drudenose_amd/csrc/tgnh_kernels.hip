@@ -19,6 +19,24 @@
 
 namespace tgnh {
 __device__ __forceinline__ double wave_sum(double v);
+#ifdef TGNH_TRACE
+// Phase timestamps of the tile kernel (tuning builds only: tools/trace_probe.py).  16 slots per work-group,
+// constant 100 MHz clock, written by thread 0.
+__device__ unsigned long long g_trace[GRID_CAP * 16];
+#define TRACE(slot) do { if (threadIdx.x == 0 && (slot) < 16) g_trace[blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+#define TRACE_WAIT() __builtin_amdgcn_s_waitcnt(0)
+extern "C" int tgnh_debug_read_trace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * GRID_CAP * 16);
+}
+extern "C" int tgnh_debug_clear_trace() {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_trace)) != hipSuccess) return 1;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * GRID_CAP * 16);
+}
+#else
+#define TRACE(slot) do {} while (0)
+#define TRACE_WAIT() do {} while (0)
+#endif
 }
 #include "tgnh_chain_device.h"
 
@@ -90,24 +108,6 @@ size_t tile_lds_bytes(int precision, int ops, bool hardwall, bool use_com) {
 // ---------------------------------------------------------------------------
 #ifndef TGNH_MINWAVES
 #define TGNH_MINWAVES 1
-#endif
-#ifdef TGNH_TRACE
-// Phase timestamps of the tile kernel (tuning builds only: tools/trace_probe.py).  16 slots per work-group,
-// constant 100 MHz clock, written by thread 0.
-__device__ unsigned long long g_trace[GRID_CAP * 16];
-#define TRACE(slot) do { if (threadIdx.x == 0 && (slot) < 16) g_trace[blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
-#define TRACE_WAIT() __builtin_amdgcn_s_waitcnt(0)
-extern "C" int tgnh_debug_read_trace(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * GRID_CAP * 16);
-}
-extern "C" int tgnh_debug_clear_trace() {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_trace)) != hipSuccess) return 1;
-    return (int)hipMemset(p, 0, sizeof(unsigned long long) * GRID_CAP * 16);
-}
-#else
-#define TRACE(slot) do {} while (0)
-#define TRACE_WAIT() do {} while (0)
 #endif
 
 // Raw register image of one tile's global loads.
@@ -863,6 +863,11 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
     Chain1Regs creg{};
     if (chain_wave && itg < NT) creg = chain1_load(a.chain, a.st_in, itg);
     tile_load<PREC, STEP_OPS2, STEP_OPS1>(a, tile_of(tt_last), cur);
+    // ... and what the chain can form without the sums (index map, constants, 1/Q, expfac): done while the others still work
+    // (single precision: its 16 registers there would cost the kernel its fourth work-group per compute unit)
+    constexpr bool EARLY_PRE = PREC != TGNH_PREC_SINGLE;
+    Chain1Pre cpre{};
+    if (EARLY_PRE && chain_wave && !L.c1_quirk) cpre = chain1_prepare(a.chain, creg, itg);
 
     // ---- meet: work-group 0 collects the rows.  Thread t owns rows t, t + 256, ...: it polls their cells until all
     // carry this launch's tag and adds them in row order; then 64-lane sums and one LDS hop, fixed order throughout.
@@ -971,7 +976,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
             }
             if (itg < NT) {
                 if (L.c1_quirk) chain1q_run(a.chain, creg, a.st_out, write, s_scale, itg);
-                else chain1_run(a.chain, creg, a.st_out, write, s_scale, itg);
+                else chain1_finish(a.chain, creg, EARLY_PRE ? cpre : chain1_prepare(a.chain, creg, itg), a.st_out, write, s_scale, itg);
             }
         }
     }
