@@ -15,11 +15,13 @@ def test_hot_kernels_keep_their_occupancy():
     assert out.returncode == 0, out.stderr[-2000:]
     rows = {}
     for line in out.stdout.splitlines():
-        m = re.match(r"(\S+<[^>]*>)\s+VGPR\s+(\d+)\s+AGPR\s+\d+\s+SGPR\s+\S+\s+scratch\s+(\d+)\s+occ\s+(\d+)", line)
+        m = re.match(r"(\S+<[^>]*>)\s+VGPR\s+(\d+)\s+AGPR\s+\d+\s+SGPR\s+\S+\s+scratch\s+(\d+)\s+occ\s+(\d+)\s+LDS\s+\d+\s+vspill\s+(\d+)\s+stackops\s+(\d+)", line)
         if m:
-            rows[m.group(1).replace(" ", "")] = (int(m.group(2)), int(m.group(3)), int(m.group(4)))
+            rows[m.group(1).replace(" ", "")] = (int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)), int(m.group(6)))
     assert len(rows) > 40, out.stdout[-2000:]
-    spills = {k: v for k, v in rows.items() if v[1] != 0}
+    # nothing may spill to memory: no vector-register spill, not one instruction that touches the stack (a few instantiations
+    # report a 36-byte scratch size with neither: a slot reserved for spilled scalar registers that all went to VGPR lanes)
+    spills = {k: v for k, v in rows.items() if v[3] != 0 or v[4] != 0 or v[1] > 64}
     assert not spills, spills
     for prec in (0, 1, 2):
         for gb in (1, 4, 8):
