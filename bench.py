@@ -19,6 +19,7 @@ torch.distributed.run before anything touches a GPU; under a launcher (WORLD_SIZ
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -91,7 +92,9 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
     if args.mode == "TGNH":
         for _ in range(ngroups):
             it.addTempGroup()
-        it._particleTempGroup = [int(x) for x in lgroup]
+        # (an array, not a list of five million Python ints: a list that long is traversed by every full pass of Python's
+        # cyclic garbage collector -- 17-22 ms each, see timed_run)
+        it._particleTempGroup = np.ascontiguousarray(lgroup, np.int32)
     dev = torch.cuda.current_device()
     kw = {}
     if world > 1 or os.environ.get("TGNH_FORCE_DIST") == "1":
@@ -213,6 +216,12 @@ def timed_run(ctx, steps, warmup, world, graph_steps=0, dom_kid=0):
     ctx.graph_used = replay is not None
     if replay is None:
         ctx.timing(2 + dom_kid)    # HIP events around the dominant kernel only: 2 records per step
+    # Python's cyclic garbage collector stays out of the timed region (as in `timeit`): a full pass landing inside it is a
+    # host-side stall of milliseconds to tens of milliseconds -- that was the leg the driver's round-1 record had at
+    # 1.95 ms/step against 0.42 ms of kernels (20 steps enqueued in 18 ms instead of 0.5; it comes and goes with where the
+    # collector's counters stand)
+    gc.collect()
+    gc.disable()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -228,6 +237,7 @@ def timed_run(ctx, steps, warmup, world, graph_steps=0, dom_kid=0):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=CDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

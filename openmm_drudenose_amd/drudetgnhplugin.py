@@ -107,6 +107,8 @@ class DrudeTGNHIntegrator:
     def addParticleTempGroup(self, tempGroup):
         if not 0 <= tempGroup < len(self._tempGroups):       # ASSERT_VALID_INDEX
             raise TgnhError(_lib.ERR_ARG, "Index out of range")
+        if not isinstance(self._particleTempGroup, list):    # (the defaults of _resolve_groups are an array)
+            self._particleTempGroup = [int(x) for x in self._particleTempGroup]
         self._particleTempGroup.append(int(tempGroup))
         return len(self._particleTempGroup) - 1
 
@@ -118,7 +120,7 @@ class DrudeTGNHIntegrator:
     def getParticleTempGroup(self, particle):
         if not 0 <= particle < len(self._particleTempGroup):
             raise TgnhError(_lib.ERR_ARG, "Index out of range")
-        return self._particleTempGroup[particle]
+        return int(self._particleTempGroup[particle])
 
     # --- stepping (DrudeTGNHIntegrator.cpp:182-194) ---
     def step(self, steps):
@@ -134,7 +136,8 @@ class DrudeTGNHIntegrator:
         if len(self._particleTempGroup) == 0:
             if len(self._tempGroups) == 0:
                 self._tempGroups.append(0)
-            self._particleTempGroup = [0] * num_particles
+            # (an array: a Python list of millions of ints is walked by every full pass of the garbage collector)
+            self._particleTempGroup = np.zeros(num_particles, np.int32)
         elif len(self._particleTempGroup) != num_particles:
             raise TgnhError(_lib.ERR_ARG, "Number of particles assigned with temperature groups does not match the number of system particles")
         return np.asarray(self._particleTempGroup, np.int32), len(self._tempGroups)

@@ -18,7 +18,7 @@ for name, build, hw in CFG:
         it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, 1, True, True)
         it.setMaxDrudeDistance(hw)
         for _ in range(ng): it.addTempGroup()
-        it._particleTempGroup = [int(x) for x in g]
+        it._particleTempGroup = g.astype("int32")
         ctx = HipContext(s, it, mode="TGNH", precision=prec, flags=FLAG_DEFER_SCALE | (FLAG_RESIDENT_STEP if var == "resident" else 0))
         ctx.step(50); torch.cuda.synchronize()
         n = 500
