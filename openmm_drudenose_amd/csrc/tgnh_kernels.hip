@@ -885,31 +885,41 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
         // RB rows of this thread per batch of loads (all of them for the resident grid of 768 when G = 1): once the last row
         // is there, one more round trip sees everything -- polled row after row, a thread whose first row came last paid
         // a round trip for each of the others behind it.  CH thermostats of a row per batch: the registers a batch takes
-        // (2 x CH x RB words) do not grow with the number of temperature groups.  (Tracking the rows already seen, so that
-        // later rounds poll the stragglers only, took 35 more VGPRs -- a work-group per compute unit -- and was dropped.)
+        // (2 x CH x RB words) do not grow with the number of temperature groups.  A row seen complete is not read again: a
+        // round waits for all of its loads together (~1 us with everything polled), and the round that finally sees the last
+        // row is a short one when it polls the stragglers only (last row -> all seen 1.6 instead of 2.3 us at 625 k slots).
         constexpr int RB = GB == 1 ? 3 : 1, CH = 3;
 #pragma unroll 1
         for (int r0 = tid; r0 < grid && ok; r0 += RB * TBLOCK) {
 #pragma unroll 1
             for (int b0 = 0; b0 < NT && ok; b0 += CH) {
                 unsigned long long w[RB][2 * CH];
+                bool have[RB];                              // a row seen complete is not read again: later rounds poll the stragglers only
+#pragma unroll
+                for (int k = 0; k < RB; k++) have[k] = r0 + k * TBLOCK >= grid;
                 unsigned n = 0;
                 for (;;) {
+#pragma unroll
+                    for (int k = 0; k < RB; k++) {
+                        if (!have[k]) {
+                            const unsigned long long* cell = a.rows + row_word(r0 + k * TBLOCK, 2 * b0);   // the lanes of a load read consecutive words
+#pragma unroll
+                            for (int b = 0; b < 2 * CH; b++) if (b0 + b / 2 < NT) w[k][b] = xchg_ld(cell + b * 64);
+                        }
+                    }
                     bool all = true;
 #pragma unroll
                     for (int k = 0; k < RB; k++) {
-                        const int r = r0 + k * TBLOCK;
-                        const unsigned long long* cell = a.rows + row_word(r, 2 * b0);   // the lanes of a load read consecutive words
+                        if (!have[k]) {
+                            bool row = true;
 #pragma unroll
-                        for (int b = 0; b < 2 * CH; b++) if (b0 + b / 2 < NT && r < grid) w[k][b] = xchg_ld(cell + b * 64);
+                            for (int b = 0; b < 2 * CH; b++) if (b0 + b / 2 < NT) row = row && (w[k][b] >> 32) == want;
+                            have[k] = row;
+                        }
+                        all = all && have[k];
                     }
-#pragma unroll
-                    for (int k = 0; k < RB; k++)
-#pragma unroll
-                        for (int b = 0; b < 2 * CH; b++) if (b0 + b / 2 < NT && r0 + k * TBLOCK < grid) all = all && (w[k][b] >> 32) == want;
                     if (all) break;
                     if (++n > XCHG_SPIN_LIMIT) { ok = false; break; }
-                    __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
                 for (int k = 0; k < RB; k++)                // row order: r0, r0 + 256, ...
