@@ -577,7 +577,7 @@ __device__ __forceinline__ void chain1_finish(const ChainArgs& a, const Chain1Re
                                               const bool write, double* s_scale, const int itg) {
     const ChainLayout& L = a.L;
     const Chain1Map& m = pre.m;
-    const double dtc = a.dtc, dtc2 = pre.dtc2, dtc4 = pre.dtc4, invQ0 = pre.invQ0, expfac = pre.expfac, hold = pre.hold;
+    const double dtc = a.dtc, dtc2 = pre.dtc2, dtc4 = pre.dtc4, invQ0 = pre.invQ0, expfac = pre.expfac;
     const bool live = pre.live, all_unit = pre.all_unit;
     double ke = r.ke;
     if (write) st_out[L.off_ke + itg] = ke;                          // KE before the chain (Cu :490)
