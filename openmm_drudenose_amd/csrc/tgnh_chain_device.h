@@ -454,7 +454,7 @@ __device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT,
     const unsigned long long* const box = x.mine + (SPREAD ? (size_t)(blockIdx.x % (unsigned)XCHG_REPLICAS) * XCHG_REPLICA_U64 : 0);
     // first batch: counter, latch and both parities of this lane's first cell, all in flight together
     const unsigned long long seq_raw = seq_expected ? seq_expected : __hip_atomic_load(x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned dead = __hip_atomic_load(x.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned dead = __hip_atomic_load(x.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long a0 = 0, a1 = 0, b0 = 0, b1 = 0;
     if (lane < cells) {
         const int r = lane / NT, i = lane - r * NT;
@@ -474,6 +474,9 @@ __device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT,
         unsigned n = 0;
         while (((w0 >> 32) != tag || (w1 >> 32) != tag) && dead == 0u && !timed_out) {
             if (++n > XCHG_SPIN_LIMIT) { timed_out = true; break; }
+            // the latch may be set while this wavefront is already polling (step_kernel's work-group 0 giving up on a row, another
+            // wavefront's time-out): looked at again every 64 polls, so that a failure ends every wait within microseconds
+            if ((n & 63u) == 0u) dead = __hip_atomic_load(x.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_s_sleep(4);
             w0 = xchg_ld(c); w1 = xchg_ld(c + 1);
         }
@@ -483,7 +486,7 @@ __device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT,
         atomicOr(x.status, 4u);
         __hip_atomic_store(x.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (failed) *failed = __any(timed_out) || dead != 0u;
+    if (failed) *failed = __any(timed_out || dead != 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -220,6 +220,36 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
     if (entries.empty()) entries.push_back(make_int2(0, 0));
     c->res_entries = entries;
     c->num_big = (int)c->big_first.size();
+
+    // Wave tiles for the kinetic-energy passes (wke_kernel, tgnh_internal.h): <= 64 consecutive slots, cut where the
+    // 512-slot tiles may be cut (never through a pair, never through a molecule when its COM is needed).  Not possible --
+    // a molecule or a pair longer than a wavefront -- leaves the list empty and the KE passes on the tile kernel.
+    c->wave_start.clear(); c->wmeta.clear(); c->com_steps = 0;
+    if (c->num_big == 0) {
+        std::vector<int> ws;
+        bool fits = true;
+        for (int st = 0; st < N && fits;) {
+            int end = std::min(st + WAVE_SLOTS, N);
+            while (end > st && end < N && forbid[end] > 0) end--;
+            if (end == st) { fits = false; break; }
+            ws.push_back(st);
+            st = end;
+        }
+        if (fits) {
+            ws.push_back(N);
+            int maxn = 1;
+            c->wmeta.assign(N, 0);
+            for (int i = 0; i < N; i++) {
+                int pos = 0, n = 1;
+                if (com) { const int r = c->resid[i]; pos = i - c->res_first[r]; n = c->res_count[r]; }
+                maxn = std::max(maxn, n);
+                const int off = partner[i] >= 0 ? partner[i] - i : 0;    // inside the wave tile: no cut goes through a pair
+                c->wmeta[i] = pack_wmeta((uint32_t)role[i], (uint32_t)c->group[i], off, (uint32_t)pos, (uint32_t)(n - 1));
+            }
+            while ((1 << c->com_steps) < maxn) c->com_steps++;
+            c->wave_start = ws;
+        }
+    }
     if (c->host_only) return TGNH_OK;
     // device copies
     HIP_OK(hipMalloc(&c->d_meta, sizeof(uint32_t) * std::max(N, 1)));
@@ -230,6 +260,12 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
     HIP_OK(hipMemcpy(c->d_tile_res, c->tile_res.data(), sizeof(int) * c->tile_res.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMalloc(&c->d_res_table, sizeof(int2) * c->res_entries.size()));
     HIP_OK(hipMemcpy(c->d_res_table, c->res_entries.data(), sizeof(int2) * c->res_entries.size(), hipMemcpyHostToDevice));
+    if (!c->wave_start.empty()) {
+        HIP_OK(hipMalloc(&c->d_wave_start, sizeof(int) * c->wave_start.size()));
+        HIP_OK(hipMemcpy(c->d_wave_start, c->wave_start.data(), sizeof(int) * c->wave_start.size(), hipMemcpyHostToDevice));
+        HIP_OK(hipMalloc(&c->d_wmeta, sizeof(uint32_t) * N));
+        HIP_OK(hipMemcpy(c->d_wmeta, c->wmeta.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
+    }
     if (c->num_big) {
         std::vector<int2> bt(c->num_big);
         for (int k = 0; k < c->num_big; k++) bt[k] = make_int2(c->big_count[k], c->big_first[k]);
@@ -408,6 +444,8 @@ static void free_device(tgnh_context* c) {
     if (c->d_tile_start) (void)hipFree(c->d_tile_start);
     if (c->d_tile_res) (void)hipFree(c->d_tile_res);
     if (c->d_res_table) (void)hipFree(c->d_res_table);
+    if (c->d_wave_start) (void)hipFree(c->d_wave_start);
+    if (c->d_wmeta) (void)hipFree(c->d_wmeta);
     if (c->d_big_table) (void)hipFree(c->d_big_table);
     if (c->d_big_com) (void)hipFree(c->d_big_com);
     if (c->d_partials) (void)hipFree(c->d_partials);
@@ -473,6 +511,10 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     }
     tgnh_status rc = build_topology(c, d);
     if (rc != TGNH_OK) { free_device(c); delete c; return rc; }
+    c->wave_ke = !c->wave_start.empty() && c->gb != 0;      // KE passes over wave tiles (register bins: G <= 8)
+#ifdef TGNH_TUNING
+    if (const char* e = getenv("TGNH_WAVE_KE")) c->wave_ke = c->wave_ke && e[0] != '0';
+#endif
     if ((d->flags & TGNH_FLAG_DEFER_SCALE) && d->mode == TGNH_MODE_TGNH && d->use_com_temp_group) {
         // s^2 KE is the exact post-rescale KE only if no molecule spans two temperature groups
         for (int r = 0; r < d->num_residues; r++) {
@@ -772,14 +814,17 @@ constexpr int64_t STATUS_POLL_EVERY = 64;
 // converge) is reported by tgnh_get_status_flags only: OpenMM's own constraint kernels do not throw either.
 static void note_status(tgnh_handle h, uint32_t flags) {
     if (h->failed_code) return;
-    if (flags & 4u) {
-        h->failed_code = TGNH_ERR_STATE;
-        h->failed = "mailbox exchange timed out (noticed at step " + std::to_string((long long)h->step_count) +
-                    "): a peer did not send its kinetic-energy sums; the run cannot continue";
-    } else if (flags & 8u) {
+    // bit 3 first: when step_kernel's work-group 0 gives up on a row it sets bit 3 and withholds the sums, and every other
+    // work-group then runs into its own time-out (bit 2) -- a residency problem, not a link fault
+    if (flags & 8u) {
         h->failed_code = TGNH_ERR_STATE;
         h->failed = "resident step (noticed at step " + std::to_string((long long)h->step_count) + "): the launch's work-groups did "
                     "not all become resident within the time limit (TGNH_FLAG_RESIDENT_STEP needs the device to itself)";
+        if (flags & 4u) h->failed += "; the waiting work-groups timed out in turn (status bits 2 and 3)";
+    } else if (flags & 4u) {
+        h->failed_code = TGNH_ERR_STATE;
+        h->failed = "mailbox exchange timed out (noticed at step " + std::to_string((long long)h->step_count) +
+                    "): a peer did not send its kinetic-energy sums; the run cannot continue";
     } else if ((flags & 1u) && h->d.mode == TGNH_MODE_DUALNH) {
         h->failed_code = TGNH_ERR_HARDWALL;
         h->failed = "Drude particle moved too far beyond hard wall constraint";        // Ref :311-312
@@ -822,6 +867,7 @@ static TileArgs tile_args(tgnh_handle h, const double* scale) {
     a.partials = h->d_partials; a.status = h->d_status;
     a.num_tiles = h->num_tiles; a.padded = h->d.padded_num_particles; a.num_groups = h->L.G;
     a.reverse = h->sweep_reverse;
+    a.wave_start = h->d_wave_start; a.wmeta = h->d_wmeta; a.num_wtiles = (int)h->wave_start.size() - 1; a.com_steps = h->com_steps;
     a.use_com = (h->d.mode == TGNH_MODE_TGNH && h->d.use_com_temp_group) ? 1 : 0;
     a.hardwall = h->d.max_drude_distance > 0 ? 1 : 0;                         // Ref :299, Cu :372
     a.dt = h->d.step_size; a.max_dist = h->d.max_drude_distance;
@@ -840,6 +886,23 @@ static int grid_for(tgnh_handle h, int ops, bool hardwall, size_t lds) {
     if (per_cu < 1) per_cu = 2;
     int g = std::min(std::min(h->num_tiles, per_cu * h->num_cus), GRID_CAP);
     if (g < 1) g = 1;
+    h->grid_cache[key] = g;
+    return g;
+}
+
+// wke_kernel: the resident work-groups, at most one per four wave tiles
+static int wave_grid_for(tgnh_handle h, int ops) {
+    const int nw = (int)h->wave_start.size() - 1, need = (nw + TBLOCK / 64 - 1) / (TBLOCK / 64);
+    if (h->grid_override > 0) return std::max(1, std::min(need, h->grid_override));
+    const int key = ops | (1 << 17);
+    auto it = h->grid_cache.find(key);
+    if (it != h->grid_cache.end()) return it->second;
+    int per_cu = wke_blocks_per_cu(h->d.precision, ops, h->gb);
+    if (per_cu < 1) per_cu = 2;
+#ifdef TGNH_TUNING
+    if (const char* e = getenv("TGNH_WKE_PER_CU")) { int v = atoi(e); if (v >= 1) per_cu = std::min(per_cu, v); }
+#endif
+    int g = std::max(1, std::min(std::min(need, per_cu * h->num_cus), GRID_CAP));
     h->grid_cache[key] = g;
     return g;
 }
@@ -876,7 +939,9 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
     if ((ops & (OP_POSDELTA | OP_MOVE)) && !h->pos_delta) return fail(TGNH_ERR_STATE, "posDelta buffer not bound");
     size_t lds = tile_lds_bytes(h->d.precision, ops, a.hardwall != 0, a.use_com != 0);
     if ((ops & OP_KE) && h->gb == 0) lds += sizeof(double) * (TBLOCK / 64) * h->L.G;   // per-wave group bins
-    const int grid = grid_for(h, ops, a.hardwall != 0, lds);
+    // the pure KE passes (KE, kick+KE, kick+KE unstored) run over the wave tiles when the topology has them
+    const bool wave = h->wave_ke && (ops & OP_KE) && !(ops & ~(OP_KE | OP_KICK | OP_NOSTORE));
+    const int grid = wave ? wave_grid_for(h, ops) : grid_for(h, ops, a.hardwall != 0, lds);
     if ((ops & OP_KE) && h->stage_pending && !inline_chain) {      // commit the staged thermostat block on the way
         a.commit_len = h->L.total; a.commit_src = h->d_stage; a.commit_dst = h->d_state;
         a.commit_skip = h->L.off_ke_red; a.commit_skip_n = h->L.NT;
@@ -893,7 +958,8 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
     }
     {
         Timed t(h, s, kid);
-        HIP_OK(launch_tile(h->d.precision, ops, h->gb, a, grid, lds, s));
+        if (wave) HIP_OK(launch_wke(h->d.precision, ops, h->gb, a, grid, s));
+        else HIP_OK(launch_tile(h->d.precision, ops, h->gb, a, grid, lds, s));
     }
     if (inline_chain) { h->chain_pending = false; h->sum_pending = false; h->xwait_pending = false; h->stage_pending = true; }   // d_stage now holds the advanced thermostat
     if (h->alternate_sweeps) h->sweep_reverse ^= 1;      // the next streaming launch starts where this one ends

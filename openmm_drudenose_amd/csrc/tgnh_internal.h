@@ -41,6 +41,19 @@ inline uint32_t pack_meta(uint32_t role, uint32_t group, int partner_off, uint32
     return role | (group << 2) | ((uint32_t)(partner_off + 1024) << 10) | (local_res << 21);
 }
 
+// ---- wave tiles: the kinetic-energy passes without LDS images and barriers ----------------------------------
+// A KE pass (KE, kick+KE) only needs, per slot, its Drude partner and its molecule's centre-of-mass velocity.  When every
+// molecule fits a wavefront the slot range is also cut into WAVE tiles of <= 64 consecutive slots (never through a pair or a
+// molecule), one per wavefront: the molecular sum of m v is a segmented sum over the lanes (log2(largest molecule) shuffle
+// steps), the partner a lane a few lanes away -- no LDS image, no __syncthreads, the four wavefronts of a work-group
+// independent of each other (wke_kernel).  Its per-slot word:
+//  bits  0..1  role            bits 2..9  temperature group       bits 10..16 partner offset + 64
+//  bits 17..22 position of the slot inside its molecule            bits 23..28 slots of the molecule - 1
+constexpr int WAVE_SLOTS = 64;
+inline uint32_t pack_wmeta(uint32_t role, uint32_t group, int partner_off, uint32_t pos_in_mol, uint32_t mol_slots_m1) {
+    return role | (group << 2) | ((uint32_t)(partner_off + 64) << 10) | (pos_in_mol << 17) | (mol_slots_m1 << 23);
+}
+
 // ---- operation mask of the tile kernel --------------------------------------
 enum : int {
     OP_SCALE = 1,      // A6  velocity rescale          (K integrateDrudeTGNHChain)
@@ -160,6 +173,11 @@ struct TileArgs {
     unsigned int* sync;        // step_kernel: [1] number of the last launch (its rows' tag); census: [2] work-groups checked in, [3] one gave up
     int census;                // step_kernel: residency check only (tgnh_create)
     unsigned long long* rows;  // step_kernel: [grid][NT] tagged cells (2 words each), uncached
+    // wave tiles (wke_kernel)
+    const int* wave_start;     // [num_wtiles + 1]
+    const uint32_t* wmeta;     // per-slot word of the wave tiles (pack_wmeta)
+    int num_wtiles;
+    int com_steps;             // ceil(log2(slots of the largest molecule)): steps of the segmented sum
     int num_tiles;
     int reverse;               // walk the tiles last-to-first: start where the previous launch ended (its lines are still in the Infinity Cache)
     int padded;
@@ -221,6 +239,8 @@ int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds);   // occupan
 hipError_t launch_step(int precision, int gb, int kind, const TileArgs& a, int grid, size_t lds, hipStream_t s);
 int step_blocks_per_cu(int precision, int gb, int kind, size_t lds);
 int step_kind_ops2(int kind);       // operations of the kind's second pass (its LDS needs)
+hipError_t launch_wke(int precision, int ops, int gb, const TileArgs& a, int grid, hipStream_t s);   // KE passes over wave tiles
+int wke_blocks_per_cu(int precision, int ops, int gb);
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s);
 hipError_t launch_big_com(int precision, const BigComArgs& a, hipStream_t s);
 hipError_t launch_force(int precision, const ForceArgs& a, hipStream_t s);
@@ -248,6 +268,12 @@ struct tgnh_context {
     int2* d_big_table = nullptr;
     void* d_big_com = nullptr;
     std::vector<uint32_t> meta;
+    std::vector<int> wave_start;      // wave tiles (empty: some molecule or pair does not fit a wavefront)
+    std::vector<uint32_t> wmeta;
+    int com_steps = 0;
+    int* d_wave_start = nullptr;
+    uint32_t* d_wmeta = nullptr;
+    bool wave_ke = false;             // the KE passes run over the wave tiles (wke_kernel)
     // dof bookkeeping (A2)
     std::vector<double> local_terms, global_terms;   // per thermostat, before CMM correction
     std::vector<double> dof, nkbt;

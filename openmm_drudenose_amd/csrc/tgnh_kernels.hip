@@ -760,6 +760,155 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
 }
 
 // ---------------------------------------------------------------------------
+// wke_kernel: the kinetic-energy passes (KE; kick+KE; kick+KE without a velocity store) over WAVE tiles.
+//
+// What such a pass needs per slot beyond its own velocity is its Drude partner (a few slots away) and its molecule's
+// centre-of-mass velocity.  tile_kernel gets both from an LDS image of a 512-slot tile: store, barrier, one thread per molecule
+// walks its slots (12 of 64 lanes busy, five dependent LDS reads each), barrier, look-ups, barrier -- and the work-group
+// issues its next loads only then: its wavefronts waited 68 % of their cycles (profiles/r02_pmc_sq.json) while the memory
+// system idled.  Here one wavefront owns <= 64 consecutive slots that never cut a molecule: sum(m v) of a molecule is a
+// segmented sum over its lanes (com_steps = log2 of the largest molecule shuffle steps, then one broadcast from the
+// molecule's first lane), the partner one shuffle away.  No LDS image, no __syncthreads until the final row: the wavefronts
+// are independent, each with its next tile's loads in flight while it works on the current one.
+// Reference: K :82-113 (COM), :119-133 (relative velocities), :138-200 (bins), :307-365 (the kick); Ref :439-460.
+// ---------------------------------------------------------------------------
+template <int PREC> struct WaveIn {
+    typename Prec<PREC>::mixed4 v;
+    uint32_t meta;
+    long long fx, fy, fz;
+    int ws, n;               // first slot, slots of the wave tile
+};
+
+template <int PREC, int OPS>
+__device__ __forceinline__ void wave_load(const TileArgs& a, const int w, const int lane, WaveIn<PREC>& in) {
+    typedef typename Prec<PREC>::mixed mixed;
+    typedef typename Prec<PREC>::mixed4 mixed4;
+    const mixed4* __restrict__ velm = reinterpret_cast<const mixed4*>(a.velm);
+    const int wi = a.reverse ? a.num_wtiles - 1 - w : w;
+    in.ws = __builtin_amdgcn_readfirstlane(a.wave_start[wi]);
+    in.n = __builtin_amdgcn_readfirstlane(a.wave_start[wi + 1]) - in.ws;
+    const int idx = in.ws + lane;
+    if (lane < in.n) {
+        in.v = velm[idx];
+        in.meta = a.wmeta[idx];
+        if (OPS & OP_KICK) {
+            in.fx = a.force[idx];
+            in.fy = a.force[idx + a.padded];
+            in.fz = a.force[idx + 2 * a.padded];
+        }
+    } else {
+        in.v = mk4((mixed)0, (mixed)0, (mixed)0, (mixed)0);      // massless, role normal, a molecule of its own: contributes nothing
+        in.meta = 64u << 10;
+        in.fx = in.fy = in.fz = 0;
+    }
+}
+
+template <int PREC, int OPS, int GB>
+__global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileArgs a) {
+    typedef typename Prec<PREC>::mixed mixed;
+    typedef typename Prec<PREC>::mixed4 mixed4;
+    constexpr bool DO_KICK = (OPS & OP_KICK) != 0, STORE = DO_KICK && !(OPS & OP_NOSTORE);
+    static_assert(GB > 0, "register bins only");
+    __shared__ double sred[TBLOCK / 64][GB + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int G = a.num_groups;
+    const bool use_com = a.use_com != 0;
+    const mixed fscale = (mixed)(0.5 * a.dt / 4294967296.0);     // Cu :295
+    mixed4* __restrict__ velm = reinterpret_cast<mixed4*>(a.velm);
+    if (a.commit_len > 0 && blockIdx.x == 0) {            // take over the thermostat block an in-kernel chain staged (as tile_kernel)
+        for (int i = tid; i < a.commit_len; i += TBLOCK)
+            if (i < a.commit_skip || i >= a.commit_skip + a.commit_skip_n) a.commit_dst[i] = a.commit_src[i];
+    }
+    double ke_g[GB], ke_com = 0.0, ke_drude = 0.0;
+#pragma unroll
+    for (int b = 0; b < GB; b++) ke_g[b] = 0.0;
+
+    // wave tile of wavefront wv in round r: (r gridDim.x + blockIdx.x) 4 + wv -- a work-group streams 4 consecutive wave tiles
+    const int stride = (int)gridDim.x * (TBLOCK / 64);
+    int w = (int)blockIdx.x * (TBLOCK / 64) + wv;
+    WaveIn<PREC> cur, nxt;
+    if (w < a.num_wtiles) wave_load<PREC, OPS>(a, w, lane, cur);
+    for (; w < a.num_wtiles; w += stride) {
+        const bool more = w + stride < a.num_wtiles;
+        if (more) wave_load<PREC, OPS>(a, w + stride, lane, nxt);        // in flight while this tile is worked on
+        mixed4 v = cur.v;
+        const uint32_t m = cur.meta;
+        const mixed mass = v.w != 0 ? rcp_(v.w) : (mixed)0;
+        if (DO_KICK && v.w != 0) {                                       // A7, per particle (tile_body)
+            const mixed c = fscale * v.w;
+            v.x += c * (mixed)cur.fx;
+            v.y += c * (mixed)cur.fy;
+            v.z += c * (mixed)cur.fz;
+        }
+        if (STORE && lane < cur.n) velm[cur.ws + lane] = v;
+        const uint32_t role = m & 3u, g = (m >> 2) & 255u;
+        const int off = (int)((m >> 10) & 127u) - 64;
+        const int j = (int)((m >> 17) & 63u), n1 = (int)((m >> 23) & 63u);
+        // ---- molecular centre-of-mass velocity (K :86-111): segmented sum of m v over the molecule's lanes
+        mixed cx = 0, cy = 0, cz = 0;
+        if (use_com) {
+            mixed px = v.x * mass, py = v.y * mass, pz = v.z * mass, pm = mass;
+            for (int st = 0, o = 1; st < a.com_steps; st++, o <<= 1) {     // after step k lane j holds the sum over j .. j + 2^k - 1
+                const mixed tx = __shfl_down(px, o, 64), ty = __shfl_down(py, o, 64), tz = __shfl_down(pz, o, 64), tm = __shfl_down(pm, o, 64);
+                const bool in = j + o <= n1;
+                px += in ? tx : (mixed)0; py += in ? ty : (mixed)0; pz += in ? tz : (mixed)0; pm += in ? tm : (mixed)0;
+            }
+            if (j == 0 && lane < cur.n) {                                // the molecule's first lane holds sum m v and M
+                const mixed wq = rcp_(pm);
+                px *= wq; py *= wq; pz *= wq;
+                ke_com += ((double)px * px + (double)py * py + (double)pz * pz) * (double)pm;     // M v_com^2 (K :154)
+            }
+            const int head = lane - j;
+            cx = __shfl(px, head, 64); cy = __shfl(py, head, 64); cz = __shfl(pz, head, 64);
+        }
+        // ---- partner (pairs are neighbours inside the wave tile; normal slots read themselves)
+        const int pl = lane + off;
+        const mixed ux = __shfl(v.x, pl, 64), uy = __shfl(v.y, pl, 64), uz = __shfl(v.z, pl, 64), um = __shfl(mass, pl, 64);
+        // ---- bins (K :138-200 ; Ref :439-460), the arithmetic of tile_body
+        double val = 0.0;
+        if (role == ROLE_NORMAL) {
+            if (v.w != 0) {
+                const double rx = v.x - cx, ry = v.y - cy, rz = v.z - cz;
+                val = (rx * rx + ry * ry + rz * rz) * (double)mass;
+            }
+        } else if (role == ROLE_DRUDE) {                                 // one lane per pair
+            const double r1x = v.x - cx, r1y = v.y - cy, r1z = v.z - cz;
+            const double r2x = ux - cx, r2y = uy - cy, r2z = uz - cz;
+            const double mass1 = mass, mass2 = um;
+            const double invTot = rcp_(mass1 + mass2);
+            const double m1f = invTot * mass1, m2f = invTot * mass2;
+            const double cmx = r1x * m1f + r2x * m2f, cmy = r1y * m1f + r2y * m2f, cmz = r1z * m1f + r2z * m2f;
+            const double rlx = r2x - r1x, rly = r2y - r1y, rlz = r2z - r1z;
+            val = (cmx * cmx + cmy * cmy + cmz * cmz) * (mass1 + mass2);
+            ke_drude += (rlx * rlx + rly * rly + rlz * rlz) * (mass1 * mass2 * invTot);
+        }
+#pragma unroll
+        for (int b = 0; b < GB; b++) ke_g[b] += (g == (uint32_t)b) ? val : 0.0;
+        if (more) cur = nxt;
+    }
+    // ---- one row of partial sums per work-group: 64-lane sums, one LDS hop, fixed order (ke_reduce's layout)
+#pragma unroll
+    for (int b = 0; b < GB; b++) ke_g[b] = wave_sum(ke_g[b]);
+    ke_com = wave_sum(ke_com);
+    ke_drude = wave_sum(ke_drude);
+    if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < GB; b++) sred[wv][b] = ke_g[b];
+        sred[wv][GB] = ke_com;
+        sred[wv][GB + 1] = ke_drude;
+    }
+    __syncthreads();
+    if (tid < GB + 2) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < TBLOCK / 64; k++) t += sred[k][tid];
+        double* row = a.partials + (size_t)blockIdx.x * (G + 2);
+        if (tid < GB) { if (tid < G) row[tid] = t; }
+        else row[G + (tid - GB)] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // step_kernel: a whole time step of the deferred pass structure in ONE launch (TGNH_FLAG_RESIDENT_STEP).
 //
 //   pass 1   half kick (unstored) + kinetic-energy sums over the work-group's tiles          (Cu :384-388, :474-488)
@@ -835,12 +984,19 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
     e.init(a, smem, s_scale, OpsOf<STEP_OPS2>::POS && a.hardwall != 0);
     auto tile_of = [&](int tt) { return a.reverse ? a.num_tiles - 1 - tt : tt; };
 
-    // this launch's number (the tag of its rows) and the exchange it will wait for: read before anything is handed in
+    // this launch's number (the tag of its rows), the exchange it will wait for and this wavefront's thermostat state: read
+    // before anything is handed in.  The thermostat block is advanced IN PLACE by work-group 0 once it holds every row, so
+    // every work-group must have READ the block before its row goes out: the loads are issued here, ahead of the first
+    // tile's (loads return in order), and their registers are pinned just before ke_reduce's tagged stores below, which the
+    // same wavefront issues -- the order is program order plus a data dependency, not a matter of latencies.
     unsigned gen0 = 0;
     unsigned long long seq0 = 0;
+    const ChainLayout& L = a.chain.L;
+    Chain1Regs creg{};
     if (chain_wave) {
         gen0 = __hip_atomic_load(&a.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         seq0 = __hip_atomic_load(a.chain.x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (itg < NT) creg = chain1_load(a.chain, a.st_in, itg);
     }
 
     // ---- pass 1
@@ -856,12 +1012,11 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
     }
     const int tt_last = tt;                                // stays in `cur`; its velocity image and COM table stay in LDS
     TRACE(1);
+    // the thermostat block has been read (its values are in registers) before this work-group's row is stored
+    if (chain_wave) asm volatile("" :: "v"(creg.eta), "v"(creg.etaDot0), "v"(creg.etaDot1), "v"(creg.etaDotDot), "v"(creg.etaMass), "v"(creg.nkbt) : "memory");
     ke_reduce<PREC, GB, true>(a, e, gen0 + 1u, s_x);
     TRACE(2);
-    // thermostat state of this wavefront's chain and the held tile's positions: issued now, needed after the meeting
-    const ChainLayout& L = a.chain.L;
-    Chain1Regs creg{};
-    if (chain_wave && itg < NT) creg = chain1_load(a.chain, a.st_in, itg);
+    // the held tile's positions: issued now, needed after the meeting
     tile_load<PREC, STEP_OPS2, STEP_OPS1>(a, tile_of(tt_last), cur);
     // ... and what the chain can form without the sums (index map, constants, 1/Q, expfac): done while the others still work
     // (single precision: its 16 registers there would cost the kernel its fourth work-group per compute unit)
@@ -933,7 +1088,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
             }
         }
         TRACE(10);
-        if (!ok) {                                         // a work-group never handed in its row: nobody goes on
+        if (!ok) {                                         // a work-group never handed in its row: nobody goes on (no send below)
             atomicOr(a.status, 8u);
             __hip_atomic_store(a.chain.x.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -948,7 +1103,10 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
                 if ((tid & 63) == 0) s_part[tid >> 6][b] = t;
             }
         }
-        __syncthreads();
+        // (the barrier of the hand-over doubles as the vote: one thread that gave up on a row stops the whole send -- incomplete
+        // sums under a valid tag would let every waiter, here and on the peer ranks, integrate with wrong scale factors; without
+        // the send they time out or see the latch, and nothing is stored)
+        const bool all_ok = __syncthreads_and(ok ? 1 : 0) != 0;
         TRACE(7);
         // the send (xchg_send's stores, tgnh_chain_device.h), straight from the four wavefronts' partial sums: every storing
         // thread adds them itself, in wavefront order -- no second hand-over through LDS, no second barrier on this path
@@ -956,7 +1114,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
         const unsigned long long seq = s_seq1, stag = (seq & 0xffffffffull) << 32;
         if (tid == 0) { a.sync[1] = s_gen + 1u; *x.seq = seq; }      // the next launch's rows carry the next tag
         const int tpp = TBLOCK / x.world;
-        if (tid < tpp * x.world) {
+        if (all_ok && tid < tpp * x.world) {
             unsigned long long* const base = my_peer + xchg_cell(x, (unsigned)(seq & 1ull), x.rank, 0, 0);
             for (int q = tid / x.world; q < NT * XCHG_REPLICAS; q += tpp) {
                 const int copy = q / NT, i = q - copy * NT;
@@ -1355,6 +1513,41 @@ hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int gr
     if (!fn) return hipErrorInvalidValue;
     TGNH_LAUNCH(fn, dim3(grid), dim3(TBLOCK), lds, s, a);
     return hipGetLastError();
+}
+
+template <int PREC, int OPS> static tile_fn_t wke_fn_gb(int gb) {
+    if (gb <= 1) return wke_kernel<PREC, OPS, 1>;
+    if (gb <= 4) return wke_kernel<PREC, OPS, 4>;
+    return wke_kernel<PREC, OPS, 8>;
+}
+template <int PREC> static tile_fn_t wke_fn_ops(int ops, int gb) {
+    switch (ops) {
+        case OP_KE: return wke_fn_gb<PREC, OP_KE>(gb);
+        case OP_KICK | OP_KE: return wke_fn_gb<PREC, OP_KICK | OP_KE>(gb);
+        case OP_KICK | OP_KE | OP_NOSTORE: return wke_fn_gb<PREC, OP_KICK | OP_KE | OP_NOSTORE>(gb);
+        default: return nullptr;
+    }
+}
+static tile_fn_t wke_fn(int precision, int ops, int gb) {
+    if (gb == 0) return nullptr;                          // more than 8 groups: LDS bins, the tile kernel
+    switch (precision) {
+        case TGNH_PREC_SINGLE: return wke_fn_ops<TGNH_PREC_SINGLE>(ops, gb);
+        case TGNH_PREC_MIXED: return wke_fn_ops<TGNH_PREC_MIXED>(ops, gb);
+        case TGNH_PREC_DOUBLE: return wke_fn_ops<TGNH_PREC_DOUBLE>(ops, gb);
+        default: return nullptr;
+    }
+}
+hipError_t launch_wke(int precision, int ops, int gb, const TileArgs& a, int grid, hipStream_t s) {
+    tile_fn_t fn = wke_fn(precision, ops, gb);
+    if (!fn) return hipErrorInvalidValue;
+    TGNH_LAUNCH(fn, dim3(grid), dim3(TBLOCK), 0, s, a);
+    return hipGetLastError();
+}
+int wke_blocks_per_cu(int precision, int ops, int gb) {
+    tile_fn_t fn = wke_fn(precision, ops, gb);
+    int n = 0;
+    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(fn), TBLOCK, 0) != hipSuccess) return 0;
+    return n;
 }
 
 typedef void (*step_fn_t)(const TileArgs);
