@@ -566,7 +566,7 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&c->h_status_seen), sizeof(uint32_t), hipHostMallocDefault));
         *c->h_status_seen = 0;
 
-        HIP_OK(hipMalloc(&c->d_scalar, sizeof(double)));
+        HIP_OK(hipMalloc(&c->d_scalar, sizeof(double) * (1 + PLAIN_KE_PARTS)));
         HIP_OK(hipMalloc(&c->d_sync, 4 * sizeof(unsigned int)));
         HIP_OK(hipMemset(c->d_sync, 0, 4 * sizeof(unsigned int)));
         if (c->d.flags & TGNH_FLAG_RESIDENT_STEP) {
@@ -1127,9 +1127,20 @@ static tgnh_status poll_status_async(tgnh_handle h, hipStream_t s) {
     return TGNH_OK;
 }
 
+// Consecutive streaming launches sweep the slots in alternating directions (a launch starts where the last one ended), and
+// the direction decides the order in which a wavefront adds its tiles' kinetic energies, i.e. the last bits of the sums.  A
+// time step holds an odd number of sweeps in every pass structure, so in an undisturbed run step k starts in direction k & 1;
+// that is made the rule: whatever was launched between two steps (queries, a flush), a step starts in the direction of
+// its number.  The trajectory's bits are then a function of the state and the step counter alone -- a handle restored from a
+// checkpoint (tgnh_set_time carries the counter) continues bit for bit, ranks of a sharded run sweep alike.
+static void start_of_step(tgnh_handle h) {
+    if (h->alternate_sweeps) h->sweep_reverse = (int)(h->step_count & 1);
+}
+
 extern "C" tgnh_status tgnh_step_begin(tgnh_handle h, void* stream) {
     tgnh_status rc = entry(h, true); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    start_of_step(h);
     if (h->end_pending) {
         if (resident_now(h)) return run_resident(h, s, 0);           // the last step's end half and this begin half: one launch
         rc = settle_end(h, s); if (rc) return rc;
@@ -1203,6 +1214,7 @@ extern "C" tgnh_status tgnh_step_begin_kick(tgnh_handle h, void* stream) {
     tgnh_status rc = entry(h, true); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     rc = settle_kick(h, s); if (rc) return rc;
+    start_of_step(h);
     if (!(h->d.flags & TGNH_FLAG_DEFER_SCALE) && resident_now(h)) return run_resident(h, s, 3);
     rc = first_half(h, s); if (rc) return rc;
     rc = run_tile(h, OP_SCALE | OP_KICK | OP_POSDELTA, KID_OTHER, s); if (rc) return rc;   // Cu :351-360
@@ -1416,7 +1428,10 @@ extern "C" tgnh_status tgnh_compute_kinetic_energies(tgnh_handle h, void* stream
     hipStream_t s = (hipStream_t)stream;
     rc = settle_kick(h, s); if (rc) return rc;
     rc = materialize_chain(h, s); if (rc) return rc;      // ke_red is about to be overwritten
-    rc = run_tile(h, OP_KE, KID_KE, s); if (rc) return rc;
+    const int dir = h->sweep_reverse;                      // a query leaves the sweep direction as it found it: the step's next
+    rc = run_tile(h, OP_KE, KID_KE, s);                    // KE launch then sums in the same order, to the same bits
+    h->sweep_reverse = dir;
+    if (rc) return rc;
     ChainArgs a = chain_args(h);
     a.do_sum = 1; a.do_chain = 0;
     if (h->xchg_on) { a.x_send = 1; a.x_wait = 1; }

@@ -244,8 +244,9 @@ int wke_blocks_per_cu(int precision, int ops, int gb);
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s);
 hipError_t launch_big_com(int precision, const BigComArgs& a, hipStream_t s);
 hipError_t launch_force(int precision, const ForceArgs& a, hipStream_t s);
+constexpr int PLAIN_KE_PARTS = 2048;         // work-group partials of the plain kinetic-energy query
 hipError_t launch_plain_ke(int precision, const void* velm, const long long* force, int n, int padded,
-                           double time_shift, double* out /*[1] device, zeroed inside*/, hipStream_t s);
+                           double time_shift, double* out /*[1 + PLAIN_KE_PARTS] device: out[0] = the result*/, hipStream_t s);
 size_t tile_lds_bytes(int precision, int ops, bool hardwall, bool use_com);
 
 }  // namespace tgnh
@@ -299,7 +300,7 @@ struct tgnh_context {
     uint32_t* h_status_seen = nullptr;   // pinned: where read-backs of the status word land (periodic, and at every query)
     int failed_code = 0;                 // sticky: a failure the device reported (note_status); every later entry returns it
     std::string failed;
-    double* d_scalar = nullptr;       // plain KE result
+    double* d_scalar = nullptr;       // plain KE: [0] the result, [1 ..] work-group partials
     // harness call-outs (tgnh_harness.hip)
     int4* d_cl_atoms = nullptr; double* d_cl_dist = nullptr; int num_clusters = 0;
     int4* d_vs_atoms = nullptr; double* d_vs_w = nullptr; int num_sites = 0;

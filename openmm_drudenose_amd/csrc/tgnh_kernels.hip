@@ -776,19 +776,31 @@ template <int PREC> struct WaveIn {
     typename Prec<PREC>::mixed4 v;
     uint32_t meta;
     long long fx, fy, fz;
-    int ws, n;               // first slot, slots of the wave tile
 };
 
+// one value from lane addr4 / 4 (ds_bpermute: the LDS crossbar, no LDS memory)
+__device__ __forceinline__ double bperm(const int addr4, const double x) {
+    const int lo = __builtin_amdgcn_ds_bpermute(addr4, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr4, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float bperm(const int addr4, const float x) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(addr4, __float_as_int(x)));
+}
+// (mixed)force: the fixed-point force as a floating-point number, rounded once.  For doubles hi 2^32 + lo in one fma --
+// both parts are exact, so this is the correctly rounded conversion (the bits of the cast) in 3 instructions instead of 4.
+__device__ __forceinline__ double force_as(const long long f, double) {
+    return fma((double)(int)(f >> 32), 4294967296.0, (double)(unsigned)f);
+}
+__device__ __forceinline__ float force_as(const long long f, float) { return (float)f; }
+
 template <int PREC, int OPS>
-__device__ __forceinline__ void wave_load(const TileArgs& a, const int w, const int lane, WaveIn<PREC>& in) {
+__device__ __forceinline__ void wave_load(const TileArgs& a, const int ws, const int n, const int lane, WaveIn<PREC>& in) {
     typedef typename Prec<PREC>::mixed mixed;
     typedef typename Prec<PREC>::mixed4 mixed4;
     const mixed4* __restrict__ velm = reinterpret_cast<const mixed4*>(a.velm);
-    const int wi = a.reverse ? a.num_wtiles - 1 - w : w;
-    in.ws = __builtin_amdgcn_readfirstlane(a.wave_start[wi]);
-    in.n = __builtin_amdgcn_readfirstlane(a.wave_start[wi + 1]) - in.ws;
-    const int idx = in.ws + lane;
-    if (lane < in.n) {
+    const int idx = ws + lane;
+    if (lane < n) {
         in.v = velm[idx];
         in.meta = a.wmeta[idx];
         if (OPS & OP_KICK) {
@@ -810,7 +822,9 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileAr
     constexpr bool DO_KICK = (OPS & OP_KICK) != 0, STORE = DO_KICK && !(OPS & OP_NOSTORE);
     static_assert(GB > 0, "register bins only");
     __shared__ double sred[TBLOCK / 64][GB + 2];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane4 = lane << 2;
     const int G = a.num_groups;
     const bool use_com = a.use_com != 0;
     const mixed fscale = (mixed)(0.5 * a.dt / 4294967296.0);     // Cu :295
@@ -823,68 +837,82 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileAr
 #pragma unroll
     for (int b = 0; b < GB; b++) ke_g[b] = 0.0;
 
-    // wave tile of wavefront wv in round r: (r gridDim.x + blockIdx.x) 4 + wv -- a work-group streams 4 consecutive wave tiles
-    const int stride = (int)gridDim.x * (TBLOCK / 64);
-    int w = (int)blockIdx.x * (TBLOCK / 64) + wv;
-    WaveIn<PREC> cur, nxt;
-    if (w < a.num_wtiles) wave_load<PREC, OPS>(a, w, lane, cur);
-    for (; w < a.num_wtiles; w += stride) {
-        const bool more = w + stride < a.num_wtiles;
-        if (more) wave_load<PREC, OPS>(a, w + stride, lane, nxt);        // in flight while this tile is worked on
+    // Wave tile of wavefront wv in round r: (r gridDim.x + blockIdx.x) 4 + wv -- a work-group streams 4 consecutive wave
+    // tiles.  Everything about WHICH tile is wavefront-uniform (scalar registers, scalar loads): the bounds of the tile after
+    // next are fetched while this one is worked on, so the vector loads of the next tile never wait for an index.
+    const int nw = a.num_wtiles, stride = (int)gridDim.x * (TBLOCK / 64);
+    auto bounds = [&](const int ww, int& ws, int& n) {
+        const int wi = a.reverse ? nw - 1 - ww : ww;
+        ws = a.wave_start[wi];
+        n = a.wave_start[wi + 1] - ws;
+    };
+    auto work = [&](const WaveIn<PREC>& cur, const int ws, const int n) {
         mixed4 v = cur.v;
         const uint32_t m = cur.meta;
-        const mixed mass = v.w != 0 ? rcp_(v.w) : (mixed)0;
-        if (DO_KICK && v.w != 0) {                                       // A7, per particle (tile_body)
+        const bool massive = v.w != 0;
+        const mixed mass = massive ? rcp_(v.w) : (mixed)0;
+        if (DO_KICK) {                                                   // A7, per particle (tile_body); w = 0: c = 0, v unchanged
             const mixed c = fscale * v.w;
-            v.x += c * (mixed)cur.fx;
-            v.y += c * (mixed)cur.fy;
-            v.z += c * (mixed)cur.fz;
+            v.x += c * force_as(cur.fx, (mixed)0);
+            v.y += c * force_as(cur.fy, (mixed)0);
+            v.z += c * force_as(cur.fz, (mixed)0);
         }
-        if (STORE && lane < cur.n) velm[cur.ws + lane] = v;
+        if (STORE && lane < n) velm[ws + lane] = v;
         const uint32_t role = m & 3u, g = (m >> 2) & 255u;
-        const int off = (int)((m >> 10) & 127u) - 64;
-        const int j = (int)((m >> 17) & 63u), n1 = (int)((m >> 23) & 63u);
         // ---- molecular centre-of-mass velocity (K :86-111): segmented sum of m v over the molecule's lanes
         mixed cx = 0, cy = 0, cz = 0;
         if (use_com) {
+            const int j = (int)((m >> 17) & 63u), room = (int)((m >> 23) & 63u) - j;      // lanes of the molecule after this one
             mixed px = v.x * mass, py = v.y * mass, pz = v.z * mass, pm = mass;
             for (int st = 0, o = 1; st < a.com_steps; st++, o <<= 1) {     // after step k lane j holds the sum over j .. j + 2^k - 1
-                const mixed tx = __shfl_down(px, o, 64), ty = __shfl_down(py, o, 64), tz = __shfl_down(pz, o, 64), tm = __shfl_down(pm, o, 64);
-                const bool in = j + o <= n1;
-                px += in ? tx : (mixed)0; py += in ? ty : (mixed)0; pz += in ? tz : (mixed)0; pm += in ? tm : (mixed)0;
+                const int src = lane4 + 4 * o;
+                const mixed tx = bperm(src, px), ty = bperm(src, py), tz = bperm(src, pz), tm = bperm(src, pm);
+                if (o <= room) { px += tx; py += ty; pz += tz; pm += tm; }
             }
-            if (j == 0 && lane < cur.n) {                                // the molecule's first lane holds sum m v and M
+            if (j == 0 && lane < n) {                                    // the molecule's first lane holds sum m v and M
                 const mixed wq = rcp_(pm);
                 px *= wq; py *= wq; pz *= wq;
                 ke_com += ((double)px * px + (double)py * py + (double)pz * pz) * (double)pm;     // M v_com^2 (K :154)
             }
-            const int head = lane - j;
-            cx = __shfl(px, head, 64); cy = __shfl(py, head, 64); cz = __shfl(pz, head, 64);
+            const int head = lane4 - 4 * j;
+            cx = bperm(head, px); cy = bperm(head, py); cz = bperm(head, pz);
         }
-        // ---- partner (pairs are neighbours inside the wave tile; normal slots read themselves)
-        const int pl = lane + off;
-        const mixed ux = __shfl(v.x, pl, 64), uy = __shfl(v.y, pl, 64), uz = __shfl(v.z, pl, 64), um = __shfl(mass, pl, 64);
-        // ---- bins (K :138-200 ; Ref :439-460), the arithmetic of tile_body
-        double val = 0.0;
-        if (role == ROLE_NORMAL) {
-            if (v.w != 0) {
-                const double rx = v.x - cx, ry = v.y - cy, rz = v.z - cz;
-                val = (rx * rx + ry * ry + rz * rz) * (double)mass;
-            }
-        } else if (role == ROLE_DRUDE) {                                 // one lane per pair
-            const double r1x = v.x - cx, r1y = v.y - cy, r1z = v.z - cz;
-            const double r2x = ux - cx, r2y = uy - cy, r2z = uz - cz;
+        // ---- bins (K :138-200 ; Ref :439-460).  Every massive slot adds m |v - v_com|^2 to its group's bin; a pair's
+        // two terms together are (m1 + m2) |cm - v_com|^2 + mu |v2 - v1|^2 (K :171-186 splits them that way), so the Drude
+        // lane moves the second part, mu |v2 - v1|^2, from the group's bin to the Drude bin: the partner is needed for that
+        // difference only
+        const double rx = v.x - cx, ry = v.y - cy, rz = v.z - cz;          // (in the velocities' own precision, as tile_body)
+        double val = (rx * rx + ry * ry + rz * rz) * (double)mass;       // 0 for massless sites
+        const int pl = lane4 + 4 * ((int)((m >> 10) & 127u) - 64);
+        const mixed ux = bperm(pl, v.x), uy = bperm(pl, v.y), uz = bperm(pl, v.z), um = bperm(pl, mass);
+        if (role == ROLE_DRUDE) {                                        // one lane per pair
+            const double dx = ux - v.x, dy = uy - v.y, dz = uz - v.z;
             const double mass1 = mass, mass2 = um;
-            const double invTot = rcp_(mass1 + mass2);
-            const double m1f = invTot * mass1, m2f = invTot * mass2;
-            const double cmx = r1x * m1f + r2x * m2f, cmy = r1y * m1f + r2y * m2f, cmz = r1z * m1f + r2z * m2f;
-            const double rlx = r2x - r1x, rly = r2y - r1y, rlz = r2z - r1z;
-            val = (cmx * cmx + cmy * cmy + cmz * cmz) * (mass1 + mass2);
-            ke_drude += (rlx * rlx + rly * rly + rlz * rlz) * (mass1 * mass2 * invTot);
+            const double mu = mass1 * mass2 * rcp_(mass1 + mass2);       // reduced mass = 1/invReducedMass (K :178, :185)
+            const double d = (dx * dx + dy * dy + dz * dz) * mu;
+            ke_drude += d;
+            val -= d;
         }
 #pragma unroll
         for (int b = 0; b < GB; b++) ke_g[b] += (g == (uint32_t)b) ? val : 0.0;
-        if (more) cur = nxt;
+    };
+
+    int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (TBLOCK / 64) + wv);
+    int ws0 = 0, n0 = 0, ws1 = 0, n1 = 0, ws2 = 0, n2 = 0;
+    WaveIn<PREC> A, B;
+    if (w < nw) { bounds(w, ws0, n0); wave_load<PREC, OPS>(a, ws0, n0, lane, A); }
+    if (w + stride < nw) bounds(w + stride, ws1, n1);
+    while (w < nw) {                                                     // two tiles per trip: the register images alternate
+        if (w + 2 * stride < nw) bounds(w + 2 * stride, ws2, n2);
+        if (w + stride < nw) wave_load<PREC, OPS>(a, ws1, n1, lane, B);  // in flight while A is worked on
+        work(A, ws0, n0);
+        w += stride;
+        if (w >= nw) break;
+        if (w + 2 * stride < nw) bounds(w + 2 * stride, ws0, n0);
+        if (w + stride < nw) wave_load<PREC, OPS>(a, ws2, n2, lane, A);
+        work(B, ws1, n1);
+        w += stride;
+        ws1 = ws0; n1 = n0; ws0 = ws2; n0 = n2;                          // (scalar moves)
     }
     // ---- one row of partial sums per work-group: 64-lane sums, one LDS hop, fixed order (ke_reduce's layout)
 #pragma unroll
@@ -1461,7 +1489,22 @@ __global__ __launch_bounds__(BLOCK) void plain_ke_kernel(const void* velm_, cons
     if (threadIdx.x == 0) {
         double s = 0.0;
         for (int w = 0; w < BLOCK / 64; w++) s += sred[w];
-        atomicAdd(out, 0.5 * s);
+        out[1 + blockIdx.x] = s;                 // one partial per work-group: no atomics, the order of the sum is fixed below
+    }
+}
+
+// out[0] = 1/2 sum of the nparts work-group partials out[1 ..], in index order: the query is reproducible bit for bit
+__global__ __launch_bounds__(BLOCK) void plain_ke_sum_kernel(double* out, int nparts) {
+    __shared__ double sred[BLOCK / 64];
+    double e = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += BLOCK) e += out[1 + i];
+    e = wave_sum(e);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < BLOCK / 64; w++) s += sred[w];
+        out[0] = 0.5 * s;
     }
 }
 
@@ -1617,10 +1660,8 @@ hipError_t launch_force(int precision, const ForceArgs& a, hipStream_t s) {
 
 hipError_t launch_plain_ke(int precision, const void* velm, const long long* force, int n, int padded,
                            double time_shift, double* out, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), s);
-    if (e != hipSuccess) return e;
     int grid = (n + BLOCK - 1) / BLOCK;
-    if (grid > 2048) grid = 2048;
+    if (grid > PLAIN_KE_PARTS) grid = PLAIN_KE_PARTS;
     if (grid < 1) grid = 1;
     switch (precision) {
         case TGNH_PREC_SINGLE: TGNH_LAUNCH((plain_ke_kernel<TGNH_PREC_SINGLE>), dim3(grid), dim3(BLOCK), 0, s, velm, force, n, padded, time_shift, out); break;
@@ -1628,6 +1669,9 @@ hipError_t launch_plain_ke(int precision, const void* velm, const long long* for
         case TGNH_PREC_DOUBLE: TGNH_LAUNCH((plain_ke_kernel<TGNH_PREC_DOUBLE>), dim3(grid), dim3(BLOCK), 0, s, velm, force, n, padded, time_shift, out); break;
         default: return hipErrorInvalidValue;
     }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    TGNH_LAUNCH(plain_ke_sum_kernel, dim3(1), dim3(BLOCK), 0, s, out, grid);
     return hipGetLastError();
 }
 

@@ -106,38 +106,82 @@ def test_torch_force_field_equals_the_oracles():
     ctx.close()
 
 
-@pytest.mark.parametrize("mode,samples,tol", [("TGNH", 10000, 0.02), ("dualNH", 4000, 0.03)])
-def test_reference_testWater_on_the_hip_path(mode, samples, tol):
-    s = wts.build()
+TRAJECTORIES = 4
+
+
+def water_trajectory(seed, mode, precision, samples):
+    """One run of the reference's protocol (test :166-185) on the HIP path.  seed 0 is the test's own lattice; the others
+    have every molecule displaced rigidly by N(0, 1e-4 nm) (tests/water_decomposition.py): independent trajectories of the
+    same chaotic system.  Returns the per-step temperatures by the test's formula and, for TGNH mode, the two terms of the
+    thermostats' own equation of motion averaged over the sampling window (water_decomposition.py: what the oracle shows
+    the offset to consist of)."""
+    from water_decomposition import jittered_system
+    s = jittered_system(seed)
     it = wts.integrator()
-    ctx = HipContext(s, it, mode=mode, precision="mixed")
+    ctx = HipContext(s, it, mode=mode, precision=precision)
     ctx.force_fn = TorchWaterForce(ctx, wts.BOX)
     ctx.state_hook = remove_cm_motion
     ctx.compute_forces()
     target, num_dof = wts.expected_temperature(s)
-    assert abs(ctx.dof()[0].sum() - num_dof) < 1e-9           # dof_g - red_g + COM + Drude = the test's numDof
+    dof, nkt = ctx.dof()
+    assert abs(dof.sum() - num_dof) < 1e-9                # dof_g - red_g + COM + Drude = the test's numDof
     it.step(5000)                                                    # test :176
     kes = np.zeros(samples)
+    nt, C = len(nkt), it.getNumNHChains()
+    l0 = np.arange(nt) * (C + 1)                                     # TGNH layout: etaDot rows [thermostat][C + 1] (Cu :94-97)
+    prod = np.zeros(nt)
+    ed_start = ctx.thermostat_state(1)[l0] if mode == "TGNH" else None
     for i in range(samples):                                         # test :180-185
         it.step(1)
         kes[i] = it.computeKineticEnergy() if mode == "TGNH" else reference_platform_kinetic_energy(ctx, it.getStepSize())
-    temps = kes / (0.5 * num_dof * synth.KB)
-    temperature = temps.mean()
-    # The reference asserts with ASSERT_USUALLY_EQUAL_TOL: one finite, chaotic trajectory, whose mean moves with every
-    # change of rounding in the code (this test has read +0.6 %, +1.4 % and +2.1 % for three versions of the kernels
-    # that agree with the oracle to 1e-11 over 100 steps).  Its standard error, from 20 block means (blocks of >= 200
-    # steps = 0.1 ps, the thermostat's coupling time), is ~0.5-0.8 %; the reference's tolerance is widened by twice that.
-    blocks = temps[:samples // 20 * 20].reshape(20, -1).mean(1)
-    stderr = blocks.std(ddof=1) / np.sqrt(20)
-    print(f"testWater on the HIP path ({mode}): <T> = {temperature:.2f} K, expected {target:.2f} K ({temperature / target - 1:+.2%}, "
-          f"standard error {stderr / target:.2%})")
-    assert stderr < 0.015 * target
-    assert abs(temperature - target) <= tol * target + 2.0 * stderr  # ASSERT_USUALLY_EQUAL_TOL
+        if mode == "TGNH":
+            ed = ctx.thermostat_state(1)
+            prod += ed[l0] * ed[l0 + 1]
+    identity = None
+    if mode == "TGNH":
+        q0 = ctx.thermostat_state(3)[np.arange(nt) * C]
+        ed_end = ctx.thermostat_state(1)[l0]
+        # <KE_b - N_b kT_b> = Q_b0 <etaDot_b0 etaDot_b1> + Q_b0 [etaDot_b0(end) - etaDot_b0(start)] / T     (Cu :566-592)
+        excess = q0 * prod / samples + q0 * (ed_end - ed_start) / (samples * it.getStepSize())
+        identity = float(excess.sum() / nkt.sum())                   # the offset those terms predict for the test's temperature
     assert ctx.check() == 0
     pos = ctx.getPositions()
     r = np.linalg.norm(pos[s.pair_drude] - pos[s.pair_parent], axis=1)
     assert r.max() <= 0.05 * (1 + 1e-6)
     ctx.close()
+    return kes / (0.5 * num_dof * synth.KB), target, identity
+
+
+# platforms/cuda/tests/CMakeLists.txt:22-24 runs the CUDA platform's testWater three times -- single, mixed, double
+# (TestCudaDrudeTGNHIntegrator.cpp:256-258), 10 000 samples, 2 %; the Reference platform's own test is double, 4 000
+# samples, 3 % (dualNH mode is that platform's algorithm: run here at every precision of the HIP path as well).
+@pytest.mark.parametrize("precision", ["single", "mixed", "double"])
+@pytest.mark.parametrize("mode,samples,tol", [("TGNH", 10000, 0.02), ("dualNH", 4000, 0.03)])
+def test_reference_testWater_on_the_hip_path(mode, samples, tol, precision):
+    """The reference's gate, unwidened, on the mean over TRAJECTORIES independent trajectories.
+
+    One trajectory's mean has a standard error of 0.4-0.5 % (chaotic system, 5 ps of sampling) and the protocol itself sits
+    +1.40 +- 0.14 % (TGNH) / +1.30 +- 0.19 % (dualNH) above the expected temperature on the oracle
+    (tests/golden/water_decomposition.json, DESIGN.md section 6: while the 0.6 nm lattice condenses, the ten-link chains hold
+    the molecular-COM kinetic energy above N kT by Q <etaDot_0 etaDot_1>, a term of the thermostat's own equation of motion;
+    gone with one-link chains or ten times the equilibration) -- so a single run is a coin with a 10 % chance of leaving a
+    2 % gate.  Pooled, the standard error is what the statistics of the reference's ASSERT_USUALLY_EQUAL_TOL assume."""
+    runs = [water_trajectory(seed, mode, precision, samples) for seed in range(TRAJECTORIES)]
+    target = runs[0][1]
+    temps = np.concatenate([r[0] for r in runs])
+    temperature = temps.mean()
+    blocks = np.concatenate([r[0][:samples // 20 * 20].reshape(20, -1).mean(1) for r in runs])   # blocks of >= 0.1 ps
+    stderr = blocks.std(ddof=1) / np.sqrt(len(blocks))
+    per_run = ", ".join(f"{r[0].mean() / target - 1:+.2%}" for r in runs)
+    print(f"testWater on the HIP path ({mode}, {precision}): <T> = {temperature:.2f} K over {TRAJECTORIES} trajectories ({per_run}), "
+          f"expected {target:.2f} K ({temperature / target - 1:+.2%}, standard error {stderr / target:.2%})")
+    assert stderr <= 0.003 * target
+    assert abs(temperature - target) <= tol * target                 # ASSERT_USUALLY_EQUAL_TOL(expectedTemp, ..., 0.02 / 0.03)
+    if mode == "TGNH":
+        # ... and the offset is the one the thermostats' equation of motion accounts for, on this path as on the oracle
+        predicted = float(np.mean([r[2] for r in runs]))
+        print(f"    offset predicted by Q0 <etaDot0 etaDot1> + Q0 d<etaDot0>/dt: {predicted:+.2%}")
+        assert abs((temperature / target - 1) - predicted) <= 0.003
 
 
 def test_reference_testSinglePair_on_the_hip_path():
