@@ -249,6 +249,13 @@ tgnh_status tgnh_harness_virtual_sites(tgnh_handle h, void* stream);
 tgnh_status tgnh_run_harness_constrained(tgnh_handle h, const void* x0, double k_drude, double k_tether,
                                          double tol, int nsteps, void* stream);
 
+/* The call-outs of the reference's own testWater (platforms/reference/tests/TestReferenceDrudeTGNHIntegrator.cpp:111-166),
+ * harness only: its force field -- NonbondedForce with reaction field, cutoff `cutoff` in a cubic box of edge `box`, +
+ * DrudeForce + the M site's force spread over O, H1, H2, for slots laid out O, D, H1, H2, M per molecule -- written into
+ * `force_out` in OpenMM's fixed-point layout, and OpenMM's CMMotionRemover on the bound velocities. */
+tgnh_status tgnh_harness_water_force(tgnh_handle h, double box, double cutoff, void* force_out, void* stream);
+tgnh_status tgnh_harness_remove_cm_motion(tgnh_handle h, void* stream);
+
 /* Per-kernel launch statistics gathered with HIP events on `stream` while
  * enabled (bench.py's live roofline).  kernel: 0 scale+kick+drift, 1 kick+KE,
  * 2 rescale, 3 KE, 4 chain, 5 harness force, 6 other, 7 resident step.  on = 1: every kernel; on = 2 + k: kernel k only

@@ -87,6 +87,8 @@ SIGNATURES = {
     "tgnh_harness_set_virtual_sites": (C.c_int, [C.c_void_p, C.c_int, c_i32p, c_f64p]),
     "tgnh_harness_virtual_sites": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_run_harness_constrained": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]),
+    "tgnh_harness_water_force": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "tgnh_harness_remove_cm_motion": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "tgnh_timing_read": (C.c_int, [C.c_void_p, C.c_int, c_f64p, C.POINTER(C.c_int64)]),
     "tgnh_algorithmic_bytes": (C.c_int, [C.c_void_p, C.c_int, c_f64p]),

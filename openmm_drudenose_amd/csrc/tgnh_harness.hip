@@ -172,6 +172,123 @@ static hipError_t launch_sites(int precision, const SiteArgs& a, hipStream_t s) 
 
 }  // namespace tgnh
 
+namespace tgnh {
+// ---------------------------------------------------------------------------
+// The force field and the CMMotionRemover of the reference's testWater (TestReferenceDrudeTGNHIntegrator.cpp:111-166), as
+// harness call-outs: what that test asks OpenMM for (reaction-field NonbondedForce, cutoff 1 nm, + DrudeForce + the M site's
+// force spread over O, H1, H2; oracle/water_ff.c is the CPU statement the tests check this against).  SWM4-NDP layout
+// O, D, H1, H2, M per molecule.  One work-group per molecule: its threads walk the other molecules (25 site pairs each, all
+// fp64), the 15 force components of the molecule's own sites are reduced over the work-group in a fixed order.
+// ---------------------------------------------------------------------------
+struct WaterArgs {
+    const void* posq; const void* posq_corr;
+    long long* force;
+    int n_mol, padded;
+    double box, cutoff;
+};
+
+__device__ __forceinline__ double h_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int PREC>
+__global__ __launch_bounds__(BLOCK) void water_force_kernel(const WaterArgs a) {
+    typedef typename HPrec<PREC>::real4 real4;
+    const real4* __restrict__ posq = reinterpret_cast<const real4*>(a.posq);
+    const float4* __restrict__ pcorr = reinterpret_cast<const float4*>(a.posq_corr);
+    __shared__ double sred[BLOCK / 64][15];
+    const double Q[5] = {1.71636, -1.71636, 0.55733, 0.55733, -1.11466};
+    const double W[3] = {0.786646558, 0.106676721, 0.106676721};
+    const double ONE_4PI_EPS0 = 138.935456, eps_rf = 78.3;
+    const double krf = (1.0 / (a.cutoff * a.cutoff * a.cutoff)) * (eps_rf - 1.0) / (2.0 * eps_rf + 1.0);
+    const double sigma = 0.318395, eps = 0.21094 * 4.184, kd = 100000.0 * 4.184;
+    const double c2 = a.cutoff * a.cutoff, inv_box = 1.0 / a.box;
+    auto site = [&](int idx, double* x) {
+        const real4 p = posq[idx];
+        x[0] = p.x; x[1] = p.y; x[2] = p.z;
+        if (PREC == TGNH_PREC_MIXED) { const float4 c = pcorr[idx]; x[0] += (double)c.x; x[1] += (double)c.y; x[2] += (double)c.z; }
+    };
+    const int ma = blockIdx.x;
+    double xa[5][3], f[5][3];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { site(5 * ma + i, xa[i]); f[i][0] = f[i][1] = f[i][2] = 0.0; }
+    for (int mb = threadIdx.x; mb < a.n_mol; mb += BLOCK) {
+        if (mb == ma) continue;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            double xb[3];
+            site(5 * mb + j, xb);
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                double d[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { d[k] = xa[i][k] - xb[k]; d[k] -= a.box * floor(d[k] * inv_box + 0.5); }
+                const double r2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+                if (r2 >= c2) continue;
+                const double r = sqrt(r2), inv_r = 1.0 / r;
+                double dEdr = ONE_4PI_EPS0 * Q[i] * Q[j] * (-inv_r * inv_r + 2.0 * krf * r);
+                if (i == 0 && j == 0) {
+                    const double s2 = sigma * sigma / r2, s6 = s2 * s2 * s2;
+                    dEdr += 4.0 * eps * (-12.0 * s6 * s6 + 6.0 * s6) * inv_r;
+                }
+                const double c = -dEdr * inv_r;
+                f[i][0] += c * d[0]; f[i][1] += c * d[1]; f[i][2] += c * d[2];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double t = h_wave_sum(f[i][k]);
+            if (lane == 0) sred[wv][3 * i + k] = t;
+        }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        double fs[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) { fs[i] = 0.0; for (int w = 0; w < BLOCK / 64; w++) fs[i] += sred[w][3 * i + k]; }
+        const double sp = kd * (xa[1][k] - xa[0][k]);                   // Drude spring (DrudeForce, test :148)
+        fs[1] -= sp; fs[0] += sp;
+        fs[0] += W[0] * fs[4]; fs[2] += W[1] * fs[4]; fs[3] += W[2] * fs[4]; fs[4] = 0.0;   // the M site's force (test :147)
+#pragma unroll
+        for (int i = 0; i < 5; i++) a.force[(size_t)k * a.padded + 5 * ma + i] = (long long)(fs[i] * 4294967296.0);
+    }
+}
+
+// OpenMM's CMMotionRemover (frequency 1): subtract the centre-of-mass velocity from every massive particle.  One work-group.
+template <int PREC>
+__global__ __launch_bounds__(BLOCK) void cmm_kernel(void* velm_, int n) {
+    typedef typename HPrec<PREC>::mixed mixed;
+    typedef typename HPrec<PREC>::mixed4 mixed4;
+    mixed4* __restrict__ velm = reinterpret_cast<mixed4*>(velm_);
+    __shared__ double sred[BLOCK / 64][4];
+    __shared__ double vcm[3];
+    double px = 0, py = 0, pz = 0, pm = 0;
+    for (int i = threadIdx.x; i < n; i += BLOCK) {
+        const mixed4 v = velm[i];
+        if (v.w != 0) { const double m = 1.0 / (double)v.w; px += m * v.x; py += m * v.y; pz += m * v.z; pm += m; }
+    }
+    px = h_wave_sum(px); py = h_wave_sum(py); pz = h_wave_sum(pz); pm = h_wave_sum(pm);
+    if ((threadIdx.x & 63) == 0) { double* r = sred[threadIdx.x >> 6]; r[0] = px; r[1] = py; r[2] = pz; r[3] = pm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[4] = {0, 0, 0, 0};
+        for (int w = 0; w < BLOCK / 64; w++) for (int k = 0; k < 4; k++) t[k] += sred[w][k];
+        for (int k = 0; k < 3; k++) vcm[k] = t[k] / t[3];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += BLOCK) {
+        mixed4 v = velm[i];
+        if (v.w != 0) { v.x -= (mixed)vcm[0]; v.y -= (mixed)vcm[1]; v.z -= (mixed)vcm[2]; velm[i] = v; }
+    }
+}
+
+}  // namespace tgnh
 using namespace tgnh;
 
 #define H_FAIL(code, msg) do { tgnh_set_error(msg); return code; } while (0)
@@ -271,5 +388,39 @@ extern "C" tgnh_status tgnh_run_harness_constrained(tgnh_handle h, const void* x
         }
         rc = tgnh_step_end_thermo(h, stream); if (rc) return rc;                         // Cu :394-406
     }
+    return TGNH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// testWater call-outs (water_force_kernel, cmm_kernel above)
+// ---------------------------------------------------------------------------
+extern "C" tgnh_status tgnh_harness_water_force(tgnh_handle h, double box, double cutoff, void* force_out, void* stream) {
+    tgnh_status rc = harness_ready(h); if (rc) return rc;
+    if (!force_out || !(box > 0) || !(cutoff > 0)) H_FAIL(TGNH_ERR_ARG, "bad box / cutoff / force buffer");
+    if (h->d.num_particles % 5) H_FAIL(TGNH_ERR_ARG, "the testWater force field needs O, D, H1, H2, M per molecule");
+    H_HIP(hipSetDevice(h->device));
+    WaterArgs a{};
+    a.posq = h->posq; a.posq_corr = h->posq_corr; a.force = reinterpret_cast<long long*>(force_out);
+    a.n_mol = h->d.num_particles / 5; a.padded = h->d.padded_num_particles; a.box = box; a.cutoff = cutoff;
+    hipStream_t s = (hipStream_t)stream;
+    switch (h->d.precision) {
+        case TGNH_PREC_SINGLE: TGNH_LAUNCH((water_force_kernel<TGNH_PREC_SINGLE>), dim3(a.n_mol), dim3(BLOCK), 0, s, a); break;
+        case TGNH_PREC_MIXED: TGNH_LAUNCH((water_force_kernel<TGNH_PREC_MIXED>), dim3(a.n_mol), dim3(BLOCK), 0, s, a); break;
+        default: TGNH_LAUNCH((water_force_kernel<TGNH_PREC_DOUBLE>), dim3(a.n_mol), dim3(BLOCK), 0, s, a); break;
+    }
+    H_HIP(hipGetLastError());
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_harness_remove_cm_motion(tgnh_handle h, void* stream) {
+    tgnh_status rc = harness_ready(h); if (rc) return rc;
+    H_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    switch (h->d.precision) {
+        case TGNH_PREC_SINGLE: TGNH_LAUNCH((cmm_kernel<TGNH_PREC_SINGLE>), dim3(1), dim3(BLOCK), 0, s, h->velm, h->d.num_particles); break;
+        case TGNH_PREC_MIXED: TGNH_LAUNCH((cmm_kernel<TGNH_PREC_MIXED>), dim3(1), dim3(BLOCK), 0, s, h->velm, h->d.num_particles); break;
+        default: TGNH_LAUNCH((cmm_kernel<TGNH_PREC_DOUBLE>), dim3(1), dim3(BLOCK), 0, s, h->velm, h->d.num_particles); break;
+    }
+    H_HIP(hipGetLastError());
     return TGNH_OK;
 }

@@ -224,30 +224,30 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
     // Wave tiles for the kinetic-energy passes (wke_kernel, tgnh_internal.h): <= 64 consecutive slots, cut where the
     // 512-slot tiles may be cut (never through a pair, never through a molecule when its COM is needed).  Not possible --
     // a molecule or a pair longer than a wavefront -- leaves the list empty and the KE passes on the tile kernel.
-    c->wave_start.clear(); c->wmeta.clear(); c->com_steps = 0;
+    c->wave_tile.clear(); c->wmeta.clear(); c->num_wtiles = 0;
     if (c->num_big == 0) {
-        std::vector<int> ws;
+        std::vector<int2> wt;
         bool fits = true;
         for (int st = 0; st < N && fits;) {
             int end = std::min(st + WAVE_SLOTS, N);
             while (end > st && end < N && forbid[end] > 0) end--;
             if (end == st) { fits = false; break; }
-            ws.push_back(st);
+            int maxn = 1;
+            if (com) for (int i = st; i < end; i++) maxn = std::max(maxn, c->res_count[c->resid[i]]);
+            wt.push_back(make_int2(st, maxn));
             st = end;
         }
         if (fits) {
-            ws.push_back(N);
-            int maxn = 1;
+            c->num_wtiles = (int)wt.size();
+            wt.push_back(make_int2(N, 0));
             c->wmeta.assign(N, 0);
             for (int i = 0; i < N; i++) {
                 int pos = 0, n = 1;
                 if (com) { const int r = c->resid[i]; pos = i - c->res_first[r]; n = c->res_count[r]; }
-                maxn = std::max(maxn, n);
                 const int off = partner[i] >= 0 ? partner[i] - i : 0;    // inside the wave tile: no cut goes through a pair
                 c->wmeta[i] = pack_wmeta((uint32_t)role[i], (uint32_t)c->group[i], off, (uint32_t)pos, (uint32_t)(n - 1));
             }
-            while ((1 << c->com_steps) < maxn) c->com_steps++;
-            c->wave_start = ws;
+            c->wave_tile = wt;
         }
     }
     if (c->host_only) return TGNH_OK;
@@ -260,9 +260,9 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
     HIP_OK(hipMemcpy(c->d_tile_res, c->tile_res.data(), sizeof(int) * c->tile_res.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMalloc(&c->d_res_table, sizeof(int2) * c->res_entries.size()));
     HIP_OK(hipMemcpy(c->d_res_table, c->res_entries.data(), sizeof(int2) * c->res_entries.size(), hipMemcpyHostToDevice));
-    if (!c->wave_start.empty()) {
-        HIP_OK(hipMalloc(&c->d_wave_start, sizeof(int) * c->wave_start.size()));
-        HIP_OK(hipMemcpy(c->d_wave_start, c->wave_start.data(), sizeof(int) * c->wave_start.size(), hipMemcpyHostToDevice));
+    if (!c->wave_tile.empty()) {
+        HIP_OK(hipMalloc(&c->d_wave_tile, sizeof(int2) * c->wave_tile.size()));
+        HIP_OK(hipMemcpy(c->d_wave_tile, c->wave_tile.data(), sizeof(int2) * c->wave_tile.size(), hipMemcpyHostToDevice));
         HIP_OK(hipMalloc(&c->d_wmeta, sizeof(uint32_t) * N));
         HIP_OK(hipMemcpy(c->d_wmeta, c->wmeta.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
     }
@@ -444,7 +444,7 @@ static void free_device(tgnh_context* c) {
     if (c->d_tile_start) (void)hipFree(c->d_tile_start);
     if (c->d_tile_res) (void)hipFree(c->d_tile_res);
     if (c->d_res_table) (void)hipFree(c->d_res_table);
-    if (c->d_wave_start) (void)hipFree(c->d_wave_start);
+    if (c->d_wave_tile) (void)hipFree(c->d_wave_tile);
     if (c->d_wmeta) (void)hipFree(c->d_wmeta);
     if (c->d_big_table) (void)hipFree(c->d_big_table);
     if (c->d_big_com) (void)hipFree(c->d_big_com);
@@ -511,7 +511,7 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     }
     tgnh_status rc = build_topology(c, d);
     if (rc != TGNH_OK) { free_device(c); delete c; return rc; }
-    c->wave_ke = !c->wave_start.empty() && c->gb != 0;      // KE passes over wave tiles (register bins: G <= 8)
+    c->wave_ke = !c->wave_tile.empty() && c->gb != 0;       // KE passes over wave tiles (register bins: G <= 8)
 #ifdef TGNH_TUNING
     if (const char* e = getenv("TGNH_WAVE_KE")) c->wave_ke = c->wave_ke && e[0] != '0';
 #endif
@@ -867,7 +867,7 @@ static TileArgs tile_args(tgnh_handle h, const double* scale) {
     a.partials = h->d_partials; a.status = h->d_status;
     a.num_tiles = h->num_tiles; a.padded = h->d.padded_num_particles; a.num_groups = h->L.G;
     a.reverse = h->sweep_reverse;
-    a.wave_start = h->d_wave_start; a.wmeta = h->d_wmeta; a.num_wtiles = (int)h->wave_start.size() - 1; a.com_steps = h->com_steps;
+    a.wave_tile = h->d_wave_tile; a.wmeta = h->d_wmeta; a.num_wtiles = h->num_wtiles;
     a.use_com = (h->d.mode == TGNH_MODE_TGNH && h->d.use_com_temp_group) ? 1 : 0;
     a.hardwall = h->d.max_drude_distance > 0 ? 1 : 0;                         // Ref :299, Cu :372
     a.dt = h->d.step_size; a.max_dist = h->d.max_drude_distance;
@@ -890,9 +890,9 @@ static int grid_for(tgnh_handle h, int ops, bool hardwall, size_t lds) {
     return g;
 }
 
-// wke_kernel: the resident work-groups, at most one per four wave tiles
+// wke_kernel: the resident work-groups, at most one per four wavefront tiles
 static int wave_grid_for(tgnh_handle h, int ops) {
-    const int nw = (int)h->wave_start.size() - 1, need = (nw + TBLOCK / 64 - 1) / (TBLOCK / 64);
+    const int nw = h->num_wtiles, need = (nw + TBLOCK / 64 - 1) / (TBLOCK / 64);
     if (h->grid_override > 0) return std::max(1, std::min(need, h->grid_override));
     const int key = ops | (1 << 17);
     auto it = h->grid_cache.find(key);

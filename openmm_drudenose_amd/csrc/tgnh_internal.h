@@ -41,12 +41,17 @@ inline uint32_t pack_meta(uint32_t role, uint32_t group, int partner_off, uint32
     return role | (group << 2) | ((uint32_t)(partner_off + 1024) << 10) | (local_res << 21);
 }
 
-// ---- wave tiles: the kinetic-energy passes without LDS images and barriers ----------------------------------
-// A KE pass (KE, kick+KE) only needs, per slot, its Drude partner and its molecule's centre-of-mass velocity.  When every
-// molecule fits a wavefront the slot range is also cut into WAVE tiles of <= 64 consecutive slots (never through a pair or a
-// molecule), one per wavefront: the molecular sum of m v is a segmented sum over the lanes (log2(largest molecule) shuffle
-// steps), the partner a lane a few lanes away -- no LDS image, no __syncthreads, the four wavefronts of a work-group
-// independent of each other (wke_kernel).  Its per-slot word:
+// ---- wave tiles: the kinetic-energy passes without barriers ---------------------------------------------------------
+// A KE pass (KE, kick+KE) only needs, per slot, its Drude partner and its molecule's centre-of-mass velocity.  tile_kernel
+// gets both from an LDS image of a 512-slot tile shared by four wavefronts: store, barrier, ONE thread per molecule walks
+// its slots (12 of 64 lanes busy, dependent reads), barrier, look-ups, barrier, and only then the work-group's next loads.
+// When every molecule fits a wavefront the slot range is also cut into WAVE tiles of <= 64 consecutive slots (never through a
+// pair or a molecule), one per wavefront, with a wavefront-PRIVATE LDS image: the wavefront stores its 64 velocities and
+// masses (4 conflict-free ds_write), and every lane then sums its own molecule from the image -- all 64 lanes busy, plain
+// ds_read_b64 (2 LDS cycles per wavefront instruction; shuffling through the crossbar instead, 38 ds_bpermute per tile, or
+// through the vector ALU's row moves, ~110 DPP moves per tile, both measured slower than the LDS pipe it was meant to spare:
+// profiles/r03_ke_pass.md).  A wavefront's own LDS operations are processed in order, so there is no barrier anywhere.
+// Its per-slot word:
 //  bits  0..1  role            bits 2..9  temperature group       bits 10..16 partner offset + 64
 //  bits 17..22 position of the slot inside its molecule            bits 23..28 slots of the molecule - 1
 constexpr int WAVE_SLOTS = 64;
@@ -174,10 +179,9 @@ struct TileArgs {
     int census;                // step_kernel: residency check only (tgnh_create)
     unsigned long long* rows;  // step_kernel: [grid][NT] tagged cells (2 words each), uncached
     // wave tiles (wke_kernel)
-    const int* wave_start;     // [num_wtiles + 1]
+    const int2* wave_tile;     // [num_wtiles + 1]: (first slot, slots of the tile's largest molecule); the next entry's first slot ends it
     const uint32_t* wmeta;     // per-slot word of the wave tiles (pack_wmeta)
     int num_wtiles;
-    int com_steps;             // ceil(log2(slots of the largest molecule)): steps of the segmented sum
     int num_tiles;
     int reverse;               // walk the tiles last-to-first: start where the previous launch ended (its lines are still in the Infinity Cache)
     int padded;
@@ -269,10 +273,10 @@ struct tgnh_context {
     int2* d_big_table = nullptr;
     void* d_big_com = nullptr;
     std::vector<uint32_t> meta;
-    std::vector<int> wave_start;      // wave tiles (empty: some molecule or pair does not fit a wavefront)
+    std::vector<int2> wave_tile;      // wave tiles (empty: some molecule or pair does not fit a wavefront)
     std::vector<uint32_t> wmeta;
-    int com_steps = 0;
-    int* d_wave_start = nullptr;
+    int num_wtiles = 0;
+    int2* d_wave_tile = nullptr;
     uint32_t* d_wmeta = nullptr;
     bool wave_ke = false;             // the KE passes run over the wave tiles (wke_kernel)
     // dof bookkeeping (A2)

@@ -762,14 +762,15 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
 // ---------------------------------------------------------------------------
 // wke_kernel: the kinetic-energy passes (KE; kick+KE; kick+KE without a velocity store) over WAVE tiles.
 //
-// What such a pass needs per slot beyond its own velocity is its Drude partner (a few slots away) and its molecule's
-// centre-of-mass velocity.  tile_kernel gets both from an LDS image of a 512-slot tile: store, barrier, one thread per molecule
-// walks its slots (12 of 64 lanes busy, five dependent LDS reads each), barrier, look-ups, barrier -- and the work-group
-// issues its next loads only then: its wavefronts waited 68 % of their cycles (profiles/r02_pmc_sq.json) while the memory
-// system idled.  Here one wavefront owns <= 64 consecutive slots that never cut a molecule: sum(m v) of a molecule is a
-// segmented sum over its lanes (com_steps = log2 of the largest molecule shuffle steps, then one broadcast from the
-// molecule's first lane), the partner one shuffle away.  No LDS image, no __syncthreads until the final row: the wavefronts
-// are independent, each with its next tile's loads in flight while it works on the current one.
+// What such a pass needs per slot beyond its own velocity is its Drude partner (a lane or so away) and its molecule's
+// centre-of-mass velocity.  tile_kernel gets both from an LDS image of a 512-slot tile shared by four wavefronts -- store,
+// barrier, one thread per molecule walks its slots (12 of 64 lanes busy, five dependent LDS reads each), barrier, look-ups,
+// barrier -- and the work-group issues its next loads only then.  Here a wavefront owns <= 64 consecutive slots that never
+// cut a molecule or a pair (tgnh_internal.h) and a PRIVATE 2 KiB LDS image: it stores its velocities and masses (component
+// arrays, conflict-free) and every lane sums its OWN molecule from the image, in slot order -- the arithmetic and the order of
+// tile_kernel's walk, with all lanes busy and no dependence between wavefronts.  A wavefront's LDS operations are processed
+// in order, so nothing waits for a barrier; the next tile's global loads are in flight while this one is worked on, the tile
+// bounds in scalar registers two tiles ahead.
 // Reference: K :82-113 (COM), :119-133 (relative velocities), :138-200 (bins), :307-365 (the kick); Ref :439-460.
 // ---------------------------------------------------------------------------
 template <int PREC> struct WaveIn {
@@ -778,15 +779,6 @@ template <int PREC> struct WaveIn {
     long long fx, fy, fz;
 };
 
-// one value from lane addr4 / 4 (ds_bpermute: the LDS crossbar, no LDS memory)
-__device__ __forceinline__ double bperm(const int addr4, const double x) {
-    const int lo = __builtin_amdgcn_ds_bpermute(addr4, __double2loint(x));
-    const int hi = __builtin_amdgcn_ds_bpermute(addr4, __double2hiint(x));
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ float bperm(const int addr4, const float x) {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(addr4, __float_as_int(x)));
-}
 // (mixed)force: the fixed-point force as a floating-point number, rounded once.  For doubles hi 2^32 + lo in one fma --
 // both parts are exact, so this is the correctly rounded conversion (the bits of the cast) in 3 instructions instead of 4.
 __device__ __forceinline__ double force_as(const long long f, double) {
@@ -822,9 +814,10 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileAr
     constexpr bool DO_KICK = (OPS & OP_KICK) != 0, STORE = DO_KICK && !(OPS & OP_NOSTORE);
     static_assert(GB > 0, "register bins only");
     __shared__ double sred[TBLOCK / 64][GB + 2];
+    __shared__ mixed s_img[TBLOCK / 64][4][WAVE_SLOTS];          // per wavefront: x[], y[], z[], mass[]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane4 = lane << 2;
+    mixed* const ix = s_img[wv][0]; mixed* const iy = s_img[wv][1]; mixed* const iz = s_img[wv][2]; mixed* const im = s_img[wv][3];
     const int G = a.num_groups;
     const bool use_com = a.use_com != 0;
     const mixed fscale = (mixed)(0.5 * a.dt / 4294967296.0);     // Cu :295
@@ -841,53 +834,56 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileAr
     // tiles.  Everything about WHICH tile is wavefront-uniform (scalar registers, scalar loads): the bounds of the tile after
     // next are fetched while this one is worked on, so the vector loads of the next tile never wait for an index.
     const int nw = a.num_wtiles, stride = (int)gridDim.x * (TBLOCK / 64);
-    auto bounds = [&](const int ww, int& ws, int& n) {
-        const int wi = a.reverse ? nw - 1 - ww : ww;
-        ws = a.wave_start[wi];
-        n = a.wave_start[wi + 1] - ws;
+    struct Bounds { int ws, maxn, n; };
+    auto bounds = [&](const int ww, Bounds& b) {
+        const int2* t = a.wave_tile + (a.reverse ? nw - 1 - ww : ww);
+        b.ws = t[0].x; b.maxn = t[0].y; b.n = t[1].x - b.ws;
     };
-    auto work = [&](const WaveIn<PREC>& cur, const int ws, const int n) {
+    auto work = [&](const WaveIn<PREC>& cur, const Bounds& bd) {
         mixed4 v = cur.v;
         const uint32_t m = cur.meta;
-        const bool massive = v.w != 0;
-        const mixed mass = massive ? rcp_(v.w) : (mixed)0;
+        const mixed mass = v.w != 0 ? rcp_(v.w) : (mixed)0;
         if (DO_KICK) {                                                   // A7, per particle (tile_body); w = 0: c = 0, v unchanged
             const mixed c = fscale * v.w;
             v.x += c * force_as(cur.fx, (mixed)0);
             v.y += c * force_as(cur.fy, (mixed)0);
             v.z += c * force_as(cur.fz, (mixed)0);
         }
-        if (STORE && lane < n) velm[ws + lane] = v;
+        if (STORE && lane < bd.n) velm[bd.ws + lane] = v;
         const uint32_t role = m & 3u, g = (m >> 2) & 255u;
-        // ---- molecular centre-of-mass velocity (K :86-111): segmented sum of m v over the molecule's lanes
+        // the wavefront's image (its own LDS operations are processed in order: the reads below see these stores, and the
+        // stores of the next tile come after this tile's reads -- the fences only keep the compiler from reordering them)
+        ix[lane] = v.x; iy[lane] = v.y; iz[lane] = v.z; im[lane] = mass;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- molecular centre-of-mass velocity (K :86-111): every lane sums its own molecule, in slot order
         mixed cx = 0, cy = 0, cz = 0;
         if (use_com) {
-            const int j = (int)((m >> 17) & 63u), room = (int)((m >> 23) & 63u) - j;      // lanes of the molecule after this one
-            mixed px = v.x * mass, py = v.y * mass, pz = v.z * mass, pm = mass;
-            for (int st = 0, o = 1; st < a.com_steps; st++, o <<= 1) {     // after step k lane j holds the sum over j .. j + 2^k - 1
-                const int src = lane4 + 4 * o;
-                const mixed tx = bperm(src, px), ty = bperm(src, py), tz = bperm(src, pz), tm = bperm(src, pm);
-                if (o <= room) { px += tx; py += ty; pz += tz; pm += tm; }
+            const int j = (int)((m >> 17) & 63u), n1 = (int)((m >> 23) & 63u);
+            const int first = lane - j;
+            mixed px = 0, py = 0, pz = 0, pm = 0;
+            for (int k = 0; k < bd.maxn; k++) {                          // (bd.maxn: the tile's largest molecule, a scalar)
+                if (k <= n1) {
+                    const mixed um = im[first + k];
+                    px += ix[first + k] * um; py += iy[first + k] * um; pz += iz[first + k] * um; pm += um;
+                }
             }
-            if (j == 0 && lane < n) {                                    // the molecule's first lane holds sum m v and M
-                const mixed wq = rcp_(pm);
-                px *= wq; py *= wq; pz *= wq;
-                ke_com += ((double)px * px + (double)py * py + (double)pz * pz) * (double)pm;     // M v_com^2 (K :154)
-            }
-            const int head = lane4 - 4 * j;
-            cx = bperm(head, px); cy = bperm(head, py); cz = bperm(head, pz);
+            const mixed wq = rcp_(pm);                                   // (a padding lane: pm = 0, unused)
+            cx = px * wq; cy = py * wq; cz = pz * wq;
+            if (j == 0 && lane < bd.n)                                   // once per molecule: M v_com^2 (K :154)
+                ke_com += ((double)cx * cx + (double)cy * cy + (double)cz * cz) * (double)pm;
         }
         // ---- bins (K :138-200 ; Ref :439-460).  Every massive slot adds m |v - v_com|^2 to its group's bin; a pair's
         // two terms together are (m1 + m2) |cm - v_com|^2 + mu |v2 - v1|^2 (K :171-186 splits them that way), so the Drude
         // lane moves the second part, mu |v2 - v1|^2, from the group's bin to the Drude bin: the partner is needed for that
         // difference only
         const double rx = v.x - cx, ry = v.y - cy, rz = v.z - cz;          // (in the velocities' own precision, as tile_body)
-        double val = (rx * rx + ry * ry + rz * rz) * (double)mass;       // 0 for massless sites
-        const int pl = lane4 + 4 * ((int)((m >> 10) & 127u) - 64);
-        const mixed ux = bperm(pl, v.x), uy = bperm(pl, v.y), uz = bperm(pl, v.z), um = bperm(pl, mass);
+        double val = v.w != 0 ? (rx * rx + ry * ry + rz * rz) * (double)mass : 0.0;
         if (role == ROLE_DRUDE) {                                        // one lane per pair
-            const double dx = ux - v.x, dy = uy - v.y, dz = uz - v.z;
-            const double mass1 = mass, mass2 = um;
+            const int pl = lane + (int)((m >> 10) & 127u) - 64;
+            const double dx = ix[pl] - v.x, dy = iy[pl] - v.y, dz = iz[pl] - v.z;
+            const double mass1 = mass, mass2 = im[pl];
             const double mu = mass1 * mass2 * rcp_(mass1 + mass2);       // reduced mass = 1/invReducedMass (K :178, :185)
             const double d = (dx * dx + dy * dy + dz * dz) * mu;
             ke_drude += d;
@@ -895,24 +891,27 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileAr
         }
 #pragma unroll
         for (int b = 0; b < GB; b++) ke_g[b] += (g == (uint32_t)b) ? val : 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
     int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (TBLOCK / 64) + wv);
-    int ws0 = 0, n0 = 0, ws1 = 0, n1 = 0, ws2 = 0, n2 = 0;
+    Bounds b0{}, b1{}, b2{};
     WaveIn<PREC> A, B;
-    if (w < nw) { bounds(w, ws0, n0); wave_load<PREC, OPS>(a, ws0, n0, lane, A); }
-    if (w + stride < nw) bounds(w + stride, ws1, n1);
+    if (w < nw) { bounds(w, b0); wave_load<PREC, OPS>(a, b0.ws, b0.n, lane, A); }
+    if (w + stride < nw) bounds(w + stride, b1);
     while (w < nw) {                                                     // two tiles per trip: the register images alternate
-        if (w + 2 * stride < nw) bounds(w + 2 * stride, ws2, n2);
-        if (w + stride < nw) wave_load<PREC, OPS>(a, ws1, n1, lane, B);  // in flight while A is worked on
-        work(A, ws0, n0);
+        if (w + 2 * stride < nw) bounds(w + 2 * stride, b2);
+        if (w + stride < nw) wave_load<PREC, OPS>(a, b1.ws, b1.n, lane, B);   // in flight while A is worked on
+        work(A, b0);
         w += stride;
         if (w >= nw) break;
-        if (w + 2 * stride < nw) bounds(w + 2 * stride, ws0, n0);
-        if (w + stride < nw) wave_load<PREC, OPS>(a, ws2, n2, lane, A);
-        work(B, ws1, n1);
+        if (w + 2 * stride < nw) bounds(w + 2 * stride, b0);
+        if (w + stride < nw) wave_load<PREC, OPS>(a, b2.ws, b2.n, lane, A);
+        work(B, b1);
         w += stride;
-        ws1 = ws0; n1 = n0; ws0 = ws2; n0 = n2;                          // (scalar moves)
+        b1 = b0; b0 = b2;                                                // (scalar moves)
     }
     // ---- one row of partial sums per work-group: 64-lane sums, one LDS hop, fixed order (ke_reduce's layout)
 #pragma unroll

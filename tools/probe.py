@@ -11,6 +11,7 @@
   probe.py placement [molecules] [pools]                     does a launch's speed go with where the driver put the buffers?
   probe.py drift [molecules]                                 does the dominant launch drift in time (clock ramp, idle gaps)?
   probe.py soak [steps] [waters] [lag]                       two-process mailbox exchange on one GPU, many thousand exchanges
+  probe.py ke [molecules]                                    the KE pass back to back vs behind a kernel that has just written 120-1000 MB
   probe.py resident-soak                                     step_kernel for 10^5 launches at three sizes: no meeting may time out
 """
 import json
@@ -236,6 +237,50 @@ def soak(argv):
               f"finite {all(np.isfinite(v).all() for v in vel)}", flush=True)
 
 
+def ke(argv):
+    """The KE pass alone, back to back, against the same launch behind a kernel that has just WRITTEN 120 / 480 MB (what the
+    harness force and the rescale+kick+drift launch leave behind in a step): does the pass run slower in a step because of what
+    it does, or because the memory system is still writing back the launch before it?  (HIP events per launch.)"""
+    import torch
+    from openmm_drudenose_amd import _lib
+    ctx = _context(int(argv[0]) if argv else 1000000)
+    ctx.step(5)
+    _check_flush(ctx)
+    n = ctx.n
+    mb = n * (32 + 4) / 1e6                       # velm + index word
+
+    def run(tag, fill_mb, reps=40):
+        buf = torch.empty(int(fill_mb * 1e6) // 8, dtype=torch.float64, device=ctx.dev) if fill_mb else None
+        for _ in range(5):
+            ctx.compute_kinetic_energies()
+        torch.cuda.synchronize()
+        ctx.timing(2 + _lib.KID_KE)
+        for i in range(reps):
+            if buf is not None:
+                buf.fill_(float(i))
+            _lib_call(ctx)
+        torch.cuda.synchronize()
+        ctx.timing(False)
+        ms, k = ctx.timing_read(_lib.KID_KE)
+        us = ms / k * 1e3
+        print(f"{tag:58s} {us:7.1f} us  {mb / us:5.2f} TB/s (velm + index word, {mb:.0f} MB)", flush=True)
+    run("KE pass, back to back", 0)
+    run("KE pass behind a 120 MB fill (the harness force's stores)", 120)
+    run("KE pass behind a 320 MB fill (rescale+kick+drift's stores)", 320)
+    run("KE pass behind a 1 GB fill", 1000)
+    run("KE pass, back to back (again)", 0)
+
+
+def _check_flush(ctx):
+    from openmm_drudenose_amd.drudetgnhplugin import _check
+    _check(ctx.lib.tgnh_flush(ctx.h, ctx._stream()))
+
+
+def _lib_call(ctx):
+    from openmm_drudenose_amd.drudetgnhplugin import _check
+    _check(ctx.lib.tgnh_compute_kinetic_energies(ctx.h, ctx._stream()))
+
+
 def resident_soak(argv):
     import numpy as np
     import torch
@@ -265,7 +310,7 @@ def resident_soak(argv):
 
 
 if __name__ == "__main__":
-    cmds = {"resident-soak": resident_soak, "knob": knob, "variants": variants, "chain": chain, "copy": copy, "stream": stream, "placement": placement,
+    cmds = {"ke": ke, "resident-soak": resident_soak, "knob": knob, "variants": variants, "chain": chain, "copy": copy, "stream": stream, "placement": placement,
             "drift": drift, "soak": soak}
     if len(sys.argv) < 2 or sys.argv[1] not in cmds:
         raise SystemExit(__doc__)
