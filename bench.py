@@ -105,6 +105,15 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
         kw = dict(allreduce=lambda t: dist.all_reduce(t), global_dof_sum=dof_sum)
     ctx = HipContext(local, it, mode=args.mode, precision=precision, device=dev, flags=flags, **kw)
     ctx.exchange = "rccl" if kw else None
+    ctx.rccl_site = None
+    if kw:
+        # The collective is the library's own ncclAllReduce (tgnh_rccl_init: its communicator, set up from an id that travels
+        # through the process group); the torch.distributed hook set above stays only if that cannot be had -- a rehearsal
+        # with several ranks on one device (RCCL refuses a device twice) or a gloo group.
+        native = "TGNH_BENCH_DEVICE" not in os.environ and os.environ.get("TGNH_BENCH_BACKEND", "nccl") == "nccl" \
+            and os.environ.get("TGNH_BENCH_RCCL", "library") == "library"
+        ctx.rccl_site = "library (ncclAllReduce enqueued by libdrudetgnh_hip)" if native and ctx.rccl_init_over(dist, rank, world) \
+            else "torch.distributed.all_reduce through the tgnh_set_allreduce hook"
     if world > 1 and "TGNH_BENCH_DEVICE" in os.environ:
         ctx.set_resident_share(world)      # rehearsal: the ranks share ONE device, so each gets 1/world of its work-group slots
     return ctx
@@ -178,6 +187,30 @@ def validate_mailbox(args, rank, world):
         print(f"[bench] rank {rank}: mailbox and rccl thermostats differ", file=sys.stderr)
         return False
     return True
+
+
+def per_rank_exchange_report(ctx, exchange, world):
+    """Where a sharded leg spends its step, rank by rank (collective): the dominant launch's average duration on every rank
+    and, for the mailbox exchange, how long work-group 0 of every rank waited for its peers' sums (device clock, whole leg:
+    warm-up, timed region and the instrumented repeat).  A rank that waits long waits for a slower peer or for the link."""
+    import torch.distributed as dist
+    from openmm_drudenose_amd import _lib
+    mine = {}
+    for kid in (_lib.KID_STEP, _lib.KID_SKD, _lib.KID_KICK_KE, _lib.KID_CHAIN):
+        row = ctx.leg["kernels"].get(_lib.KERNEL_NAMES[kid])
+        if row:
+            mine[_lib.KERNEL_NAMES[kid]] = row["avg_us"]
+    if exchange == "mailbox":
+        mean, mx, n = ctx.exchange_wait_stats()
+        mine["wait_us_mean"], mine["wait_us_max"], mine["exchanges"] = round(mean, 2), round(mx, 2), n
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    rep = {"per_rank_kernel_us": [{k: v for k, v in e.items() if not k.startswith("wait") and k != "exchanges"} for e in every]}
+    if exchange == "mailbox":
+        rep["wait_us_mean"] = [e["wait_us_mean"] for e in every]
+        rep["wait_us_max"] = [e["wait_us_max"] for e in every]
+        rep["exchanges"] = every[0]["exchanges"]
+    return rep
 
 
 def dominant_kid(variant):
@@ -540,6 +573,7 @@ def main():
                              "ms_per_step": round(d2 / args.steps * 1e3, 5), "hipgraph": c2.graph_used,
                              "step_kernel_ran": _lib.KERNEL_NAMES[_lib.KID_STEP] in c2.leg["kernels"],
                              "timed_out": timed_out, "sum_kernels_us_per_step": c2.leg["sum_kernels_us_per_step"]})
+                info.update(per_rank_exchange_report(c2, other, world))
                 close_sharded(c2)
             else:
                 info["attached"] = False
@@ -567,6 +601,8 @@ def main():
         raise SystemExit("bench.py: the mailbox exchange timed out inside the timed run")
     graph_used = ctx.graph_used
     exchange_used = ctx.exchange
+    rccl_site = ctx.rccl_site
+    headline_ranks = per_rank_exchange_report(ctx, exchange_used, world) if use_dist else None
     leg = ctx.leg
     rows = leg["kernels"]
     assert ctx.check() == 0
@@ -635,6 +671,8 @@ def main():
                 "hipgraph": graph_used,
                 "parallelism": f"particle-sharded x{world} (whole molecules), one KE all-reduce per step",
                 "exchange": exchange_used, "rccl_ranks": ranks_met if use_dist else None,
+                "rccl_site": rccl_site if exchange_used == "rccl" else None,
+                "per_rank": headline_ranks,
                 "slots_per_gpu": local_slots,
                 "model_bytes_per_step": b_step,
                 "step_GBps_vs_model": round(b_step / (dt / args.steps) / 1e9 / world, 1),

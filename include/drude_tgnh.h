@@ -136,6 +136,21 @@ tgnh_status tgnh_set_max_drude_distance(tgnh_handle h, double d);
 tgnh_status tgnh_get_local_dof_terms(tgnh_handle h, double* terms, int* count);
 tgnh_status tgnh_set_global_dof_terms(tgnh_handle h, const double* terms, int count);
 tgnh_status tgnh_set_allreduce(tgnh_handle h, tgnh_allreduce_fn fn, void* user);
+
+/* The collective done by the library itself: one ncclAllReduce(sum, ncclDouble, NT values, in place) per thermostat half
+ * step -- per time step with TGNH_FLAG_DEFER_SCALE -- enqueued on the step's stream between the row sum and the chain
+ * (the reference integrates on one device only, platforms/cuda/src/CudaDrudeTGNHKernelFactory.cpp:62: this is the exchange
+ * north_star adds, "a single RCCL all-reduce over xGMI of the per-group KE scalars each step").  Either hand over a
+ * communicator the caller already has (an ncclComm_t of the RCCL this library is linked against), or let the library make
+ * its own: rank 0 calls tgnh_rccl_unique_id and passes the TGNH_RCCL_ID_BYTES to every rank by whatever means the caller
+ * has (MPI, a file, torch.distributed), then EVERY rank calls tgnh_rccl_init (collective; the handle's device must be
+ * current-able).  Replaces a tgnh_set_allreduce hook; tgnh_rccl_shutdown (or tgnh_destroy) destroys a communicator the
+ * library made.  Capturable into a hipGraph like every launch of a step. */
+#define TGNH_RCCL_ID_BYTES 128
+tgnh_status tgnh_rccl_unique_id(void* id_out);
+tgnh_status tgnh_rccl_init(tgnh_handle h, int world, int rank, const void* id);
+tgnh_status tgnh_set_rccl_comm(tgnh_handle h, void* nccl_comm);
+tgnh_status tgnh_rccl_shutdown(tgnh_handle h);
 /* TGNH_FLAG_RESIDENT_STEP: this handle may fill 1/share of the device's resident work-group slots (default 1 = all of
  * them).  Several handles that step concurrently on one device (replicas, or the ranks of a rehearsal on one GPU) must
  * share it, or their launches wait for each other's work-groups until the meeting times out (status bit 3). */
@@ -159,6 +174,11 @@ tgnh_status tgnh_exchange_create(tgnh_handle h, int world, int rank, void* ipc_h
 tgnh_status tgnh_exchange_attach(tgnh_handle h, const void* ipc_handles);
 tgnh_status tgnh_exchange_attach_pointers(tgnh_handle h, void* const* mailboxes);
 tgnh_status tgnh_exchange_detach(tgnh_handle h);
+/* How long the waits of the mailbox exchange took on this rank since the last call (or attach): per exchange, the time from
+ * "this rank's sums are complete" to "every rank's sums are here" as seen by work-group 0 of the waiting launch, measured on
+ * the device (wall_clock64, 10 ns ticks) -- the figure that says WHERE a sharded run loses time when it scales worse than the
+ * one-GPU ceiling: a rank that waits long is waiting for a slower peer or for the link.  Synchronises `stream`; resets. */
+tgnh_status tgnh_exchange_wait_stats(tgnh_handle h, void* stream, double* mean_us, double* max_us, int64_t* exchanges);
 
 /* One time step, split at the force call-out:
  *   begin: [KE -> chain ->] rescale, half kick, drift, hard wall

@@ -47,7 +47,7 @@ def build(force=False, verbose=False):
     cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-x", "hip"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB]
+    cmd += ["-ldl", "-o", LIB]       # (RCCL is bound with dlopen at the first tgnh_rccl_* call: tgnh_host.cpp)
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

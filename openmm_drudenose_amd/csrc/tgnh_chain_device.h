@@ -451,6 +451,8 @@ template <bool SPREAD = false>
 __device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT, const int lane, double* s_val,
                                                 const unsigned long long seq_expected = 0ull, bool* failed = nullptr) {
     const int cells = x.world * NT;
+    const bool stamp = x.stat != nullptr && blockIdx.x == 0;            // work-group 0 keeps the rank's wait statistics
+    const unsigned long long t_in = stamp ? wall_clock64() : 0ull;
     const unsigned long long* const box = x.mine + (SPREAD ? (size_t)(blockIdx.x % (unsigned)XCHG_REPLICAS) * XCHG_REPLICA_U64 : 0);
     // first batch: counter, latch and both parities of this lane's first cell, all in flight together
     const unsigned long long seq_raw = seq_expected ? seq_expected : __hip_atomic_load(x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -487,6 +489,15 @@ __device__ __forceinline__ double xchg_wait_sum(const XchgArgs& x, const int NT,
         __hip_atomic_store(x.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (failed) *failed = __any(timed_out || dead != 0u);
+    if (stamp) {                                                        // from "my sums are out" to "everybody's are here"
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long dt = wall_clock64() - t_in;
+        if (lane == 0) {                                                // (one writer per launch: plain read-modify-write)
+            x.stat[0] += dt;
+            if (dt > x.stat[1]) x.stat[1] = dt;
+            x.stat[2] += 1ull;
+        }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -12,6 +12,9 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include "tgnh_internal.h"
 #ifndef TGNH_MEETING_MEM
 #define TGNH_MEETING_MEM hipDeviceMallocFinegrained
@@ -435,6 +438,8 @@ static void exchange_release(tgnh_context* c) {
     if (c->d_x_seq) (void)hipFree(c->d_x_seq);
     if (c->d_x_dead) (void)hipFree(c->d_x_dead);
     if (c->d_x_peers) (void)hipFree(c->d_x_peers);
+    if (c->d_x_stat) (void)hipFree(c->d_x_stat);
+    c->d_x_stat = nullptr;
     c->x_mailbox = nullptr; c->d_x_seq = nullptr; c->d_x_dead = nullptr; c->d_x_peers = nullptr;
     c->xchg_on = false;
 }
@@ -622,6 +627,7 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
 
 extern "C" tgnh_status tgnh_destroy(tgnh_handle h) {
     CHECK_H(h);
+    if (h->rccl_comm) (void)tgnh_rccl_shutdown(h);
     if (!h->host_only) { (void)hipSetDevice(h->device); free_device(h); }
     delete h;
     return TGNH_OK;
@@ -702,6 +708,8 @@ extern "C" tgnh_status tgnh_exchange_create(tgnh_handle h, int world, int rank, 
     HIP_OK(hipMalloc(&h->d_x_dead, sizeof(unsigned int)));
     HIP_OK(hipMemset(h->d_x_dead, 0, sizeof(unsigned int)));
     HIP_OK(hipMalloc(&h->d_x_peers, sizeof(unsigned long long*) * world));
+    HIP_OK(hipMalloc(&h->d_x_stat, 3 * sizeof(unsigned long long)));
+    HIP_OK(hipMemset(h->d_x_stat, 0, 3 * sizeof(unsigned long long)));
     HIP_OK(hipDeviceSynchronize());
     h->x_world = world; h->x_rank = rank;
     if (ipc_handle_out) {
@@ -720,6 +728,7 @@ static tgnh_status exchange_finish_attach(tgnh_handle h, const std::vector<unsig
     h->x.on = 1; h->x.world = h->x_world; h->x.rank = h->x_rank;
     h->x.peers = h->d_x_peers; h->x.mine = h->x_mailbox; h->x.seq = h->d_x_seq; h->x.dead = h->d_x_dead;
     h->x.status = h->d_status;
+    h->x.stat = h->d_x_stat;
     h->xchg_on = true;
     return TGNH_OK;
 }
@@ -784,7 +793,106 @@ extern "C" tgnh_status tgnh_exchange_detach(tgnh_handle h) {
 extern "C" tgnh_status tgnh_set_allreduce(tgnh_handle h, tgnh_allreduce_fn fn, void* user) {
     CHECK_H(h);
     tgnh_status rc = deferred_guard(h, "tgnh_set_allreduce"); if (rc) return rc;
+    if (h->rccl_comm) { rc = tgnh_rccl_shutdown(h); if (rc) return rc; }
     h->allreduce = fn; h->allreduce_user = user;
+    return TGNH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// RCCL: the all-reduce of SURVEY 8e enqueued by the library itself
+// ---------------------------------------------------------------------------
+// RCCL is bound at the first tgnh_rccl_* call, not at load time: the process may already hold one (PyTorch ships its own
+// librccl.so.1 and a second copy in one address space is two sets of communicators), so the copy that is loaded is used, and
+// the system's (/opt/rocm/lib) is opened only when there is none.  A library that never shards never touches RCCL.
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+    bool ok = false;
+};
+Rccl& rccl() {
+    static Rccl r;
+    if (r.lib || !r.error.empty()) return r;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);     // the copy the process already has
+    for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!r.lib) { r.error = std::string("RCCL not found (librccl.so.1): ") + dlerror(); return r; }
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;
+    if (!r.ok) r.error = "RCCL: a required symbol is missing from librccl";
+    return r;
+}
+#define RCCL_OK(expr)                                                                                        \
+    do {                                                                                                     \
+        ncclResult_t r_ = (expr);                                                                            \
+        if (r_ != ncclSuccess) return fail(TGNH_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(r_)); \
+    } while (0)
+
+// the tgnh_allreduce_fn the library installs for itself: the kinetic-energy sums, in place, on the step's stream
+int rccl_allreduce(void* buf, int count, void* stream, void* user) {
+    tgnh_context* h = static_cast<tgnh_context*>(user);
+    return rccl().AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, static_cast<ncclComm_t>(h->rccl_comm),
+                            static_cast<hipStream_t>(stream)) == ncclSuccess ? 0 : 1;
+}
+}  // namespace
+
+extern "C" tgnh_status tgnh_rccl_unique_id(void* id_out) {
+    if (!id_out) return fail(TGNH_ERR_ARG, "null id");
+    static_assert(sizeof(ncclUniqueId) == TGNH_RCCL_ID_BYTES, "ncclUniqueId size");
+    if (!rccl().ok) return fail(TGNH_ERR_HIP, rccl().error);
+    ncclUniqueId id;
+    RCCL_OK(rccl().GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof(id));
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_set_rccl_comm(tgnh_handle h, void* nccl_comm) {
+    CHECK_H(h);
+    if (h->host_only) return fail(TGNH_ERR_STATE, "host-only handle");
+    tgnh_status rc = deferred_guard(h, "tgnh_set_rccl_comm"); if (rc) return rc;
+    if (!rccl().ok) return fail(TGNH_ERR_HIP, rccl().error);
+    if (h->rccl_comm) { rc = tgnh_rccl_shutdown(h); if (rc) return rc; }
+    if (!nccl_comm) { h->allreduce = nullptr; h->allreduce_user = nullptr; return TGNH_OK; }
+    h->rccl_comm = nccl_comm; h->rccl_owned = false;
+    h->allreduce = rccl_allreduce; h->allreduce_user = h;
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_rccl_init(tgnh_handle h, int world, int rank, const void* id) {
+    CHECK_H(h);
+    if (h->host_only) return fail(TGNH_ERR_STATE, "host-only handle");
+    if (world < 1 || rank < 0 || rank >= world || !id) return fail(TGNH_ERR_ARG, "bad world / rank / id");
+    tgnh_status rc = deferred_guard(h, "tgnh_rccl_init"); if (rc) return rc;
+    if (!rccl().ok) return fail(TGNH_ERR_HIP, rccl().error);
+    if (h->rccl_comm) { rc = tgnh_rccl_shutdown(h); if (rc) return rc; }
+    HIP_OK(hipSetDevice(h->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    ncclComm_t comm = nullptr;
+    RCCL_OK(rccl().CommInitRank(&comm, world, uid, rank));
+    h->rccl_comm = comm; h->rccl_owned = true;
+    h->allreduce = rccl_allreduce; h->allreduce_user = h;
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_rccl_shutdown(tgnh_handle h) {
+    CHECK_H(h);
+    if (!h->rccl_comm) return TGNH_OK;
+    if (!h->host_only) { HIP_OK(hipSetDevice(h->device)); HIP_OK(hipDeviceSynchronize()); }
+    if (h->allreduce == rccl_allreduce) { h->allreduce = nullptr; h->allreduce_user = nullptr; }
+    ncclComm_t comm = static_cast<ncclComm_t>(h->rccl_comm);
+    const bool owned = h->rccl_owned;
+    h->rccl_comm = nullptr; h->rccl_owned = false;
+    if (owned) RCCL_OK(rccl().CommDestroy(comm));
     return TGNH_OK;
 }
 
@@ -792,6 +900,22 @@ extern "C" tgnh_status tgnh_get_resident_work_groups(tgnh_handle h, int* per_com
     CHECK_H(h);
     if (!per_compute_unit) return fail(TGNH_ERR_ARG, "null out");
     *per_compute_unit = resident_now(h) ? h->resident_per_cu : 0;
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_exchange_wait_stats(tgnh_handle h, void* stream, double* mean_us, double* max_us, int64_t* exchanges) {
+    CHECK_H(h);
+    if (!h->d_x_stat) return fail(TGNH_ERR_STATE, "tgnh_exchange_create first");
+    HIP_OK(hipSetDevice(h->device));
+    unsigned long long st[3] = {0, 0, 0};
+    hipStream_t s = (hipStream_t)stream;
+    HIP_OK(hipMemcpyAsync(st, h->d_x_stat, sizeof(st), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemsetAsync(h->d_x_stat, 0, sizeof(st), s));
+    HIP_OK(hipStreamSynchronize(s));
+    const double tick_us = 0.01;                           // wall_clock64: 100 MHz
+    if (mean_us) *mean_us = st[2] ? tick_us * (double)st[0] / (double)st[2] : 0.0;
+    if (max_us) *max_us = tick_us * (double)st[1];
+    if (exchanges) *exchanges = (int64_t)st[2];
     return TGNH_OK;
 }
 

@@ -137,6 +137,7 @@ struct XchgArgs {
     unsigned long long* seq;    // this rank's exchange counter (device)
     unsigned int* dead;         // latch: an exchange timed out
     unsigned int* status;       // the handle's status word (bit 2: exchange time-out)
+    unsigned long long* stat;   // [3] wait statistics of work-group 0: sum of ticks, largest, exchanges (wall_clock64, 10 ns); may be null
 };
 
 constexpr int CHAIN_INLINE_SUM_NT = 10;     // thermostats (G <= 8) ...
@@ -331,6 +332,9 @@ struct tgnh_context {
     int64_t step_count = 0;
     tgnh_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
+    void* rccl_comm = nullptr;        // ncclComm_t: the library enqueues ncclAllReduce itself (tgnh_rccl_init / tgnh_set_rccl_comm)
+    bool rccl_owned = false;
+    unsigned long long* d_x_stat = nullptr;   // mailbox wait statistics (XchgArgs::stat)
     // mailbox exchange (tgnh_exchange_*): replaces the hook when attached
     tgnh::XchgArgs x{};
     bool xchg_on = false, xwait_pending = false;

@@ -360,8 +360,58 @@ class HipContext(_HandleQueries):
         self._views = {}
         _check(self.lib.tgnh_set_allreduce(self.h, self._hook, None))
 
+    # ---- the library's own RCCL all-reduce (include/drude_tgnh.h: tgnh_rccl_*) ----
+    RCCL_ID_BYTES = 128
+
+    def rccl_init(self, world, rank, unique_id):
+        """Collective: every rank of `world` calls this with rank 0's id (rccl_unique_id())."""
+        _check(self.lib.tgnh_rccl_init(self.h, int(world), int(rank), C.c_char_p(unique_id)))
+        self._hook = None
+
+    def rccl_unique_id(self):
+        buf = C.create_string_buffer(self.RCCL_ID_BYTES)
+        _check(self.lib.tgnh_rccl_unique_id(buf))
+        return buf.raw
+
+    def rccl_shutdown(self):
+        _check(self.lib.tgnh_rccl_shutdown(self.h))
+
+    def rccl_init_over(self, dist, rank, world):
+        """The library's communicator set up through a torch.distributed process group (which only carries the 128-byte id):
+        all ranks return True (the library enqueues ncclAllReduce itself from now on) or all return False (nothing changed)."""
+        torch = self.torch
+        ok, err = 1, None
+        ids = [None]
+        try:
+            if rank == 0:
+                ids[0] = self.rccl_unique_id()
+        except Exception as e:                      # noqa: BLE001
+            ids[0], err = None, e
+        dist.broadcast_object_list(ids, src=0)
+        if ids[0] is None:
+            self.rccl_error = err or RuntimeError("rank 0 could not create an RCCL id")
+            return False
+        try:
+            self.rccl_init(world, rank, ids[0])
+        except Exception as e:                      # noqa: BLE001
+            ok, err = 0, e
+        flags = [None] * world
+        dist.all_gather_object(flags, ok)
+        if not all(flags):
+            if ok:
+                self.rccl_shutdown()
+            self.rccl_error = err
+            return False
+        return True
+
     # ---- mailbox exchange over xGMI (include/drude_tgnh.h: tgnh_exchange_*) ----
     XCHG_HANDLE_BYTES = 64
+
+    def exchange_wait_stats(self):
+        """(mean us, max us, exchanges) of this rank's waits for its peers' sums since the last call; resets."""
+        mean, mx, n = C.c_double(), C.c_double(), C.c_int64()
+        _check(self.lib.tgnh_exchange_wait_stats(self.h, self._stream(), C.byref(mean), C.byref(mx), C.byref(n)))
+        return mean.value, mx.value, n.value
 
     def exchange_create(self, world, rank):
         """-> (IPC handle bytes for peers in other processes, device pointer for peers in this process)"""

@@ -1179,6 +1179,39 @@ def test_collective_hook_path_against_the_oracle(sysname, mode, drude_chains, pr
     ctx.close()
 
 
+@pytest.mark.parametrize("flags,chains", [(FLAG_DEFER_SCALE, 1), (0, 1), (FLAG_DEFER_SCALE, 3)])
+def test_native_rccl_site_equals_the_hook_path(flags, chains):
+    """tgnh_rccl_init: the library enqueues ncclAllReduce(sum, ncclDouble, NT values) itself, between the row sum and the
+    chain.  A one-rank communicator (all a one-GPU box can hold; its all-reduce is the identity) against the same run with an
+    identity hook: the same launches around the collective, so positions, velocities and thermostats agree bit for bit --
+    eagerly, and with the collective captured into a hipGraph with the steps.  Across ranks the path is the driver's to run
+    (bench.py --gpus N uses it for the headline)."""
+    runs = {}
+    for which in ("hook", "rccl", "rccl-graph"):
+        s, g, ng, it, ctx = make("mixed", "TGNH", "mixed", flags=flags, chains=chains, hardwall=0.02)
+        if which == "hook":
+            ctx.set_allreduce(lambda t: None)
+        else:
+            ctx.rccl_init(1, 0, ctx.rccl_unique_id())
+        if which == "rccl-graph":
+            ctx.step(4)
+            replay = ctx.capture_steps(4)
+            for _ in range(9):
+                replay()
+        else:
+            ctx.step(40)
+        ctx.torch.cuda.synchronize()
+        assert ctx.check() == 0
+        runs[which] = (ctx.getPositions(), ctx.getVelocities(), ctx.thermostat_state(0), ctx.thermostat_state(1))
+        if which == "rccl":
+            ctx.rccl_shutdown()              # back to no exchange: the handle keeps stepping
+            ctx.step(2)
+        ctx.close()
+    for which in ("rccl", "rccl-graph"):
+        for a, b in zip(runs["hook"], runs[which]):
+            assert np.array_equal(a, b), which
+
+
 @pytest.mark.parametrize("flags", [FLAG_DEFER_SCALE, RESIDENT])
 def test_collective_hook_path_two_shards_on_one_gpu(flags):
     """The collective-hook path with two shards (two handles on this GPU, one stream), with the deferred launches and with
