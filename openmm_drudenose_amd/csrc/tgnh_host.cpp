@@ -614,6 +614,21 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
                     HIP_OK(hipMemcpy(res, c->d_sync + 2, sizeof(res), hipMemcpyDeviceToHost));
                     if (res[0] == (unsigned)grid && res[1] == 0) c->resident_per_cu = per_cu;
                 }
+                // the same count for wstep_kernel, which runs the whole deferred step when the topology has wave tiles
+                bool want_w = c->wave_ke && (c->d.flags & TGNH_FLAG_DEFER_SCALE) && c->resident_per_cu > 0;
+#ifdef TGNH_TUNING
+                if (const char* e = getenv("TGNH_WSTEP")) want_w = want_w && e[0] != '0';
+#endif
+                for (int per_cu = want_w ? std::min(wstep_blocks_per_cu(c->d.precision, c->gb), 8) : 0; per_cu >= 1 && !c->wresident_per_cu; per_cu--) {
+                    TileArgs a{};
+                    a.census = 1; a.sync = c->d_sync;
+                    HIP_OK(hipMemset(c->d_sync + 2, 0, 2 * sizeof(unsigned int)));
+                    const int grid = std::min(per_cu * c->num_cus, GRID_CAP);
+                    HIP_OK(launch_wstep(c->d.precision, c->gb, a, grid, (hipStream_t)0));
+                    unsigned int res[2] = {0, 1};
+                    HIP_OK(hipMemcpy(res, c->d_sync + 2, sizeof(res), hipMemcpyDeviceToHost));
+                    if (res[0] == (unsigned)grid && res[1] == 0) c->wresident_per_cu = per_cu;
+                }
             }
         }
         return TGNH_OK;
@@ -923,6 +938,7 @@ extern "C" tgnh_status tgnh_set_resident_share(tgnh_handle h, int share) {
     CHECK_H(h);
     if (share < 1 || share > 64) return fail(TGNH_ERR_ARG, "resident share must be 1..64");
     h->resident_share = share;
+    h->wresident_grid = 0;
     for (auto& g : h->resident_grid) g[0] = g[1] = 0;
     return TGNH_OK;
 }
@@ -1208,9 +1224,18 @@ static tgnh_status run_resident(tgnh_handle h, hipStream_t s, int kind) {
     a.st_in = h->d_state; a.st_out = h->d_state;       // advanced in place by work-group 0 after everybody has read it
     a.sync = h->d_sync; a.rows = h->d_rows;
     if (h->num_big && a.use_com) { tgnh_status rc = run_big_com(h, kind == 0 || kind == 2, s); if (rc) return rc; }
-    h->ke_parts = grid;
     h->last_step_kind = kind;
-    {
+    if (kind == 0 && h->wresident_per_cu > 0) {            // a whole deferred step over wave tiles (wstep_kernel)
+        if (h->wresident_grid == 0) {
+            const int need = (h->num_wtiles + WBLOCK / 64 - 1) / (WBLOCK / 64);
+            h->wresident_grid = std::max(1, std::min(std::min(need, h->wresident_per_cu * h->num_cus / h->resident_share), GRID_CAP));
+        }
+        a.chain.nparts = h->wresident_grid;
+        h->ke_parts = h->wresident_grid;
+        Timed t(h, s, KID_STEP);
+        HIP_OK(launch_wstep(h->d.precision, h->gb, a, h->wresident_grid, s));
+    } else {
+        h->ke_parts = grid;
         Timed t(h, s, KID_STEP);
         HIP_OK(launch_step(h->d.precision, h->gb, kind, a, grid, lds, s));
     }

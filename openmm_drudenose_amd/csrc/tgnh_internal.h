@@ -55,6 +55,7 @@ inline uint32_t pack_meta(uint32_t role, uint32_t group, int partner_off, uint32
 //  bits  0..1  role            bits 2..9  temperature group       bits 10..16 partner offset + 64
 //  bits 17..22 position of the slot inside its molecule            bits 23..28 slots of the molecule - 1
 constexpr int WAVE_SLOTS = 64;
+constexpr int WBLOCK = 512;                 // wstep_kernel's work-group: 8 wavefronts hand in ONE row of sums (half the rows to collect)
 inline uint32_t pack_wmeta(uint32_t role, uint32_t group, int partner_off, uint32_t pos_in_mol, uint32_t mol_slots_m1) {
     return role | (group << 2) | ((uint32_t)(partner_off + 64) << 10) | (pos_in_mol << 17) | (mol_slots_m1 << 23);
 }
@@ -244,6 +245,8 @@ int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds);   // occupan
 hipError_t launch_step(int precision, int gb, int kind, const TileArgs& a, int grid, size_t lds, hipStream_t s);
 int step_blocks_per_cu(int precision, int gb, int kind, size_t lds);
 int step_kind_ops2(int kind);       // operations of the kind's second pass (its LDS needs)
+hipError_t launch_wstep(int precision, int gb, const TileArgs& a, int grid, hipStream_t s);   // a whole deferred step over wave tiles
+int wstep_blocks_per_cu(int precision, int gb);
 hipError_t launch_wke(int precision, int ops, int gb, const TileArgs& a, int grid, hipStream_t s);   // KE passes over wave tiles
 int wke_blocks_per_cu(int precision, int ops, int gb);
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s);
@@ -326,6 +329,7 @@ struct tgnh_context {
     tgnh::XchgArgs self_x{};
     int resident_grid[5][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};   // step_kernel's grid by kind and hard wall
     int resident_share = 1, last_step_kind = 0;
+    int wresident_per_cu = 0, wresident_grid = 0;   // the same for wstep_kernel (0: none, or no wave tiles)
     int resident_per_cu = 0;          // work-groups of step_kernel per compute unit that the census at create found resident together (0: none -- the handle steps the DEFER_SCALE way)
     bool first_half_done = false;     // DEFER_SCALE: chain for the coming step's first half already run
     double time = 0;

@@ -575,7 +575,7 @@ __device__ __forceinline__ size_t row_word(const int r, const int j) {
 // Work-group reduction of the fp64 KE bins: 64-lane sums (wave_sum), then one LDS hop; one row of `partials` per work-group.
 // TAGGED: the row is read by another work-group of the SAME launch (step_kernel): every sum goes out as a cell of two
 // 8-byte words {32 bits of the double, tag} into a.rows -- data and "it is there" in one atomic store, as in the mailboxes.
-template <int PREC, int GB, bool TAGGED>
+template <int PREC, int GB, bool TAGGED, int NTH = TBLOCK>
 __device__ __forceinline__ void ke_reduce(const TileArgs& a, TileEnv<PREC, GB>& e, const unsigned tag = 0u, double* scratch = nullptr) {
     typedef TileEnv<PREC, GB> E;
     const int tid = e.tid, G = e.G;
@@ -607,16 +607,16 @@ __device__ __forceinline__ void ke_reduce(const TileArgs& a, TileEnv<PREC, GB>& 
     if (tid < GB + 2) {
         double s = 0.0;
 #pragma unroll
-        for (int w = 0; w < TBLOCK / 64; w++) s += sred[w * (GB + 2) + tid];   // fixed order
+        for (int w = 0; w < NTH / 64; w++) s += sred[w * (GB + 2) + tid];   // fixed order
         if (tid < GB) { if (tid < G) put(tid, s); }
         else put(G + (tid - GB), s);
     }
     if (GB == 0) {
         const double* w0 = e.wbins0;
-        for (int g = tid; g < G; g += TBLOCK) {
+        for (int g = tid; g < G; g += NTH) {
             double s = 0.0;
 #pragma unroll
-            for (int w = 0; w < TBLOCK / 64; w++) s += w0[w * G + g];     // fixed order
+            for (int w = 0; w < NTH / 64; w++) s += w0[w * G + g];     // fixed order
             put(g, s);
         }
     }
@@ -935,6 +935,166 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileAr
     }
 }
 
+// The meeting of step_kernel / wstep_kernel: every work-group hands in its row of kinetic-energy sums (tagged cells), work-group 0
+// collects them in a fixed order and sends the sums to the mailbox of every rank, one wavefront of every work-group waits for all
+// ranks' sums and runs both chain halves (the scale factors land in sh.s_scale).  `prefetch` is called between handing in the
+// row and the wait: the loads the second pass will need.  Returns false when an exchange timed out (nothing may be stored).
+struct MeetShared {
+    double* s_scale;                                  // [MAX_GROUPS + 2]
+    double (*s_part)[CHAIN_INLINE_SUM_NT];            // [TBLOCK / 64]
+    double* s_x;                                      // [64 + XCHG_MAX_WORLD * CHAIN_INLINE_SUM_NT]
+    int* s_go_p; unsigned* s_gen_p; unsigned long long* s_seq1_p;
+};
+template <int PREC, int GB, bool LEAN = false, int NTH = TBLOCK, typename Prefetch>
+__device__ __forceinline__ bool step_meet(const TileArgs& a, TileEnv<PREC, GB>& e, const unsigned gen0, const unsigned long long seq0,
+                                          Chain1Regs& creg, const MeetShared& sh, Prefetch&& prefetch) {
+    double* const s_scale = sh.s_scale; double (*const s_part)[CHAIN_INLINE_SUM_NT] = sh.s_part; double* const s_x = sh.s_x;
+    int& s_go = *sh.s_go_p; unsigned& s_gen = *sh.s_gen_p; unsigned long long& s_seq1 = *sh.s_seq1_p;
+    const int tid = threadIdx.x, G = a.num_groups, NT = G + 2, grid = (int)gridDim.x;
+    const bool chain_wave = tid < 64, leader = blockIdx.x == 0;
+    const int itg = tid & 63;
+    const ChainLayout& L = a.chain.L;
+    // the thermostat block has been read (its values are in registers) before this work-group's row is stored
+    if (chain_wave) asm volatile("" :: "v"(creg.eta), "v"(creg.etaDot0), "v"(creg.etaDot1), "v"(creg.etaDotDot), "v"(creg.etaMass), "v"(creg.nkbt) : "memory");
+    ke_reduce<PREC, GB, true, NTH>(a, e, gen0 + 1u, s_x);
+    TRACE(2);
+    // what the second pass needs of the held tile beyond what is in registers (its positions): issued now, needed after the meeting
+    prefetch();
+    // ... and what the chain can form without the sums (index map, constants, 1/Q, expfac): done while the others still work
+    // (single precision: its 16 registers there would cost the kernel its fourth work-group per compute unit)
+    constexpr bool EARLY_PRE = PREC != TGNH_PREC_SINGLE && !LEAN;      // (LEAN: wstep_kernel, which lives on a small register count)
+    Chain1Pre cpre{};
+    if (EARLY_PRE && chain_wave && !L.c1_quirk) cpre = chain1_prepare(a.chain, creg, itg);
+
+    // ---- meet: work-group 0 collects the rows.  Thread t owns rows t, t + 256, ...: it polls their cells until all
+    // carry this launch's tag and adds them in row order; then 64-lane sums and one LDS hop, fixed order throughout.
+    if (tid == 0) { s_gen = gen0; s_seq1 = seq0 + 1ull; }
+    __syncthreads();
+    const unsigned long long want = (unsigned long long)(s_gen + 1u);
+    if (leader) {
+        unsigned long long* const my_peer = xchg_peer_of(a.chain.x, tid);   // for the send: fetched before the collection, not after
+        constexpr int NTM = GB + 2;                        // NT = G + 2 <= GB + 2: the register arrays follow the instantiation
+        double acc[NTM];
+#pragma unroll
+        for (int b = 0; b < NTM; b++) acc[b] = 0.0;
+        bool ok = true;
+        TRACE(6);
+        // RB rows of this thread per batch of loads (all of them for the resident grid of 768 when G = 1): once the last row
+        // is there, one more round trip sees everything -- polled row after row, a thread whose first row came last paid
+        // a round trip for each of the others behind it.  CH thermostats of a row per batch: the registers a batch takes
+        // (2 x CH x RB words) do not grow with the number of temperature groups.  A row seen complete is not read again: a
+        // round waits for all of its loads together (~1 us with everything polled), and the round that finally sees the last
+        // row is a short one when it polls the stragglers only (last row -> all seen 1.6 instead of 2.3 us at 625 k slots).
+        constexpr int RB = (GB == 1 && !LEAN) ? 3 : 1, CH = 3;
+#pragma unroll 1
+        for (int r0 = tid; r0 < grid && ok; r0 += RB * NTH) {
+#pragma unroll 1
+            for (int b0 = 0; b0 < NT && ok; b0 += CH) {
+                unsigned long long w[RB][2 * CH];
+                bool have[RB];                              // a row seen complete is not read again: later rounds poll the stragglers only
+#pragma unroll
+                for (int k = 0; k < RB; k++) have[k] = r0 + k * NTH >= grid;
+                unsigned n = 0;
+                for (;;) {
+#pragma unroll
+                    for (int k = 0; k < RB; k++) {
+                        if (!have[k]) {
+                            const unsigned long long* cell = a.rows + row_word(r0 + k * NTH, 2 * b0);   // the lanes of a load read consecutive words
+#pragma unroll
+                            for (int b = 0; b < 2 * CH; b++) if (b0 + b / 2 < NT) w[k][b] = xchg_ld(cell + b * 64);
+                        }
+                    }
+                    bool all = true;
+#pragma unroll
+                    for (int k = 0; k < RB; k++) {
+                        if (!have[k]) {
+                            bool row = true;
+#pragma unroll
+                            for (int b = 0; b < 2 * CH; b++) if (b0 + b / 2 < NT) row = row && (w[k][b] >> 32) == want;
+                            have[k] = row;
+                        }
+                        all = all && have[k];
+                    }
+                    if (all) break;
+                    if (++n > XCHG_SPIN_LIMIT) { ok = false; break; }
+                }
+#pragma unroll
+                for (int k = 0; k < RB; k++)                // row order: r0, r0 + 256, ...
+#pragma unroll
+                    for (int b = 0; b < CH; b++)
+                        if (b0 + b < NT && r0 + k * NTH < grid) {
+                            const double v = __longlong_as_double((long long)((w[k][2 * b + 1] << 32) | (w[k][2 * b] & 0xffffffffull)));
+#pragma unroll
+                            for (int t = 0; t < NTM; t++) acc[t] += (t == b0 + b) ? v : 0.0;
+                        }
+            }
+        }
+        TRACE(10);
+        if (!ok) {                                         // a work-group never handed in its row: nobody goes on (no send below)
+            atomicOr(a.status, 8u);
+            __hip_atomic_store(a.chain.x.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const double* big = a.partials + (size_t)GRID_CAP * NT;               // rows of big_com_kernel (an earlier launch)
+        for (int r = tid; r < a.chain.nbig; r += NTH)
+#pragma unroll
+            for (int b = 0; b < NTM; b++) if (b < NT) acc[b] += big[(size_t)r * NT + b];
+#pragma unroll
+        for (int b = 0; b < NTM; b++) {
+            if (b < NT) {
+                const double t = wave_sum(acc[b]);
+                if ((tid & 63) == 0) s_part[tid >> 6][b] = t;
+            }
+        }
+        // (the barrier of the hand-over doubles as the vote: one thread that gave up on a row stops the whole send -- incomplete
+        // sums under a valid tag would let every waiter, here and on the peer ranks, integrate with wrong scale factors; without
+        // the send they time out or see the latch, and nothing is stored)
+        const bool all_ok = __syncthreads_and(ok ? 1 : 0) != 0;
+        TRACE(7);
+        // the send (xchg_send's stores, tgnh_chain_device.h), straight from the four wavefronts' partial sums: every storing
+        // thread adds them itself, in wavefront order -- no second hand-over through LDS, no second barrier on this path
+        const XchgArgs& x = a.chain.x;
+        const unsigned long long seq = s_seq1, stag = (seq & 0xffffffffull) << 32;
+        if (tid == 0) { a.sync[1] = s_gen + 1u; *x.seq = seq; }      // the next launch's rows carry the next tag
+        const int tpp = NTH / x.world;
+        if (all_ok && tid < tpp * x.world) {
+            unsigned long long* const base = my_peer + xchg_cell(x, (unsigned)(seq & 1ull), x.rank, 0, 0);
+            for (int q = tid / x.world; q < NT * XCHG_REPLICAS; q += tpp) {
+                const int copy = q / NT, i = q - copy * NT;
+                double v = 0.0;
+#pragma unroll
+                for (int w = 0; w < NTH / 64; w++) v += s_part[w][i];
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                unsigned long long* cell = base + (size_t)copy * XCHG_REPLICA_U64 + (size_t)i * XCHG_CELL_U64;
+                __hip_atomic_store(cell, stag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(cell + 1, stag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        TRACE(13);
+    }
+    if (chain_wave) {
+        bool dead = false;                                 // an exchange has timed out, now or earlier (the latch)
+        const double mine = xchg_wait_sum<true>(a.chain.x, NT, itg, s_x + 64, seq0 + 1ull, &dead);
+        TRACE(8);
+        if (itg == 0) s_go = dead ? 0 : 1;
+        if (!dead) {
+            const bool write = leader;
+            creg.ke = mine;
+            if (write && itg < NT) a.st_out[L.off_ke_red + itg] = mine;
+            if (write) {                                   // Cu :493-497 (work-group 0 only: the others go straight on to the chain)
+                const double kesum = wave_sum(itg < NT ? mine : 0.0);
+                if (itg == 63) a.st_out[L.off_kesum] = 0.5 * kesum;
+            }
+            if (itg < NT) {
+                if (L.c1_quirk) chain1q_run(a.chain, creg, a.st_out, write, s_scale, itg);
+                else chain1_finish(a.chain, creg, EARLY_PRE ? cpre : chain1_prepare(a.chain, creg, itg), a.st_out, write, s_scale, itg);
+            }
+        }
+    }
+    __syncthreads();
+    return s_go != 0;
+}
+
+
 // ---------------------------------------------------------------------------
 // step_kernel: a whole time step of the deferred pass structure in ONE launch (TGNH_FLAG_RESIDENT_STEP).
 //
@@ -1039,144 +1199,9 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
     }
     const int tt_last = tt;                                // stays in `cur`; its velocity image and COM table stay in LDS
     TRACE(1);
-    // the thermostat block has been read (its values are in registers) before this work-group's row is stored
-    if (chain_wave) asm volatile("" :: "v"(creg.eta), "v"(creg.etaDot0), "v"(creg.etaDot1), "v"(creg.etaDotDot), "v"(creg.etaMass), "v"(creg.nkbt) : "memory");
-    ke_reduce<PREC, GB, true>(a, e, gen0 + 1u, s_x);
-    TRACE(2);
-    // the held tile's positions: issued now, needed after the meeting
-    tile_load<PREC, STEP_OPS2, STEP_OPS1>(a, tile_of(tt_last), cur);
-    // ... and what the chain can form without the sums (index map, constants, 1/Q, expfac): done while the others still work
-    // (single precision: its 16 registers there would cost the kernel its fourth work-group per compute unit)
-    constexpr bool EARLY_PRE = PREC != TGNH_PREC_SINGLE;
-    Chain1Pre cpre{};
-    if (EARLY_PRE && chain_wave && !L.c1_quirk) cpre = chain1_prepare(a.chain, creg, itg);
-
-    // ---- meet: work-group 0 collects the rows.  Thread t owns rows t, t + 256, ...: it polls their cells until all
-    // carry this launch's tag and adds them in row order; then 64-lane sums and one LDS hop, fixed order throughout.
-    if (tid == 0) { s_gen = gen0; s_seq1 = seq0 + 1ull; }
-    __syncthreads();
-    const unsigned long long want = (unsigned long long)(s_gen + 1u);
-    if (leader) {
-        unsigned long long* const my_peer = xchg_peer_of(a.chain.x, tid);   // for the send: fetched before the collection, not after
-        constexpr int NTM = GB + 2;                        // NT = G + 2 <= GB + 2: the register arrays follow the instantiation
-        double acc[NTM];
-#pragma unroll
-        for (int b = 0; b < NTM; b++) acc[b] = 0.0;
-        bool ok = true;
-        TRACE(6);
-        // RB rows of this thread per batch of loads (all of them for the resident grid of 768 when G = 1): once the last row
-        // is there, one more round trip sees everything -- polled row after row, a thread whose first row came last paid
-        // a round trip for each of the others behind it.  CH thermostats of a row per batch: the registers a batch takes
-        // (2 x CH x RB words) do not grow with the number of temperature groups.  A row seen complete is not read again: a
-        // round waits for all of its loads together (~1 us with everything polled), and the round that finally sees the last
-        // row is a short one when it polls the stragglers only (last row -> all seen 1.6 instead of 2.3 us at 625 k slots).
-        constexpr int RB = GB == 1 ? 3 : 1, CH = 3;
-#pragma unroll 1
-        for (int r0 = tid; r0 < grid && ok; r0 += RB * TBLOCK) {
-#pragma unroll 1
-            for (int b0 = 0; b0 < NT && ok; b0 += CH) {
-                unsigned long long w[RB][2 * CH];
-                bool have[RB];                              // a row seen complete is not read again: later rounds poll the stragglers only
-#pragma unroll
-                for (int k = 0; k < RB; k++) have[k] = r0 + k * TBLOCK >= grid;
-                unsigned n = 0;
-                for (;;) {
-#pragma unroll
-                    for (int k = 0; k < RB; k++) {
-                        if (!have[k]) {
-                            const unsigned long long* cell = a.rows + row_word(r0 + k * TBLOCK, 2 * b0);   // the lanes of a load read consecutive words
-#pragma unroll
-                            for (int b = 0; b < 2 * CH; b++) if (b0 + b / 2 < NT) w[k][b] = xchg_ld(cell + b * 64);
-                        }
-                    }
-                    bool all = true;
-#pragma unroll
-                    for (int k = 0; k < RB; k++) {
-                        if (!have[k]) {
-                            bool row = true;
-#pragma unroll
-                            for (int b = 0; b < 2 * CH; b++) if (b0 + b / 2 < NT) row = row && (w[k][b] >> 32) == want;
-                            have[k] = row;
-                        }
-                        all = all && have[k];
-                    }
-                    if (all) break;
-                    if (++n > XCHG_SPIN_LIMIT) { ok = false; break; }
-                }
-#pragma unroll
-                for (int k = 0; k < RB; k++)                // row order: r0, r0 + 256, ...
-#pragma unroll
-                    for (int b = 0; b < CH; b++)
-                        if (b0 + b < NT && r0 + k * TBLOCK < grid) {
-                            const double v = __longlong_as_double((long long)((w[k][2 * b + 1] << 32) | (w[k][2 * b] & 0xffffffffull)));
-#pragma unroll
-                            for (int t = 0; t < NTM; t++) acc[t] += (t == b0 + b) ? v : 0.0;
-                        }
-            }
-        }
-        TRACE(10);
-        if (!ok) {                                         // a work-group never handed in its row: nobody goes on (no send below)
-            atomicOr(a.status, 8u);
-            __hip_atomic_store(a.chain.x.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const double* big = a.partials + (size_t)GRID_CAP * NT;               // rows of big_com_kernel (an earlier launch)
-        for (int r = tid; r < a.chain.nbig; r += TBLOCK)
-#pragma unroll
-            for (int b = 0; b < NTM; b++) if (b < NT) acc[b] += big[(size_t)r * NT + b];
-#pragma unroll
-        for (int b = 0; b < NTM; b++) {
-            if (b < NT) {
-                const double t = wave_sum(acc[b]);
-                if ((tid & 63) == 0) s_part[tid >> 6][b] = t;
-            }
-        }
-        // (the barrier of the hand-over doubles as the vote: one thread that gave up on a row stops the whole send -- incomplete
-        // sums under a valid tag would let every waiter, here and on the peer ranks, integrate with wrong scale factors; without
-        // the send they time out or see the latch, and nothing is stored)
-        const bool all_ok = __syncthreads_and(ok ? 1 : 0) != 0;
-        TRACE(7);
-        // the send (xchg_send's stores, tgnh_chain_device.h), straight from the four wavefronts' partial sums: every storing
-        // thread adds them itself, in wavefront order -- no second hand-over through LDS, no second barrier on this path
-        const XchgArgs& x = a.chain.x;
-        const unsigned long long seq = s_seq1, stag = (seq & 0xffffffffull) << 32;
-        if (tid == 0) { a.sync[1] = s_gen + 1u; *x.seq = seq; }      // the next launch's rows carry the next tag
-        const int tpp = TBLOCK / x.world;
-        if (all_ok && tid < tpp * x.world) {
-            unsigned long long* const base = my_peer + xchg_cell(x, (unsigned)(seq & 1ull), x.rank, 0, 0);
-            for (int q = tid / x.world; q < NT * XCHG_REPLICAS; q += tpp) {
-                const int copy = q / NT, i = q - copy * NT;
-                double v = 0.0;
-#pragma unroll
-                for (int w = 0; w < TBLOCK / 64; w++) v += s_part[w][i];
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-                unsigned long long* cell = base + (size_t)copy * XCHG_REPLICA_U64 + (size_t)i * XCHG_CELL_U64;
-                __hip_atomic_store(cell, stag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(cell + 1, stag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-        TRACE(13);
-    }
-    if (chain_wave) {
-        bool dead = false;                                 // an exchange has timed out, now or earlier (the latch)
-        const double mine = xchg_wait_sum<true>(a.chain.x, NT, itg, s_x + 64, seq0 + 1ull, &dead);
-        TRACE(8);
-        if (itg == 0) s_go = dead ? 0 : 1;
-        if (!dead) {
-            const bool write = leader;
-            creg.ke = mine;
-            if (write && itg < NT) a.st_out[L.off_ke_red + itg] = mine;
-            if (write) {                                   // Cu :493-497 (work-group 0 only: the others go straight on to the chain)
-                const double kesum = wave_sum(itg < NT ? mine : 0.0);
-                if (itg == 63) a.st_out[L.off_kesum] = 0.5 * kesum;
-            }
-            if (itg < NT) {
-                if (L.c1_quirk) chain1q_run(a.chain, creg, a.st_out, write, s_scale, itg);
-                else chain1_finish(a.chain, creg, EARLY_PRE ? cpre : chain1_prepare(a.chain, creg, itg), a.st_out, write, s_scale, itg);
-            }
-        }
-    }
-    __syncthreads();
-    if (!s_go) return;                                     // an exchange timed out: reported by the status word; nothing is stored
+    MeetShared sh{s_scale, s_part, s_x, &s_go, &s_gen, &s_seq1};
+    if (!step_meet<PREC, GB>(a, e, gen0, seq0, creg, sh, [&] { tile_load<PREC, STEP_OPS2, STEP_OPS1>(a, tile_of(tt_last), cur); }))
+        return;                                            // an exchange timed out: reported by the status word; nothing is stored
     e.s_com = (mixed)s_scale[G]; e.s_drude = (mixed)s_scale[G + 1];
     TRACE(9);
 
@@ -1187,6 +1212,318 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
         if (tt - grid < 0) break;
         tt -= grid;
         tile_load<PREC, STEP_OPS2>(a, tile_of(tt), cur);
+    }
+    TRACE(15);
+}
+
+// ---------------------------------------------------------------------------
+// wstep_kernel: step_kernel's whole deferred time step (STEP_DEFER) over WAVE tiles -- wke_kernel's structure for both passes.
+//
+// A wavefront owns <= 64 consecutive slots and a private LDS image; nothing in a pass waits for another wavefront.  What that
+// buys at shard sizes: the kernel needs half of step_kernel's registers (one slot per lane, no second copy of a 512-slot
+// tile's arrays), so 2048 work-groups = 524 k slots are resident at once instead of 393 k -- at 625 k slots five wavefronts of
+// six hold ONE tile each for the whole step -- and for a held tile the second pass starts from registers: its kicked
+// velocities, forces, index word, mass and centre-of-mass velocity are pass 1's, its partner's velocity is still in the
+// wavefront's image, its positions were fetched before the meeting.  Same meeting (step_meet), same arithmetic per slot as
+// tile_body / wke_kernel, same fixed order of every sum.  Topologies without wave tiles (a molecule longer than a wavefront,
+// more than 8 temperature groups) and the other step kinds run step_kernel.
+//   pass 1   half kick (unstored) + kinetic-energy sums            (Cu :384-388, :474-488)
+//   meet     rows -> work-group 0 -> mailboxes -> both chain halves (Cu :433-652 twice)
+//   pass 2   the kick again, rescale, half kick, drift, hard wall   (Cu :351-376 ; K :249-301, :307-365, :435-466, :471-574)
+// ---------------------------------------------------------------------------
+template <int PREC> struct WStepIn {
+    typename Prec<PREC>::mixed4 v;
+    uint32_t meta;
+    long long fx, fy, fz;
+    typename Prec<PREC>::real4 p;
+    float4 c;
+    // formed by the first half of the work on a tile (prepare): mass, centre-of-mass velocity of the slot's molecule
+    typename Prec<PREC>::mixed mass, cx, cy, cz;
+};
+
+template <int PREC, int GB>
+__global__ __launch_bounds__(WBLOCK) void wstep_kernel(const TileArgs a) {
+    typedef typename Prec<PREC>::real real;
+    typedef typename Prec<PREC>::mixed mixed;
+    typedef typename Prec<PREC>::real4 real4;
+    typedef typename Prec<PREC>::mixed4 mixed4;
+    static_assert(GB > 0, "register bins only");
+    __shared__ double s_scale[MAX_GROUPS + 2];
+    __shared__ double s_part[WBLOCK / 64][CHAIN_INLINE_SUM_NT];
+    __shared__ double s_x[64 + XCHG_MAX_WORLD * CHAIN_INLINE_SUM_NT];
+    __shared__ int s_go;
+    __shared__ unsigned s_gen;
+    __shared__ unsigned long long s_seq1;
+    __shared__ mixed s_img[WBLOCK / 64][7][WAVE_SLOTS];          // per wavefront: velocity x, y, z, mass; position x, y, z (hard wall)
+    const int tid = threadIdx.x, lane = tid & 63, G = a.num_groups, NT = G + 2;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool chain_wave = tid < 64;
+    const int itg = tid & 63;
+    if (a.census) {                                        // residency check at tgnh_create, as step_kernel's
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&a.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned n = 0;
+            while (__hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && ++n < CENSUS_SPIN_LIMIT)
+                __builtin_amdgcn_s_sleep(16);
+            if (__hip_atomic_load(&a.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) atomicOr(&a.sync[3], 1u);
+        }
+        return;
+    }
+    mixed* const ix = s_img[wv][0]; mixed* const iy = s_img[wv][1]; mixed* const iz = s_img[wv][2]; mixed* const im = s_img[wv][3];
+    mixed* const jx = s_img[wv][4]; mixed* const jy = s_img[wv][5]; mixed* const jz = s_img[wv][6];
+    const bool use_com = a.use_com != 0, hardwall = a.hardwall != 0;
+    const mixed dt = (mixed)a.dt, fscale = (mixed)(0.5 * a.dt / 4294967296.0);     // Cu :295
+    mixed4* __restrict__ velm = reinterpret_cast<mixed4*>(a.velm);
+    real4* __restrict__ posq = reinterpret_cast<real4*>(a.posq);
+    float4* __restrict__ pcorr = reinterpret_cast<float4*>(a.posq_corr);
+    TileEnv<PREC, GB> e;                                   // the kinetic-energy bins, in the shape ke_reduce takes them
+    e.tid = tid; e.G = G; e.smem = nullptr; e.wbins0 = nullptr; e.s_scale = s_scale;
+    e.clear_ke();
+    auto wfence = [] {                                     // a wavefront's LDS operations are processed in order: only the compiler is held
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    // launch number, exchange number and the thermostat state: read before anything is handed in (step_kernel)
+    unsigned gen0 = 0;
+    unsigned long long seq0 = 0;
+    Chain1Regs creg{};
+    if (chain_wave) {
+        gen0 = __hip_atomic_load(&a.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seq0 = __hip_atomic_load(a.chain.x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (itg < NT) creg = chain1_load(a.chain, a.st_in, itg);
+    }
+
+    const int nw = a.num_wtiles, stride = (int)gridDim.x * (WBLOCK / 64);
+    struct Bounds { int ws, maxn, n; };
+    auto bounds = [&](const int ww, Bounds& b) {
+        const int2* t = a.wave_tile + (a.reverse ? nw - 1 - ww : ww);
+        b.ws = t[0].x; b.maxn = t[0].y; b.n = t[1].x - b.ws;
+    };
+    auto load_vf = [&](const Bounds& b, WStepIn<PREC>& in) {          // what pass 1 needs
+        const int idx = b.ws + lane;
+        if (lane < b.n) {
+            in.v = reinterpret_cast<const mixed4*>(a.velm)[idx];
+            in.meta = a.wmeta[idx];
+            in.fx = a.force[idx]; in.fy = a.force[idx + a.padded]; in.fz = a.force[idx + 2 * a.padded];
+        } else {
+            in.v = mk4((mixed)0, (mixed)0, (mixed)0, (mixed)0);
+            in.meta = 64u << 10;
+            in.fx = in.fy = in.fz = 0;
+        }
+    };
+    auto load_x = [&](const Bounds& b, WStepIn<PREC>& in) {           // ... and what pass 2 needs on top
+        const int idx = b.ws + lane;
+        if (lane < b.n) {
+            in.p = reinterpret_cast<const real4*>(a.posq)[idx];
+            if (PREC == TGNH_PREC_MIXED) in.c = reinterpret_cast<const float4*>(a.posq_corr)[idx];      // K :443-445
+        }
+    };
+    // first half of the work on a tile: mass, the pending half kick, the wavefront's image, the molecule's centre-of-mass
+    // velocity; KE: this tile's kinetic energies go into the bins (pass 1)
+    auto prepare = [&](WStepIn<PREC>& t, const Bounds& bd, const bool ke) {
+        mixed4& v = t.v;
+        const uint32_t m = t.meta;
+        t.mass = v.w != 0 ? rcp_(v.w) : (mixed)0;
+        {                                                                // A7 (Cu :384-388), per particle; w = 0: c = 0, v unchanged
+            const mixed c = fscale * v.w;
+            v.x += c * force_as(t.fx, (mixed)0);
+            v.y += c * force_as(t.fy, (mixed)0);
+            v.z += c * force_as(t.fz, (mixed)0);
+        }
+        ix[lane] = v.x; iy[lane] = v.y; iz[lane] = v.z; im[lane] = t.mass;
+        wfence();
+        mixed cx = 0, cy = 0, cz = 0;
+        if (use_com) {                                                   // K :86-111: every lane sums its own molecule, in slot order
+            const int j = (int)((m >> 17) & 63u), n1 = (int)((m >> 23) & 63u);
+            const int first = lane - j;
+            mixed px = 0, py = 0, pz = 0, pm = 0;
+            for (int k = 0; k < bd.maxn; k++) {
+                if (k <= n1) {
+                    const mixed um = im[first + k];
+                    px += ix[first + k] * um; py += iy[first + k] * um; pz += iz[first + k] * um; pm += um;
+                }
+            }
+            const mixed wq = rcp_(pm);
+            cx = px * wq; cy = py * wq; cz = pz * wq;
+            if (ke && j == 0 && lane < bd.n)                             // M v_com^2 (K :154)
+                e.ke_com += ((double)cx * cx + (double)cy * cy + (double)cz * cz) * (double)pm;
+        }
+        t.cx = cx; t.cy = cy; t.cz = cz;
+        if (ke) {                                                        // bins, as wke_kernel (K :138-200)
+            const uint32_t role = m & 3u, g = (m >> 2) & 255u;
+            const double rx = v.x - cx, ry = v.y - cy, rz = v.z - cz;
+            double val = v.w != 0 ? (rx * rx + ry * ry + rz * rz) * (double)t.mass : 0.0;
+            if (role == ROLE_DRUDE) {
+                const int pl = lane + (int)((m >> 10) & 127u) - 64;
+                const double dx = ix[pl] - v.x, dy = iy[pl] - v.y, dz = iz[pl] - v.z;
+                const double mass1 = t.mass, mass2 = im[pl];
+                const double mu = mass1 * mass2 * rcp_(mass1 + mass2);
+                const double d = (dx * dx + dy * dy + dz * dz) * mu;
+                e.ke_drude += d;
+                val -= d;
+            }
+#pragma unroll
+            for (int b = 0; b < GB; b++) e.ke_g[b] += (g == (uint32_t)b) ? val : 0.0;
+        }
+    };
+    // second half (pass 2): rescale, half kick, drift, hard wall, stores.  The image holds the tile's kicked velocities and masses.
+    auto finish = [&](WStepIn<PREC>& t, const Bounds& bd) {
+        mixed4 v = t.v;
+        const uint32_t m = t.meta;
+        const uint32_t role = m & 3u, g = (m >> 2) & 255u;
+        const int pl = lane + (int)((m >> 10) & 127u) - 64;
+        const mixed mass = t.mass, cx = t.cx, cy = t.cy, cz = t.cz;
+        const mixed s_com = (mixed)s_scale[G], s_drude = (mixed)s_scale[G + 1], s_g = (mixed)s_scale[g];
+        mixed px = t.p.x, py = t.p.y, pz = t.p.z;
+        const real pq = t.p.w;
+        if (PREC == TGNH_PREC_MIXED) { px += (mixed)t.c.x; py += (mixed)t.c.y; pz += (mixed)t.c.z; }
+        // ---- A6: rescale (K :249-301 ; Ref :516-541), tile_body's expressions
+        if (role == ROLE_NORMAL) {
+            if (v.w != 0) {
+                const mixed rx = v.x - cx, ry = v.y - cy, rz = v.z - cz;
+                v.x = s_g * rx + s_com * (v.x - rx);
+                v.y = s_g * ry + s_com * (v.y - ry);
+                v.z = s_g * rz + s_com * (v.z - rz);
+            }
+        } else {
+            const mixed ux = ix[pl], uy = iy[pl], uz = iz[pl], um = im[pl];      // partner velocity and mass
+            const mixed rsx = v.x - cx, rsy = v.y - cy, rsz = v.z - cz;
+            const mixed rpx = ux - cx, rpy = uy - cy, rpz = uz - cz;
+            const mixed invTot = rcp_(mass + um);
+            const mixed msf = invTot * mass, mpf = invTot * um;
+            const mixed sdp = s_drude * mpf;
+            v.x = s_g * (rsx * msf + rpx * mpf) + sdp * (rsx - rpx) + s_com * (v.x - rsx);
+            v.y = s_g * (rsy * msf + rpy * mpf) + sdp * (rsy - rpy) + s_com * (v.y - rsy);
+            v.z = s_g * (rsz * msf + rpz * mpf) + sdp * (rsz - rpz) + s_com * (v.z - rsz);
+        }
+        // ---- A7: half kick (K :307-365) and A8: drift (Ref :253-258 ; K :322-324, :450-452)
+        if (v.w != 0) {
+            const mixed c = fscale * v.w;
+            v.x += c * force_as(t.fx, (mixed)0);
+            v.y += c * force_as(t.fy, (mixed)0);
+            v.z += c * force_as(t.fz, (mixed)0);
+            px += dt * v.x; py += dt * v.y; pz += dt * v.z;
+        }
+        // ---- A10: hard wall (K :471-574 ; Ref :298-363), tile_body's arithmetic from the lane's own point of view
+        if (hardwall) {
+            wfence();                                                    // every lane has read its partner's old velocity
+            ix[lane] = v.x; iy[lane] = v.y; iz[lane] = v.z;
+            jx[lane] = px; jy[lane] = py; jz[lane] = pz;
+            wfence();
+            if (role != ROLE_NORMAL) {
+                const mixed maxd = (mixed)a.max_dist, hws = (mixed)a.hw_scale;
+                const mixed sxd = px - jx[pl], syd = py - jy[pl], szd = pz - jz[pl];     // self - partner
+                const mixed d2 = sxd * sxd + syd * syd + szd * szd;
+                if (d2 > maxd * maxd) {
+                    const mixed4 uv = mk4(ix[pl], iy[pl], iz[pl], im[pl]);
+                    const bool is_d = role == ROLE_DRUDE;
+                    const mixed4 vel1 = is_d ? v : uv, vel2 = is_d ? uv : v;
+                    const mixed dx = is_d ? sxd : -sxd, dy = is_d ? syd : -syd, dz = is_d ? szd : -szd;   // Drude - parent (K :487)
+                    const mixed r = sqrt_(d2);
+                    const mixed rInv = rcp_(r);
+                    if (rInv * maxd < (mixed)0.5) atomicOr(a.status, 1u);     // Ref :311-312
+                    const mixed bx = dx * rInv, by = dy * rInv, bz = dz * rInv;
+                    const mixed mass1 = is_d ? mass : uv.w, mass2 = is_d ? uv.w : mass;
+                    const mixed deltaR = r - maxd;
+                    mixed deltaT = dt;
+                    mixed dotvr1 = vel1.x * bx + vel1.y * by + vel1.z * bz;
+                    const mixed vp1x = vel1.x - bx * dotvr1, vp1y = vel1.y - by * dotvr1, vp1z = vel1.z - bz * dotvr1;
+                    const mixed invTot = rcp_(mass1 + mass2);
+                    mixed dotvr2 = vel2.x * bx + vel2.y * by + vel2.z * bz;
+                    const mixed vp2x = vel2.x - bx * dotvr2, vp2y = vel2.y - by * dotvr2, vp2z = vel2.z - bz * dotvr2;
+                    const mixed vbCMass = (mass1 * dotvr1 + mass2 * dotvr2) * invTot;
+                    dotvr1 -= vbCMass;
+                    dotvr2 -= vbCMass;
+                    if (dotvr1 != dotvr2) deltaT = deltaR / abs_(dotvr1 - dotvr2);
+                    if (deltaT > dt) deltaT = dt;
+                    const mixed vBond = hws / sqrt_(mass1);
+                    dotvr1 = -dotvr1 * vBond * mass2 * invTot / abs_(dotvr1);
+                    dotvr2 = -dotvr2 * vBond * mass1 * invTot / abs_(dotvr2);
+                    const mixed dr1 = -deltaR * mass2 * invTot + deltaT * dotvr1;
+                    const mixed dr2 = deltaR * mass1 * invTot + deltaT * dotvr2;
+                    dotvr1 += vbCMass;
+                    dotvr2 += vbCMass;
+                    if (is_d) {
+                        px += bx * dr1; py += by * dr1; pz += bz * dr1;
+                        v.x = vp1x + bx * dotvr1; v.y = vp1y + by * dotvr1; v.z = vp1z + bz * dotvr1;
+                    } else {
+                        px += bx * dr2; py += by * dr2; pz += bz * dr2;
+                        v.x = vp2x + bx * dotvr2; v.y = vp2y + by * dotvr2; v.z = vp2z + bz * dotvr2;
+                    }
+                }
+            }
+        }
+        wfence();                                                        // the next tile's image comes after this tile's reads
+        if (lane < bd.n) {
+            const int idx = bd.ws + lane;
+            velm[idx] = v;
+            if (PREC == TGNH_PREC_MIXED) {                               // K :457-458
+                const float hx = (float)px, hy = (float)py, hz = (float)pz;
+                posq[idx] = mk4((real)hx, (real)hy, (real)hz, pq);
+                pcorr[idx] = make_float4((float)(px - hx), (float)(py - hy), (float)(pz - hz), 0.0f);
+            } else {
+                posq[idx] = mk4((real)px, (real)py, (real)pz, pq);
+            }
+        }
+    };
+
+    // ---- pass 1: this wavefront's tiles w0, w0 + stride, ...; the next tile's loads in flight while one is worked on
+    TRACE(0);
+    const int w0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (WBLOCK / 64) + wv);
+    const bool have = w0 < nw;                             // (a wavefront beyond the last tile only takes part in the meeting)
+    int w = w0;
+    // One register image: no tile is loaded ahead of the one being worked on.  What hides a tile's load latency is the other
+    // wavefronts of the SIMD -- six of them at this register count, against four with a second image (measured: the second
+    // image bought nothing at 4 per SIMD, and at 625 k slots six per SIMD means no wavefront walks more than two tiles).
+    // Tile bounds are scalar loads one tile ahead of their use.
+    Bounds b0{}, b1{};
+    WStepIn<PREC> cur;
+    if (have) {
+        bounds(w, b0);
+        if (w + stride < nw) bounds(w + stride, b1);
+        load_vf(b0, cur);
+    }
+    while (have) {
+#ifdef TGNH_TRACE
+        if (w == w0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TRACE(3); }
+#endif
+        prepare(cur, b0, true);
+#ifdef TGNH_TRACE
+        if (w == w0) TRACE(4);
+#endif
+        if (w + stride >= nw) break;
+        wfence();                                          // (this tile's image reads are done before the next tile's image is stored)
+        w += stride;
+        b0 = b1;
+        if (w + stride < nw) bounds(w + stride, b1);
+        load_vf(b0, cur);
+    }
+    const int w_last = w;                                  // stays in `cur` (kicked velocities, mass, v_com), its image in LDS
+    TRACE(1);
+    MeetShared sh{s_scale, s_part, s_x, &s_go, &s_gen, &s_seq1};
+    if (!step_meet<PREC, GB, true, WBLOCK>(a, e, gen0, seq0, creg, sh, [&] {
+            if (have) {
+                load_x(b0, cur);
+                if (w_last - stride >= 0) bounds(w_last - stride, b1);        // the way back: known long before it is needed
+            }
+        })) return;
+
+    // ---- pass 2, backwards from the held tile
+    TRACE(9);
+    if (have) {
+        w = w_last;
+        finish(cur, b0);                                   // the held tile: everything but its positions is pass 1's
+        TRACE(5);
+        while (w - stride >= 0) {
+            w -= stride;
+            b0 = b1;
+            if (w - stride >= 0) bounds(w - stride, b1);
+            load_vf(b0, cur); load_x(b0, cur);
+            prepare(cur, b0, false);
+            finish(cur, b0);
+        }
     }
     TRACE(15);
 }
@@ -1616,6 +1953,27 @@ static step_fn_t step_fn(int precision, int gb, int kind) {
         case TGNH_PREC_DOUBLE: return step_fn_kind<TGNH_PREC_DOUBLE>(kind, gb);
         default: return nullptr;
     }
+}
+static step_fn_t wstep_fn(int precision, int gb) {
+    if (gb == 0) return nullptr;
+    switch (precision) {
+        case TGNH_PREC_SINGLE: return gb <= 1 ? wstep_kernel<TGNH_PREC_SINGLE, 1> : gb <= 4 ? wstep_kernel<TGNH_PREC_SINGLE, 4> : wstep_kernel<TGNH_PREC_SINGLE, 8>;
+        case TGNH_PREC_MIXED: return gb <= 1 ? wstep_kernel<TGNH_PREC_MIXED, 1> : gb <= 4 ? wstep_kernel<TGNH_PREC_MIXED, 4> : wstep_kernel<TGNH_PREC_MIXED, 8>;
+        case TGNH_PREC_DOUBLE: return gb <= 1 ? wstep_kernel<TGNH_PREC_DOUBLE, 1> : gb <= 4 ? wstep_kernel<TGNH_PREC_DOUBLE, 4> : wstep_kernel<TGNH_PREC_DOUBLE, 8>;
+        default: return nullptr;
+    }
+}
+hipError_t launch_wstep(int precision, int gb, const TileArgs& a, int grid, hipStream_t s) {
+    step_fn_t fn = wstep_fn(precision, gb);
+    if (!fn) return hipErrorInvalidValue;
+    TGNH_LAUNCH(fn, dim3(grid), dim3(WBLOCK), 0, s, a);
+    return hipGetLastError();
+}
+int wstep_blocks_per_cu(int precision, int gb) {
+    step_fn_t fn = wstep_fn(precision, gb);
+    int n = 0;
+    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(fn), WBLOCK, 0) != hipSuccess) return 0;
+    return n;
 }
 int step_kind_ops2(int kind) { return step_ops2(kind); }
 hipError_t launch_step(int precision, int gb, int kind, const TileArgs& a, int grid, size_t lds, hipStream_t s) {

@@ -11,7 +11,7 @@ from openmm_drudenose_amd import synth, _lib
 from openmm_drudenose_amd.drudetgnhplugin import DrudeTGNHIntegrator, HipContext, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP
 
 NAMES = {0: "entry", 1: "pass 1 done", 2: "row handed in", 6: "poll starts*", 10: "rows all seen*", 7: "rows collected*", 13: "sums sent*", 14: "chain loop 1 in", 11: "chain loop 2 out", 12: "chain out", 8: "sums received", 9: "chain done",
-         3: "p2 t0 data in", 4: "p2 t0 rescaled", 5: "p2 t0 pre-store", 15: "exit"}
+         3: "p1 t0 data in", 4: "p1 t0 prepared", 5: "p2 t0 pre-store", 15: "exit"}
 for mol in [int(x) for x in sys.argv[1:]] or [125000]:
     s, g, ng = synth.water_box(mol)
     it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, 1, True, True)
@@ -32,7 +32,7 @@ for mol in [int(x) for x in sys.argv[1:]] or [125000]:
         tr = tr[live]
         base = tr[:, 0].min()
         print(f"--- {mol} molecules, step_kernel: {live.sum()} work-groups, span {(tr[:, 15].max() - base) / 100:.2f} us")
-        for sl in (0, 1, 2, 6, 10, 7, 13, 8, 14, 11, 12, 9, 3, 4, 5, 15):
+        for sl in (0, 3, 4, 1, 2, 6, 10, 7, 13, 8, 14, 11, 12, 9, 5, 15):
             col = tr[:, sl]
             m = col >= base
             if m.sum() == 0:
