@@ -753,7 +753,7 @@ __device__ __forceinline__ void chain1q_run(const ChainArgs& a, const Chain1Regs
 
 // The Reference platform's coupled real/Drude chain on its interleaved vectors.  Ref :467-504.
 // LEN = compile-time bound of the vectors (2*CC+2), 0 = dynamic (LDS).
-template <int CC>
+template <int CC, bool LIBM = true>
 __device__ __forceinline__ void run_dualnh(const ChainArgs& a, const double* st_in, double* st_out, const bool write,
                                            double* s_scale, double* lds, const double ke0, const double ke1, const double ke2) {
     const ChainLayout& L = a.L;
@@ -790,14 +790,14 @@ __device__ __forceinline__ void run_dualnh(const ChainArgs& a, const double* st_
 #pragma unroll
             for (int i = NB - 3; i >= 0; i--) {                      // Ref :476-481 (i = idxMaxNHChains .. 0)
                 if (i <= idxMax) {
-                    expfac = chain_exp(-dtc8 * (ntg == 2 ? etaDot[i + 2] : etaDot[i + 1]));
+                    expfac = chain_exp<LIBM>(-dtc8 * (ntg == 2 ? etaDot[i + 2] : etaDot[i + 1]));
                     etaDot[i] *= expfac;
                     etaDot[i] += etaDotDot[i] * dtc4;
                     etaDot[i] *= expfac;
                 }
             }
-            { const double e = chain_exp(-dtc2 * etaDot[0]); scaleReal *= e; realKE *= e * e; }    // Ref :483-486
-            { const double e = chain_exp(-dtc2 * etaDot[1]); scaleDrude *= e; drudeKE *= e * e; }
+            { const double e = chain_exp<LIBM>(-dtc2 * etaDot[0]); scaleReal *= e; realKE *= e * e; }    // Ref :483-486
+            { const double e = chain_exp<LIBM>(-dtc2 * etaDot[1]); scaleDrude *= e; drudeKE *= e * e; }
 #pragma unroll
             for (int i = 0; i < NB - 2; i++) if (i < iNum) eta[i] += dtc2 * etaDot[i];             // Ref :487-489
             etaDotDot[0] = (realKE - realNkbT) * invQr;              // Ref :491-492
@@ -805,7 +805,7 @@ __device__ __forceinline__ void run_dualnh(const ChainArgs& a, const double* st_
 #pragma unroll
             for (int i = 0; i < NB - 2; i++) {                       // Ref :494-503
                 if (i < iNum) {
-                    expfac = chain_exp(-dtc8 * etaDot[i + 2]);
+                    expfac = chain_exp<LIBM>(-dtc8 * etaDot[i + 2]);
                     etaDot[i] *= expfac;
                     if (i > 1) {
                         const double dofkbT = (i % 2 == 0 ? a.realkbT : a.drudekbT);
@@ -834,6 +834,34 @@ __device__ __forceinline__ void run_dualnh(const ChainArgs& a, const double* st_
     for (int i = 0; i < NB; i++) {
         if (i < n) { st_out[L.off_eta + i] = eta[i]; st_out[L.off_etaDotDot + i] = etaDotDot[i]; }
         if (i < nd) st_out[L.off_etaDot + i] = etaDot[i];
+    }
+}
+
+// Chains of 2-4 links inside a streaming launch (the one-link chains have chain1_run): called by the 64 lanes of one
+// wavefront, converged; lane itg < NT holds its thermostat's summed kinetic energy `ke`.  TGNH: lane itg runs its thermostat
+// (run_tgnh, register-resident links; the real thermostats and the Drude thermostat are two code paths of one wavefront
+// here, one after the other).  dualNH: lane 0 runs the Reference platform's coupled vectors (run_dualnh).  No library exp
+// (chain_exp<false>): ocml's would cost the streaming kernels ~30 registers.  Longer chains keep their own launch (chain_kernel).
+__device__ __forceinline__ void chainN_run(const ChainArgs& a, const double* st_in, double* st_out, const bool write,
+                                           double* s_scale, const int itg, const double ke) {
+    const ChainLayout& L = a.L;
+    if (L.mode == TGNH_MODE_TGNH) {
+        if (itg < L.NT) {
+            switch (L.C) {
+                case 2: run_tgnh<2, false>(a, st_in, st_out, write, s_scale, itg, nullptr, ke); break;
+                case 3: run_tgnh<3, false>(a, st_in, st_out, write, s_scale, itg, nullptr, ke); break;
+                default: run_tgnh<4, false>(a, st_in, st_out, write, s_scale, itg, nullptr, ke); break;
+            }
+        }
+    } else {
+        const double ke0 = __shfl(ke, 0, 64), ke1 = __shfl(ke, 1, 64), ke2 = __shfl(ke, 2, 64);
+        if (itg == 0) {
+            switch (L.C) {
+                case 2: run_dualnh<2, false>(a, st_in, st_out, write, s_scale, nullptr, ke0, ke1, ke2); break;
+                case 3: run_dualnh<3, false>(a, st_in, st_out, write, s_scale, nullptr, ke0, ke1, ke2); break;
+                default: run_dualnh<4, false>(a, st_in, st_out, write, s_scale, nullptr, ke0, ke1, ke2); break;
+            }
+        }
     }
 }
 

@@ -558,7 +558,11 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
 #endif
         // dualNH qualifies too: with useDrudeNHChains its real and Drude chains are independent (Chain1Map), without
         // them coupled through one shuffle per sub-step (chain1q_run)
-        c->inline_chain = c->L.C == 1 && want;
+        // Chains of 2-4 links too, but in instantiations of their own that hold two work-groups per compute unit where the
+        // one-link kernels hold three (the links' registers): taken below 2 M slots, where a step is bound by its launches and
+        // the chain launch it saves; beyond, the streaming launches are bandwidth-bound and keep their occupancy
+        c->inline_chain = want && (c->L.C == 1 || (c->L.C <= 4 && d->num_particles < 2000000));
+        if (c->L.total > 256 && c->L.C > 1) c->inline_chain = c->inline_chain && false;     // (wstep_kernel parks the block in 256 doubles)
     }
     auto alloc = [&]() -> tgnh_status {
         if (host_only) return TGNH_OK;
@@ -600,11 +604,12 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
             // How many work-groups of step_kernel per compute unit are resident TOGETHER?  The occupancy API's answer is
             // checked by a census launch (every work-group checks in and waits for all the others, bounded); one fewer per
             // unit is tried until a grid passes.  0 = none did: the handle steps the DEFER_SCALE way.
-            if (c->gb != 0 && c->L.C == 1 && c->L.NT <= CHAIN_INLINE_SUM_NT) {
+            if (c->gb != 0 && c->inline_chain && c->L.NT <= CHAIN_INLINE_SUM_NT) {
                 // (the kind with the largest footprint this handle will launch: a whole deferred step, or the plain begin half)
                 const int kind = (c->d.flags & TGNH_FLAG_DEFER_SCALE) ? 0 : 1;
                 const size_t lds = tile_lds_bytes(c->d.precision, step_kind_ops2(kind), true, true);
-                for (int per_cu = std::min(step_blocks_per_cu(c->d.precision, c->gb, kind, lds), 8); per_cu >= 1 && !c->resident_per_cu; per_cu--) {
+                // (step_kernel runs one-link chains only; longer ones have wstep_kernel below, or the launches)
+                for (int per_cu = c->L.C == 1 ? std::min(step_blocks_per_cu(c->d.precision, c->gb, kind, lds), 8) : 0; per_cu >= 1 && !c->resident_per_cu; per_cu--) {
                     TileArgs a{};
                     a.census = 1; a.sync = c->d_sync;
                     HIP_OK(hipMemset(c->d_sync + 2, 0, 2 * sizeof(unsigned int)));
@@ -615,16 +620,17 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
                     if (res[0] == (unsigned)grid && res[1] == 0) c->resident_per_cu = per_cu;
                 }
                 // the same count for wstep_kernel, which runs the whole deferred step when the topology has wave tiles
-                bool want_w = c->wave_ke && (c->d.flags & TGNH_FLAG_DEFER_SCALE) && c->resident_per_cu > 0;
+                const bool multi = c->L.C > 1;
+                bool want_w = c->wave_ke && (c->d.flags & TGNH_FLAG_DEFER_SCALE) && (c->resident_per_cu > 0 || multi);
 #ifdef TGNH_TUNING
                 if (const char* e = getenv("TGNH_WSTEP")) want_w = want_w && e[0] != '0';
 #endif
-                for (int per_cu = want_w ? std::min(wstep_blocks_per_cu(c->d.precision, c->gb), 8) : 0; per_cu >= 1 && !c->wresident_per_cu; per_cu--) {
+                for (int per_cu = want_w ? std::min(wstep_blocks_per_cu(c->d.precision, c->gb, multi), 8) : 0; per_cu >= 1 && !c->wresident_per_cu; per_cu--) {
                     TileArgs a{};
                     a.census = 1; a.sync = c->d_sync;
                     HIP_OK(hipMemset(c->d_sync + 2, 0, 2 * sizeof(unsigned int)));
                     const int grid = std::min(per_cu * c->num_cus, GRID_CAP);
-                    HIP_OK(launch_wstep(c->d.precision, c->gb, a, grid, (hipStream_t)0));
+                    HIP_OK(launch_wstep(c->d.precision, c->gb, multi, a, grid, (hipStream_t)0));
                     unsigned int res[2] = {0, 1};
                     HIP_OK(hipMemcpy(res, c->d_sync + 2, sizeof(res), hipMemcpyDeviceToHost));
                     if (res[0] == (unsigned)grid && res[1] == 0) c->wresident_per_cu = per_cu;
@@ -914,7 +920,7 @@ extern "C" tgnh_status tgnh_rccl_shutdown(tgnh_handle h) {
 extern "C" tgnh_status tgnh_get_resident_work_groups(tgnh_handle h, int* per_compute_unit) {
     CHECK_H(h);
     if (!per_compute_unit) return fail(TGNH_ERR_ARG, "null out");
-    *per_compute_unit = resident_now(h) ? h->resident_per_cu : 0;
+    *per_compute_unit = resident_now(h) ? std::max(h->resident_per_cu, h->wresident_per_cu) : 0;
     return TGNH_OK;
 }
 
@@ -1022,7 +1028,7 @@ static int grid_for(tgnh_handle h, int ops, bool hardwall, size_t lds) {
     const int key = ops | (hardwall ? 1 << 16 : 0);
     auto it = h->grid_cache.find(key);
     if (it != h->grid_cache.end()) return it->second;
-    int per_cu = tile_blocks_per_cu(h->d.precision, ops, h->gb, lds);
+    int per_cu = tile_blocks_per_cu(h->d.precision, ops, h->gb, lds, (ops & OP_SCALE) && h->inline_chain && h->L.C > 1);
     if (per_cu < 1) per_cu = 2;
     int g = std::min(std::min(h->num_tiles, per_cu * h->num_cus), GRID_CAP);
     if (g < 1) g = 1;
@@ -1195,9 +1201,14 @@ static tgnh_status materialize_chain(tgnh_handle h, hipStream_t s) {
 // ---- TGNH_FLAG_RESIDENT_STEP: one launch per time step (step_kernel) ----
 // Eligible: deferred pass structure, one-link chains (the chain runs inside the launch), at most 8 temperature groups,
 // and an exchange the kernel can do itself (none, or the mailboxes -- a collective hook is a launch of its own).
+static bool resident_kind(tgnh_handle h, int kind) {
+    if (!((h->d.flags & TGNH_FLAG_RESIDENT_STEP) && h->inline_chain && h->gb != 0 && h->L.NT <= CHAIN_INLINE_SUM_NT &&
+          (h->xchg_on || !h->allreduce))) return false;
+    if (kind == 0 && h->wresident_per_cu > 0) return true;           // wstep_kernel: a whole deferred step, chains of 1-4 links
+    return h->resident_per_cu > 0 && h->L.C == 1;                    // step_kernel: every kind, one-link chains
+}
 static bool resident_now(tgnh_handle h) {
-    return (h->d.flags & TGNH_FLAG_RESIDENT_STEP) && h->resident_per_cu > 0 && h->inline_chain && h->gb != 0 &&
-           h->L.NT <= CHAIN_INLINE_SUM_NT && (h->xchg_on || !h->allreduce);
+    return resident_kind(h, (h->d.flags & TGNH_FLAG_DEFER_SCALE) ? 0 : 1);
 }
 
 // One launch of step_kernel.  kind 0: a whole deferred step (the last step's end half + this step's begin half, both chain
@@ -1210,7 +1221,7 @@ static tgnh_status run_resident(tgnh_handle h, hipStream_t s, int kind) {
     const bool hw = a.hardwall != 0 && (ops2 & (OP_DRIFT | OP_MOVE));
     const size_t lds = tile_lds_bytes(h->d.precision, ops2, hw, a.use_com != 0);
     int& grid = h->resident_grid[kind][hw ? 1 : 0];
-    if (grid == 0) {       // the work-groups that are resident at once (counted at create; never more than this kind's own occupancy)
+    if (grid == 0 && !(kind == 0 && h->wresident_per_cu > 0)) {       // the work-groups that are resident at once (counted at create; never more than this kind's own occupancy)
         int per_cu = std::min(h->resident_per_cu, step_blocks_per_cu(h->d.precision, h->gb, kind, lds));
         if (per_cu < 1) return fail(TGNH_ERR_HIP, "step_kernel: occupancy query failed");
         grid = std::max(1, std::min(std::min(h->num_tiles, per_cu * h->num_cus / h->resident_share), GRID_CAP));
@@ -1233,7 +1244,7 @@ static tgnh_status run_resident(tgnh_handle h, hipStream_t s, int kind) {
         a.chain.nparts = h->wresident_grid;
         h->ke_parts = h->wresident_grid;
         Timed t(h, s, KID_STEP);
-        HIP_OK(launch_wstep(h->d.precision, h->gb, a, h->wresident_grid, s));
+        HIP_OK(launch_wstep(h->d.precision, h->gb, h->L.C > 1, a, h->wresident_grid, s));
     } else {
         h->ke_parts = grid;
         Timed t(h, s, KID_STEP);

@@ -239,14 +239,14 @@ struct ForceArgs {
 
 // launchers (tgnh_kernels.hip)
 hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s);
-int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds);   // occupancy of that instantiation
+int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds, bool multi = false);   // occupancy of that instantiation (multi: its in-kernel chain has 2-4 links)
 // step_kernel; kind: 0 a whole deferred step, 1 / 2 the begin / end half of the reference's pass structure, 3 / 4 the same
 // around the constraint call-outs (tgnh_kernels.hip: STEP_*)
 hipError_t launch_step(int precision, int gb, int kind, const TileArgs& a, int grid, size_t lds, hipStream_t s);
 int step_blocks_per_cu(int precision, int gb, int kind, size_t lds);
 int step_kind_ops2(int kind);       // operations of the kind's second pass (its LDS needs)
-hipError_t launch_wstep(int precision, int gb, const TileArgs& a, int grid, hipStream_t s);   // a whole deferred step over wave tiles
-int wstep_blocks_per_cu(int precision, int gb);
+hipError_t launch_wstep(int precision, int gb, bool multi, const TileArgs& a, int grid, hipStream_t s);   // a whole deferred step over wave tiles
+int wstep_blocks_per_cu(int precision, int gb, bool multi);
 hipError_t launch_wke(int precision, int ops, int gb, const TileArgs& a, int grid, hipStream_t s);   // KE passes over wave tiles
 int wke_blocks_per_cu(int precision, int ops, int gb);
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s);

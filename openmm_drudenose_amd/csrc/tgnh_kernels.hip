@@ -622,7 +622,10 @@ __device__ __forceinline__ void ke_reduce(const TileArgs& a, TileEnv<PREC, GB>& 
     }
 }
 
-template <int PREC, int OPS, int GB>
+// MULTI: the in-kernel chain may have 2-4 links (chainN_run: ~100 registers of its own).  Its own instantiation, so that the
+// one-link kernels keep their register count; and in it no wavefront issues its first tile's loads before the chain is done --
+// the image of a tile in flight and the chain's links together would not fit three work-groups per compute unit.
+template <int PREC, int OPS, int GB, bool MULTI = false>
 __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileArgs a) {
     typedef typename Prec<PREC>::mixed mixed;
     typedef OpsOf<OPS> O;
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
             for (int f = (tid >> 6) * W + lane; f < a.chain.nbig * NT; f += stride) racc += big[f];
         }
     }
-    if (!chain_wave && have_tile) load_tile(blockIdx.x, cur);
+    if (!MULTI && !chain_wave && have_tile) load_tile(blockIdx.x, cur);
     if (DO_SCALE && a.chain_on && a.sum_rows == 2) {
         const int NT = G + 2;
         for (int b = 0; b < NT; b++) {
@@ -703,8 +706,9 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                 const bool write = blockIdx.x == 0;
                 const int itg = tid & 63;
                 TRACE(13);
+                const bool one_link = !MULTI || L.C == 1;            // (2-4 links: chainN_run reads its state itself)
                 Chain1Regs creg{};
-                if (itg < NT) creg = chain1_load(a.chain, a.st_in, itg);
+                if (itg < NT) { if (one_link) creg = chain1_load(a.chain, a.st_in, itg); else creg.ke = a.st_in[L.off_ke_red + itg]; }
                 if (a.x_wait) {                                      // sharded: everybody's sums arrive by mailbox
                     const double tot = xchg_wait_sum(a.chain.x, NT, itg, reinterpret_cast<double*>(smem));   // the images are not in use yet
                     creg.ke = tot;
@@ -732,15 +736,17 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     for (int i = 0; i < NT; i++) s += a.x_wait ? s_scale[i] : a.st_in[L.off_ke_red + i];
                     a.st_out[L.off_kesum] = 0.5 * s;
                 }
-                if (itg < NT) {
+                if (MULTI && !one_link) chainN_run(a.chain, a.st_in, a.st_out, write, s_scale, itg, creg.ke);
+                else if (itg < NT) {
                     if (L.c1_quirk) chain1q_run(a.chain, creg, a.st_out, write, s_scale, itg);
                     else chain1_run(a.chain, creg, a.st_out, write, s_scale, itg);
                 }
                 TRACE(14);
                 if (have_tile) load_tile(blockIdx.x, cur);
-            }
-        } else if (tid < NT) {
-            s_scale[tid] = a.scale[tid];
+            } else if (MULTI && have_tile) load_tile(blockIdx.x, cur);
+        } else {
+            if (tid < NT) s_scale[tid] = a.scale[tid];
+            if (MULTI && have_tile) load_tile(blockIdx.x, cur);
         }
         __syncthreads();
         e.s_com = (mixed)s_scale[G]; e.s_drude = (mixed)s_scale[G + 1];
@@ -944,8 +950,9 @@ struct MeetShared {
     double (*s_part)[CHAIN_INLINE_SUM_NT];            // [TBLOCK / 64]
     double* s_x;                                      // [64 + XCHG_MAX_WORLD * CHAIN_INLINE_SUM_NT]
     int* s_go_p; unsigned* s_gen_p; unsigned long long* s_seq1_p;
+    const double* s_block;                            // MULTI: the thermostat block as it was at kernel entry (chains of 2-4 links)
 };
-template <int PREC, int GB, bool LEAN = false, int NTH = TBLOCK, typename Prefetch>
+template <int PREC, int GB, bool LEAN = false, int NTH = TBLOCK, bool MULTI = false, typename Prefetch>
 __device__ __forceinline__ bool step_meet(const TileArgs& a, TileEnv<PREC, GB>& e, const unsigned gen0, const unsigned long long seq0,
                                           Chain1Regs& creg, const MeetShared& sh, Prefetch&& prefetch) {
     double* const s_scale = sh.s_scale; double (*const s_part)[CHAIN_INLINE_SUM_NT] = sh.s_part; double* const s_x = sh.s_x;
@@ -964,7 +971,7 @@ __device__ __forceinline__ bool step_meet(const TileArgs& a, TileEnv<PREC, GB>& 
     // (single precision: its 16 registers there would cost the kernel its fourth work-group per compute unit)
     constexpr bool EARLY_PRE = PREC != TGNH_PREC_SINGLE && !LEAN;      // (LEAN: wstep_kernel, which lives on a small register count)
     Chain1Pre cpre{};
-    if (EARLY_PRE && chain_wave && !L.c1_quirk) cpre = chain1_prepare(a.chain, creg, itg);
+    if (EARLY_PRE && chain_wave && !L.c1_quirk && !(MULTI && L.C > 1)) cpre = chain1_prepare(a.chain, creg, itg);
 
     // ---- meet: work-group 0 collects the rows.  Thread t owns rows t, t + 256, ...: it polls their cells until all
     // carry this launch's tag and adds them in row order; then 64-lane sums and one LDS hop, fixed order throughout.
@@ -1084,7 +1091,8 @@ __device__ __forceinline__ bool step_meet(const TileArgs& a, TileEnv<PREC, GB>& 
                 const double kesum = wave_sum(itg < NT ? mine : 0.0);
                 if (itg == 63) a.st_out[L.off_kesum] = 0.5 * kesum;
             }
-            if (itg < NT) {
+            if (MULTI && L.C > 1) chainN_run(a.chain, sh.s_block, a.st_out, write, s_scale, itg, mine);
+            else if (itg < NT) {
                 if (L.c1_quirk) chain1q_run(a.chain, creg, a.st_out, write, s_scale, itg);
                 else chain1_finish(a.chain, creg, EARLY_PRE ? cpre : chain1_prepare(a.chain, creg, itg), a.st_out, write, s_scale, itg);
             }
@@ -1199,7 +1207,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
     }
     const int tt_last = tt;                                // stays in `cur`; its velocity image and COM table stay in LDS
     TRACE(1);
-    MeetShared sh{s_scale, s_part, s_x, &s_go, &s_gen, &s_seq1};
+    MeetShared sh{s_scale, s_part, s_x, &s_go, &s_gen, &s_seq1, nullptr};
     if (!step_meet<PREC, GB>(a, e, gen0, seq0, creg, sh, [&] { tile_load<PREC, STEP_OPS2, STEP_OPS1>(a, tile_of(tt_last), cur); }))
         return;                                            // an exchange timed out: reported by the status word; nothing is stored
     e.s_com = (mixed)s_scale[G]; e.s_drude = (mixed)s_scale[G + 1];
@@ -1241,7 +1249,7 @@ template <int PREC> struct WStepIn {
     typename Prec<PREC>::mixed mass, cx, cy, cz;
 };
 
-template <int PREC, int GB>
+template <int PREC, int GB, bool MULTI = false>
 __global__ __launch_bounds__(WBLOCK) void wstep_kernel(const TileArgs a) {
     typedef typename Prec<PREC>::real real;
     typedef typename Prec<PREC>::mixed mixed;
@@ -1255,6 +1263,7 @@ __global__ __launch_bounds__(WBLOCK) void wstep_kernel(const TileArgs a) {
     __shared__ unsigned s_gen;
     __shared__ unsigned long long s_seq1;
     __shared__ mixed s_img[WBLOCK / 64][7][WAVE_SLOTS];          // per wavefront: velocity x, y, z, mass; position x, y, z (hard wall)
+    __shared__ double s_block[256];                              // chains of 2-4 links: the thermostat block as it was at entry
     const int tid = threadIdx.x, lane = tid & 63, G = a.num_groups, NT = G + 2;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool chain_wave = tid < 64;
@@ -1292,8 +1301,12 @@ __global__ __launch_bounds__(WBLOCK) void wstep_kernel(const TileArgs a) {
     if (chain_wave) {
         gen0 = __hip_atomic_load(&a.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         seq0 = __hip_atomic_load(a.chain.x.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (itg < NT) creg = chain1_load(a.chain, a.st_in, itg);
+        if (itg < NT && !(MULTI && a.chain.L.C > 1)) creg = chain1_load(a.chain, a.st_in, itg);
     }
+    // Chains of 2-4 links: the whole block (<= 256 doubles, checked on the host) goes to LDS now -- work-group 0 advances it in
+    // place once it holds every row, and a row leaves only behind the barrier in ke_reduce, which every thread reaches after
+    // its load has landed and been stored here.
+    if (MULTI && a.chain.L.C > 1 && tid < a.chain.L.total) s_block[tid] = a.st_in[tid];
 
     const int nw = a.num_wtiles, stride = (int)gridDim.x * (WBLOCK / 64);
     struct Bounds { int ws, maxn, n; };
@@ -1502,8 +1515,8 @@ __global__ __launch_bounds__(WBLOCK) void wstep_kernel(const TileArgs a) {
     }
     const int w_last = w;                                  // stays in `cur` (kicked velocities, mass, v_com), its image in LDS
     TRACE(1);
-    MeetShared sh{s_scale, s_part, s_x, &s_go, &s_gen, &s_seq1};
-    if (!step_meet<PREC, GB, true, WBLOCK>(a, e, gen0, seq0, creg, sh, [&] {
+    MeetShared sh{s_scale, s_part, s_x, &s_go, &s_gen, &s_seq1, s_block};
+    if (!step_meet<PREC, GB, true, WBLOCK, MULTI>(a, e, gen0, seq0, creg, sh, [&] {
             if (have) {
                 load_x(b0, cur);
                 if (w_last - stride >= 0) bounds(w_last - stride, b1);        // the way back: known long before it is needed
@@ -1887,8 +1900,29 @@ static tile_fn_t tile_fn(int precision, int ops, int gb) {
     }
 }
 
+// the instantiations whose in-kernel chain may have 2-4 links (rescale launches only; no KE bins in any of them)
+template <int PREC> static tile_fn_t tile_fn_multi(int ops) {
+    switch (ops) {
+        case OP_SCALE: return tile_kernel<PREC, OP_SCALE, 1, true>;
+        case OP_SCALE | OP_KICK | OP_DRIFT: return tile_kernel<PREC, OP_SCALE | OP_KICK | OP_DRIFT, 1, true>;
+        case OP_PREKICK | OP_SCALE | OP_KICK | OP_DRIFT: return tile_kernel<PREC, OP_PREKICK | OP_SCALE | OP_KICK | OP_DRIFT, 1, true>;
+        case OP_PREKICK | OP_SCALE: return tile_kernel<PREC, OP_PREKICK | OP_SCALE, 1, true>;
+        case OP_SCALE | OP_KICK | OP_POSDELTA: return tile_kernel<PREC, OP_SCALE | OP_KICK | OP_POSDELTA, 1, true>;
+        default: return nullptr;
+    }
+}
+static tile_fn_t tile_fn_any(int precision, int ops, int gb, bool multi) {
+    if (!multi) return tile_fn(precision, ops, gb);
+    switch (precision) {
+        case TGNH_PREC_SINGLE: return tile_fn_multi<TGNH_PREC_SINGLE>(ops);
+        case TGNH_PREC_MIXED: return tile_fn_multi<TGNH_PREC_MIXED>(ops);
+        case TGNH_PREC_DOUBLE: return tile_fn_multi<TGNH_PREC_DOUBLE>(ops);
+        default: return nullptr;
+    }
+}
+
 hipError_t launch_tile(int precision, int ops, int gb, const TileArgs& a, int grid, size_t lds, hipStream_t s) {
-    tile_fn_t fn = tile_fn(precision, ops, gb);
+    tile_fn_t fn = tile_fn_any(precision, ops, gb, a.chain_on && a.chain.L.C > 1);
     if (!fn) return hipErrorInvalidValue;
     TGNH_LAUNCH(fn, dim3(grid), dim3(TBLOCK), lds, s, a);
     return hipGetLastError();
@@ -1954,23 +1988,26 @@ static step_fn_t step_fn(int precision, int gb, int kind) {
         default: return nullptr;
     }
 }
-static step_fn_t wstep_fn(int precision, int gb) {
+template <int PREC, bool MULTI> static step_fn_t wstep_fn_gb(int gb) {
+    return gb <= 1 ? wstep_kernel<PREC, 1, MULTI> : gb <= 4 ? wstep_kernel<PREC, 4, MULTI> : wstep_kernel<PREC, 8, MULTI>;
+}
+static step_fn_t wstep_fn(int precision, int gb, bool multi) {
     if (gb == 0) return nullptr;
     switch (precision) {
-        case TGNH_PREC_SINGLE: return gb <= 1 ? wstep_kernel<TGNH_PREC_SINGLE, 1> : gb <= 4 ? wstep_kernel<TGNH_PREC_SINGLE, 4> : wstep_kernel<TGNH_PREC_SINGLE, 8>;
-        case TGNH_PREC_MIXED: return gb <= 1 ? wstep_kernel<TGNH_PREC_MIXED, 1> : gb <= 4 ? wstep_kernel<TGNH_PREC_MIXED, 4> : wstep_kernel<TGNH_PREC_MIXED, 8>;
-        case TGNH_PREC_DOUBLE: return gb <= 1 ? wstep_kernel<TGNH_PREC_DOUBLE, 1> : gb <= 4 ? wstep_kernel<TGNH_PREC_DOUBLE, 4> : wstep_kernel<TGNH_PREC_DOUBLE, 8>;
+        case TGNH_PREC_SINGLE: return multi ? wstep_fn_gb<TGNH_PREC_SINGLE, true>(gb) : wstep_fn_gb<TGNH_PREC_SINGLE, false>(gb);
+        case TGNH_PREC_MIXED: return multi ? wstep_fn_gb<TGNH_PREC_MIXED, true>(gb) : wstep_fn_gb<TGNH_PREC_MIXED, false>(gb);
+        case TGNH_PREC_DOUBLE: return multi ? wstep_fn_gb<TGNH_PREC_DOUBLE, true>(gb) : wstep_fn_gb<TGNH_PREC_DOUBLE, false>(gb);
         default: return nullptr;
     }
 }
-hipError_t launch_wstep(int precision, int gb, const TileArgs& a, int grid, hipStream_t s) {
-    step_fn_t fn = wstep_fn(precision, gb);
+hipError_t launch_wstep(int precision, int gb, bool multi, const TileArgs& a, int grid, hipStream_t s) {
+    step_fn_t fn = wstep_fn(precision, gb, multi);
     if (!fn) return hipErrorInvalidValue;
     TGNH_LAUNCH(fn, dim3(grid), dim3(WBLOCK), 0, s, a);
     return hipGetLastError();
 }
-int wstep_blocks_per_cu(int precision, int gb) {
-    step_fn_t fn = wstep_fn(precision, gb);
+int wstep_blocks_per_cu(int precision, int gb, bool multi) {
+    step_fn_t fn = wstep_fn(precision, gb, multi);
     int n = 0;
     if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(fn), WBLOCK, 0) != hipSuccess) return 0;
     return n;
@@ -1989,8 +2026,8 @@ int step_blocks_per_cu(int precision, int gb, int kind, size_t lds) {
     return n;
 }
 
-int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds) {
-    tile_fn_t fn = tile_fn(precision, ops, gb);
+int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds, bool multi) {
+    tile_fn_t fn = tile_fn_any(precision, ops, gb, multi);
     int n = 0;
     if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(fn), TBLOCK, lds) != hipSuccess) return 0;
     return n;

@@ -406,18 +406,26 @@ RESIDENT = FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP
 
 
 @pytest.mark.parametrize("precision", ["mixed", "double"])
-@pytest.mark.parametrize("sysname,mode,drude_chains,com", [
-    ("mixed", "TGNH", True, True), ("mixed", "dualNH", True, True), ("mixed", "dualNH", False, True),
-    ("polymer", "TGNH", True, True), ("water1000", "TGNH", True, False), ("il40", "TGNH", True, True),
-    ("ragged6", "TGNH", True, True), ("groups6", "TGNH", True, True)])
-def test_100_step_parity_resident_step(sysname, mode, drude_chains, com, precision):
-    """TGNH_FLAG_RESIDENT_STEP: one launch per time step (step_kernel: kick + KE sums, the work-groups meet on the
-    device, row sum, both chain halves, kick + rescale + kick + drift + hard wall) against the oracle directly."""
-    s, g, ng, it, ctx = make(sysname, mode, precision, flags=RESIDENT, chains=1, drude_chains=drude_chains, com=com, hardwall=0.02)
+@pytest.mark.parametrize("sysname,mode,drude_chains,com,chains", [
+    ("mixed", "TGNH", True, True, 1), ("mixed", "dualNH", True, True, 1), ("mixed", "dualNH", False, True, 1),
+    ("polymer", "TGNH", True, True, 1), ("water1000", "TGNH", True, False, 1), ("il40", "TGNH", True, True, 1),
+    ("ragged6", "TGNH", True, True, 1), ("groups6", "TGNH", True, True, 1),
+    # chains of 2-4 links: the whole step still one launch (wstep_kernel with the links in registers)
+    ("mixed", "TGNH", True, True, 3), ("mixed", "TGNH", False, True, 2), ("water1000", "TGNH", True, True, 4),
+    ("mixed", "dualNH", True, True, 3), ("mixed", "dualNH", False, True, 4), ("groups6", "TGNH", True, True, 2)])
+def test_100_step_parity_resident_step(sysname, mode, drude_chains, com, chains, precision):
+    """TGNH_FLAG_RESIDENT_STEP: one launch per time step (wstep_kernel / step_kernel: kick + KE sums, the work-groups meet on
+    the device, row sum, both chain halves, kick + rescale + kick + drift + hard wall) against the oracle directly."""
+    s, g, ng, it, ctx = make(sysname, mode, precision, flags=RESIDENT, chains=chains, drude_chains=drude_chains, com=com, hardwall=0.02)
     o = make_oracle(s, g, ng, mode, it)
     pos_o, vel_o = oracle_run(o, s, 100, x0=ctx.sites())
     assert ctx.resident_work_groups() >= 1
+    ctx.timing(True)
     ctx.step(100)
+    ctx.torch.cuda.synchronize()
+    ctx.timing(False)
+    from openmm_drudenose_amd import _lib
+    assert ctx.timing_read(_lib.KID_STEP)[1] >= 99 and ctx.timing_read(_lib.KID_CHAIN)[1] == 0        # really one launch per step
     ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
     print(f"resident step {sysname} {mode} {precision}: pos {ep:.2e} vel {ev:.2e}")
     assert ep <= TOL and ev <= TOL and ctx.check() == 0
@@ -491,9 +499,9 @@ def test_resident_step_is_the_deferred_integrator():
 
 
 def test_resident_step_falls_back_where_it_cannot_run():
-    """Three-link chains (the chain kernel) and more than 8 temperature groups are not step_kernel's: the flag is
-    accepted and the handle steps the deferred way."""
-    for sysname, chains in (("mixed", 3), ("groups12", 1)):
+    """Chains longer than four links (the chain kernel's) and more than 8 temperature groups are not the step kernels': the
+    flag is accepted and the handle steps the deferred way."""
+    for sysname, chains in (("mixed", 6), ("groups12", 1)):
         ref = make(sysname, "TGNH", "double", flags=FLAG_DEFER_SCALE, chains=chains)
         alt = make(sysname, "TGNH", "double", flags=RESIDENT, chains=chains)
         alt[4].timing(True)
