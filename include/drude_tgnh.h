@@ -203,6 +203,13 @@ tgnh_status tgnh_flush(tgnh_handle h, void* stream);
 /* A caller that captured `nsteps` steps into a hipGraph and replays it tells the handle here: the host-side
  * clock and step count advance only when the step functions are called, not when a graph is replayed. */
 tgnh_status tgnh_note_replayed_steps(tgnh_handle h, int nsteps);
+/* What the handle still owes the trajectory, as a bit set (inspection only; a caller that records steps into a hipGraph
+ * checks that the set is the same before and after the recorded steps -- a graph replays launches, not decisions):
+ * bit 0 the end half of the last step waits for the next tgnh_step_begin (RESIDENT_STEP), 1 velm lags by the scale factors,
+ * 2 velm lags by the second half kick, 3 the next step's first thermostat half has already run (DEFER_SCALE), 4 the summed
+ * kinetic energies wait for the next rescale launch to run the chain, 5 the partial rows are not summed yet, 6 an exchange is
+ * sent but not yet waited for, 7 the advanced thermostat block sits in the staging copy, 8 direction of the next sweep. */
+tgnh_status tgnh_get_pending_state(tgnh_handle h, uint32_t* bits);
 /* Restore the clock of a checkpointed run (time, stepCount: ReferenceDrudeTGNHKernels.cpp:413-414, CudaDrudeTGNHKernels.cpp:405-406). */
 tgnh_status tgnh_set_time(tgnh_handle h, double time, int64_t step_count);
 /* Velocities were changed behind the integrator's back (setVelocities, CMMotionRemover,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "tgnh_set_rccl_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_rccl_shutdown": (C.c_int, [C.c_void_p]),
     "tgnh_exchange_wait_stats": (C.c_int, [C.c_void_p, C.c_void_p, c_f64p, c_f64p, C.POINTER(C.c_int64)]),
+    "tgnh_get_pending_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "tgnh_set_resident_share": (C.c_int, [C.c_void_p, C.c_int]),
     "tgnh_get_resident_work_groups": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "tgnh_exchange_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -1442,6 +1442,17 @@ extern "C" tgnh_status tgnh_set_time(tgnh_handle h, double time, int64_t step_co
     return TGNH_OK;
 }
 
+static uint32_t owed(tgnh_handle h) {
+    return (h->end_pending ? 1u : 0u) | (h->scale_pending ? 2u : 0u) | (h->kick_pending ? 4u : 0u) | (h->first_half_done ? 8u : 0u) |
+           (h->chain_pending ? 16u : 0u) | (h->sum_pending ? 32u : 0u) | (h->xwait_pending ? 64u : 0u) | (h->stage_pending ? 128u : 0u);
+}
+extern "C" tgnh_status tgnh_get_pending_state(tgnh_handle h, uint32_t* bits) {
+    CHECK_H(h);
+    if (!bits) return fail(TGNH_ERR_ARG, "null out");
+    *bits = owed(h) | (h->sweep_reverse ? 256u : 0u);
+    return TGNH_OK;
+}
+
 extern "C" tgnh_status tgnh_state_changed(tgnh_handle h) {
     CHECK_H(h);
     return deferred_guard(h, "tgnh_state_changed");       // kinetic energies are recomputed at every step anyway

@@ -482,6 +482,7 @@ class HipContext(_HandleQueries):
     # ---- state (Context::setPositions / setVelocities / getState) ----
     def setPositions(self, pos):
         torch = self.torch
+        self._state_changed()
         p = torch.from_numpy(np.ascontiguousarray(pos, np.float64)).to(self.dev)
         if self.precision == PREC_DOUBLE:
             self.posq[:, :3] = p
@@ -490,7 +491,6 @@ class HipContext(_HandleQueries):
             self.posq[:, :3] = hi
             if self.posq_corr is not None:
                 self.posq_corr[:, :3] = (p - hi.to(torch.float64)).to(torch.float32)
-        self._state_changed()
 
     def set_sites(self, x0):
         """Harness tether sites (stored in the position type, so float-rounded unless precision is double);
@@ -505,8 +505,8 @@ class HipContext(_HandleQueries):
         return self.x0[:, :3].to(self.torch.float64).cpu().numpy()
 
     def setVelocities(self, vel):
+        self._state_changed()                                # (first: refused between the steps of a deferred sequence, and then nothing is written)
         self.velm[:, :3] = self.torch.from_numpy(np.ascontiguousarray(vel, np.float64)).to(self.dev, self.mdt)
-        self._state_changed()
 
     def _state_changed(self):                                # DrudeTGNHIntegrator.cpp:166-170
         self.ke_sum_valid = False
@@ -582,25 +582,43 @@ class HipContext(_HandleQueries):
 
     def capture_steps(self, steps):
         """Captures `steps` time steps (harness force call-out included, and the KE all-reduce when sharded) into
-        a hipGraph on a side stream and returns a callable that replays it.  The step sequence must be in its
-        steady state (at least one step taken) and must not change afterwards (no setters)."""
+        a hipGraph on a side stream and returns a callable that replays it.  The step sequence must not change afterwards
+        (no setters).  A handle that is not in the steady state of its step sequence is brought there first, by up to
+        three times `steps` real steps (see below): read the step count afterwards if it matters."""
         torch = self.torch
         if self.force_fn is not None:
             raise TgnhError(_lib.ERR_STATE, "capture_steps supports the harness force call-out only")
+        # A graph replays launches, not the decisions that chose them: it may only be replayed from the state it was recorded
+        # in.  The first steps of a handle differ from the later ones (nothing pending yet, a staged thermostat block to
+        # commit), and so does a step after a query or a split step that settled part of what a step leaves owed.  So the
+        # recording is checked: what the handle owes the trajectory (tgnh_get_pending_state) must be the same after the
+        # recorded steps as before.  If it is not, the recording is a transition into the steady state: it is replayed once --
+        # which takes exactly those steps, correctly, from the state they were recorded in -- and dropped, and the steps are
+        # recorded again from where that leaves the handle.
         torch.cuda.synchronize(self.dev)
         # Consecutive streaming launches sweep the tiles in alternating directions, and a time step holds an odd number
         # of them: the launches of `steps` steps captured now and the launches of the `steps` steps after them differ in
         # that direction when `steps` is odd.  Two graphs are therefore captured back to back and replayed in turn, so a
         # replayed run issues exactly the launches the eager loop would (bitwise the same trajectory, for any `steps`).
-        graphs = []
-        clock = None
-        for _ in range(2):
+        def record():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 _check(self.lib.tgnh_run_harness(self.h, self.x0.data_ptr(), self.k_drude, self.k_tether, int(steps), self._stream()))
-            graphs.append(g)
-            if clock is None:
-                clock = self.time()
+            return g
+        for _ in range(4):
+            owed_before = self.pending_state() & 0xff
+            first = record()
+            if self.pending_state() & 0xff == owed_before:
+                break
+            first.replay()                                   # a transition: taken for real (the recording has advanced the clock)
+            torch.cuda.synchronize(self.dev)
+            self.ke_sum_valid = True
+        else:
+            raise TgnhError(_lib.ERR_STATE, "capture_steps: the handle does not reach a steady state of its step sequence")
+        clock = self.time()
+        graphs = [first, record()]
+        if self.pending_state() & 0xff != owed_before:
+            raise TgnhError(_lib.ERR_STATE, "capture_steps: the step sequence is not periodic")
         # a capture advances the host-side clock without running anything: the first one stands for the first replay,
         # the second one is taken back
         self.set_time(*clock)
@@ -618,6 +636,12 @@ class HipContext(_HandleQueries):
         replay.graph = graphs[0]
         replay.graphs = graphs
         return replay
+
+    def pending_state(self):
+        """tgnh_get_pending_state: what the handle still owes the trajectory (bit set, include/drude_tgnh.h)."""
+        bits = C.c_uint32()
+        _check(self.lib.tgnh_get_pending_state(self.h, C.byref(bits)))
+        return bits.value
 
     def status_flags(self):
         """The device's status word (bit 0 Drude beyond 2x the hard wall, bit 1 harness SHAKE not converged, bit 2 mailbox

@@ -1,0 +1,172 @@
+"""Random call sequences against the C ABI's host state machine (DrudeTGNHIntegrator.cpp:166-194: anything may happen between
+two steps -- queries, setters, a changed step size -- and the integrator must go on as if nothing had).
+
+The library steers its launches with a handful of "still owed" flags (tgnh_get_pending_state) x 4 flag combinations x 3 kinds
+of exchange; the deterministic tests walk the transitions somebody thought of.  Here a seeded random walk over the entry
+points drives a handle of every combination, and a PLAIN handle (flags 0, no exchange: the reference's own pass structure)
+is fed the same physical sequence -- the same steps, the same accepted setters at the same step boundaries; queries do not
+change physics.  Every 25 calls positions must agree to 1e-12, velocities to 1e-10 and (where the variant does not run the chain
+ahead) the thermostats to 1e-9; a call the variant refuses must be refused with TGNH_ERR_STATE, and is then not made on
+the plain handle either -- a refusal is allowed, a wrong trajectory is not."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import rel_err
+from openmm_drudenose_amd import synth, HipContext, _lib
+from openmm_drudenose_amd.drudetgnhplugin import DrudeTGNHIntegrator, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, TgnhError
+
+pytestmark = pytest.mark.gpu
+
+CALLS_PER_WALK = 500
+CHECK_EVERY = 25
+
+
+def build(flags, exchange, chains):
+    s, g, ng = synth.mixed(60, 6)
+    it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, chains, True, True)
+    it.setMaxDrudeDistance(0.02)
+    for _ in range(ng):
+        it.addTempGroup()
+    for i, gi in enumerate(g):
+        it.addParticleTempGroup(int(gi))
+    ctx = HipContext(s, it, mode="TGNH", precision="double", flags=flags)
+    if exchange == "hook":
+        ctx.set_allreduce(lambda t: None)                    # one rank: the all-reduce is the identity
+    elif exchange == "mailbox":
+        _, ptr = ctx.exchange_create(1, 0)
+        ctx.exchange_attach_pointers([ptr])
+    elif exchange == "rccl":
+        ctx.rccl_init(1, 0, ctx.rccl_unique_id())
+    return s, it, ctx
+
+
+class Walk:
+    def __init__(self, flags, exchange, chains, seed):
+        self.rng = np.random.default_rng(seed)
+        self.s, self.it, self.ctx = build(flags, exchange, chains)
+        _, self.rit, self.ref = build(0, None, chains)
+        self.flags = flags
+        self.replay = None
+        self.log = []
+
+    def both(self, fn):
+        fn(self.ctx); fn(self.ref)
+
+    def refused_or(self, call_on, apply_ref):
+        """a setter: made on the variant first; refused (ERR_STATE) = skipped on both, anything else must succeed"""
+        try:
+            call_on(self.ctx)
+        except TgnhError as e:
+            assert e.status == _lib.ERR_STATE, (self.log[-5:], e)
+            self.log.append("  (refused)")
+            return False
+        apply_ref(self.ref)
+        return True
+
+    # ---- physical operations (made on both handles)
+    def op_step(self):
+        n = int(self.rng.integers(1, 4))
+        self.both(lambda c: c.step(n))
+
+    def op_step_pieces(self):
+        self.both(lambda c: (c.step_begin(), c.compute_forces(), c.step_end()))
+
+    def op_split_step(self):
+        def split(c):
+            lib, h, st = c.lib, c.h, c._stream
+            assert lib.tgnh_step_begin_kick(h, st()) == 0
+            assert lib.tgnh_step_begin_move(h, st()) == 0
+            c.compute_forces()
+            assert lib.tgnh_step_end_kick(h, st()) == 0
+            assert lib.tgnh_step_end_thermo(h, st()) == 0
+            c.ke_sum_valid = True
+        self.both(split)
+
+    def op_graph(self):
+        """steps recorded into a hipGraph on the variant, the same number of eager steps on the plain handle"""
+        k, reps = int(self.rng.integers(1, 4)), int(self.rng.integers(1, 4))
+        before = self.ctx.time()[1]
+        rep = self.ctx.capture_steps(k)
+        for _ in range(reps):
+            rep()
+        self.ctx.torch.cuda.synchronize()
+        taken = self.ctx.time()[1] - before                  # (capture_steps takes real steps first when the handle is not in its steady state)
+        assert taken >= k * reps
+        self.ref.step(taken)
+
+    def op_set_step_size(self):
+        dt, old = float(self.rng.choice([0.001, 0.0005, 0.00075])), self.ctx.integrator.getStepSize()
+        if not self.refused_or(lambda c: c.integrator.setStepSize(dt), lambda c: c.integrator.setStepSize(dt)):
+            self.ctx.integrator._stepSize = old              # (the setter pushes to the handle: refused, the integrator keeps its value)
+
+    def op_set_drude_steps(self):
+        n, old = int(self.rng.choice([20, 10, 5])), self.ctx.integrator.getDrudeStepsPerRealStep()
+        if not self.refused_or(lambda c: c.integrator.setDrudeStepsPerRealStep(n), lambda c: c.integrator.setDrudeStepsPerRealStep(n)):
+            self.ctx.integrator._drudeSteps = old
+
+    def op_set_velocities(self):
+        """Context::setVelocities (stateChanged, DrudeTGNHIntegrator.cpp:166-170): the current velocities scaled by 0.999"""
+        v = self.ctx.getVelocities() * 0.999
+        if self.refused_or(lambda c: c.setVelocities(v), lambda c: c.setVelocities(c.getVelocities() * 0.999)):
+            self.both(lambda c: c.compute_forces())
+
+    def op_set_thermostat(self):
+        which = int(self.rng.integers(0, 2))
+        try:
+            cur = self.ctx.thermostat_state(which)
+        except TgnhError as e:
+            assert e.status == _lib.ERR_STATE
+            return
+        self.refused_or(lambda c: c.set_thermostat_state(which, cur), lambda c: None)     # (its own values: no change of physics)
+
+    # ---- queries (variant only: they must not change its trajectory)
+    def op_flush(self):
+        assert self.ctx.lib.tgnh_flush(self.ctx.h, self.ctx._stream()) == 0
+
+    def op_queries(self):
+        c = self.ctx
+        pick = int(self.rng.integers(0, 6))
+        if pick == 0:
+            c.getVelocities()
+        elif pick == 1:
+            c.kinetic_energy()
+        elif pick == 2:
+            c.last_kinetic_energies(); c.last_scale_factors()
+        elif pick == 3:
+            c.thermostat_state(int(self.rng.integers(0, 4)))
+        elif pick == 4:
+            c.compute_kinetic_energies()
+        else:
+            assert c.check() == 0 and c.time()[1] == self.ref.time()[1]
+
+    OPS = [("step", 6), ("step_pieces", 3), ("split_step", 2), ("graph", 1), ("set_step_size", 1), ("set_drude_steps", 1),
+           ("set_velocities", 1), ("set_thermostat", 1), ("flush", 2), ("queries", 5)]
+
+    def compare(self, where):
+        pos, vel = self.ctx.getPositions(), self.ctx.getVelocities()
+        ep, ev = rel_err(pos, self.ref.getPositions()), rel_err(vel, self.ref.getVelocities())
+        assert ep <= 1e-12 and ev <= 1e-10, (where, ep, ev, self.log[-12:])      # (different orders of the sums, ~800 steps: 2.6e-11 seen)
+        assert self.ctx.time() == pytest.approx(self.ref.time(), rel=1e-12) and self.ctx.check() == 0
+        if not self.flags & FLAG_DEFER_SCALE:                # (deferred: the chain has run the next step's first half already)
+            for which in (0, 1):
+                a, b = self.ctx.thermostat_state(which), self.ref.thermostat_state(which)
+                assert np.allclose(a, b, rtol=1e-9, atol=1e-12), (where, which, self.log[-12:])
+
+    def run(self):
+        names = [n for n, w in self.OPS for _ in range(w)]
+        for i in range(CALLS_PER_WALK):
+            name = names[int(self.rng.integers(0, len(names)))]
+            self.log.append(f"{i}: {name} (owed {self.ctx.pending_state():#x})")
+            getattr(self, "op_" + name)()
+            if (i + 1) % CHECK_EVERY == 0:
+                self.compare(i)
+        self.ctx.close(); self.ref.close()
+
+
+@pytest.mark.parametrize("exchange", [None, "hook", "mailbox", "rccl"])
+@pytest.mark.parametrize("flags", [0, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP])
+def test_random_call_sequences(flags, exchange):
+    chains = 1 if (flags + (0 if exchange is None else 1)) % 2 == 0 else 3          # one- and three-link chains, mixed over the grid
+    Walk(flags, exchange, chains, seed=1000 + 16 * flags + len(exchange or "")).run()
