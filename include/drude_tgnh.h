@@ -104,6 +104,19 @@ typedef struct tgnh_desc {
 
 typedef struct tgnh_context* tgnh_handle;
 
+/* What is reproducible bit for bit (no atomics anywhere in a sum; every order of additions is fixed by the topology, the grid
+ * and the direction of the sweep):
+ *   - the same handle configuration, the same state and the same step counter give the same bits from there on: the sweep
+ *     direction, which orders the additions of the kinetic-energy sums, is a function of the step counter, and queries
+ *     (tgnh_get_*, tgnh_compute_kinetic_energies, tgnh_flush) neither change it nor anything else of the trajectory -- so a
+ *     run restored from a checkpoint (thermostat arrays + tgnh_set_time) continues bit for bit, and a query asked twice
+ *     returns the same bits (the plain kinetic energy of tgnh_get_kinetic_energy included);
+ *   - the ranks of one sharded run hold bit-identical thermostats whatever each of them is asked in between: every rank adds
+ *     the same world x NT sums in rank order (mailboxes) or receives the same all-reduced values (RCCL) and runs the same
+ *     chain arithmetic, in the standalone chain kernel or inside a streaming launch;
+ *   - different pass structures (flags), grids (devices with another number of compute units) or shardings of the same
+ *     system sum in different orders: they agree to rounding (1e-12 over 100 steps), not bit for bit. */
+
 /* Collective hook for particle-sharded runs: in-place sum of `count` doubles
  * at device pointer `buf` over all ranks, enqueued on `stream` (an RCCL
  * ncclAllReduce in the glue / a torch.distributed all_reduce in the harness).

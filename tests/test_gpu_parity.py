@@ -830,6 +830,67 @@ def test_particle_sharded_mailbox_exchange_on_one_gpu(variant, chains, nranks, s
         c.close()
 
 
+@pytest.mark.parametrize("variant", [FLAG_DEFER_SCALE, 0])
+def test_mailbox_ranks_stay_bit_identical_when_one_rank_is_queried(variant):
+    """The determinism contract of include/drude_tgnh.h: the ranks of one run hold bit-identical thermostats whatever each of
+    them is asked in between.  Two ranks (handles on this GPU, mailboxes by pointer); rank 0 alone serves a query between
+    steps every few steps -- the thermostat state (which makes it run the chain in the standalone kernel where rank 1 runs it
+    inside its next rescale launch), the cached and the plain kinetic energy, the velocities (a flush: extra sweeps on rank 0
+    only).  Every rank adds the same world x NT numbers in rank order and runs the same chain arithmetic, so nothing of that
+    may show: thermostats equal bit for bit over the ranks at the end, trajectory the unsharded one."""
+    from openmm_drudenose_amd.system import shard_bounds
+    s, g, ng = synth.mixed(400, 30)
+    it = integ(chains=1, hardwall=0.02)
+    bind_groups(it, g, ng)
+    ref = HipContext(s, it, mode="TGNH", precision="double", flags=variant)
+    torch = ref.torch
+    b = shard_bounds(s, 2)
+    parts, terms, streams = [], [], []
+    for r in range(2):
+        loc, lg = s.slice_molecules(b[r], b[r + 1]), g[b[r]:b[r + 1]]
+        itr = integ(chains=1, hardwall=0.02)
+        bind_groups(itr, lg, ng)
+        parts.append(HipContext(loc, itr, mode="TGNH", precision="double", flags=variant))
+        terms.append(parts[-1].local_dof_terms())
+        streams.append(torch.cuda.Stream(priority=-r))
+    total = sum(terms)
+    boxes = [c.exchange_create(2, r)[1] for r, c in enumerate(parts)]
+    for c in parts:
+        c.set_global_dof_terms(total)
+        c.exchange_attach_pointers(boxes)
+    torch.cuda.synchronize()
+    asked = 0
+    for step in range(60):
+        ref.step_begin(); ref.compute_forces(); ref.step_end()
+        for c, st in zip(parts, streams):
+            with torch.cuda.stream(st):
+                c.step_begin(); c.compute_forces(); c.step_end()
+        if step % 4 == 3:
+            with torch.cuda.stream(streams[0]):
+                c0 = parts[0]
+                which = (step // 4) % 4
+                if which == 0:
+                    c0.thermostat_state(1)
+                elif which == 1:
+                    c0.last_kinetic_energies(); c0.kinetic_energy()
+                elif which == 2:
+                    c0.getVelocities()
+                else:
+                    c0.ke_sum_valid = False; c0.kinetic_energy(); c0.ke_sum_valid = True
+                asked += 1
+    torch.cuda.synchronize()
+    assert asked >= 12
+    for c in parts:
+        assert c.check() & 4 == 0
+    pos = np.concatenate([c.getPositions() for c in parts])
+    vel = np.concatenate([c.getVelocities() for c in parts])
+    assert rel_err(pos, ref.getPositions()) < 1e-12 and rel_err(vel, ref.getVelocities()) < 1e-10
+    for which in (0, 1, 2):
+        assert np.array_equal(parts[0].thermostat_state(which), parts[1].thermostat_state(which))
+    for c in parts + [ref]:
+        c.close()
+
+
 def test_mailbox_exchange_times_out_instead_of_hanging():
     """A peer that never sends: the wait is bounded, status bit 2 is raised, later waits return at once."""
     import time
