@@ -1580,6 +1580,8 @@ static const std::vector<int>* topo_vec(tgnh_handle h, int which) {
 extern "C" tgnh_status tgnh_get_topology_len(tgnh_handle h, int which, int* len) {
     CHECK_H(h);
     if (which == 8) { *len = (int)h->meta.size(); return TGNH_OK; }
+    if (which == 9) { *len = 2 * (int)h->wave_tile.size(); return TGNH_OK; }      // wave tiles: (first slot, largest molecule) pairs, one more than tiles; 0 = none
+    if (which == 10) { *len = (int)h->wmeta.size(); return TGNH_OK; }
     const std::vector<int>* v = topo_vec(h, which);
     if (!v) return fail(TGNH_ERR_ARG, "bad topology array id");
     *len = (int)v->size();
@@ -1588,6 +1590,8 @@ extern "C" tgnh_status tgnh_get_topology_len(tgnh_handle h, int which, int* len)
 extern "C" tgnh_status tgnh_get_topology(tgnh_handle h, int which, int32_t* out) {
     CHECK_H(h);
     if (which == 8) { std::memcpy(out, h->meta.data(), sizeof(uint32_t) * h->meta.size()); return TGNH_OK; }
+    if (which == 9) { std::memcpy(out, h->wave_tile.data(), sizeof(int2) * h->wave_tile.size()); return TGNH_OK; }
+    if (which == 10) { std::memcpy(out, h->wmeta.data(), sizeof(uint32_t) * h->wmeta.size()); return TGNH_OK; }
     const std::vector<int>* v = topo_vec(h, which);
     if (!v) return fail(TGNH_ERR_ARG, "bad topology array id");
     std::copy(v->begin(), v->end(), out);

@@ -53,6 +53,48 @@ def test_topology_bit_exact_against_oracle(name):
     assert np.array_equal((meta >> 21).astype(np.int64), s.resid - res_first_of_tile[tile_of])
 
 
+@pytest.mark.parametrize("name,com", [("pnm", True), ("nacl", True), ("il", True), ("mixed", True), ("water", True), ("mixed", False),
+                                      ("polymer", True), ("polymer", False)])
+def test_wave_tiles_and_their_words(name, com):
+    """The wave tiles of the kinetic-energy passes (wke_kernel / wstep_kernel): <= 64 consecutive slots, cut never through a
+    Drude pair and -- when the molecular COM is needed -- never through a molecule; each entry carries the tile's largest
+    molecule; the per-slot word decodes to role, group, partner, position in the molecule and its size.  A topology with a
+    molecule longer than a wavefront (and a COM to form) has no wave tiles: its KE passes stay on the tile kernel."""
+    s, g, ng = synth.polymer_in_water(150, 40) if name == "polymer" else BUILDERS[name]()       # (polymer: one 750-slot molecule)
+    it = integ(group=g, ngroups=ng, com=com)
+    t = HostTopology(s, it, mode="TGNH")
+    wt = t.topology(9).reshape(-1, 2)
+    n = s.num_particles
+    longest = np.bincount(s.resid).max()
+    if com and longest > 64:
+        assert len(wt) == 0                                  # no wave tiles: the tile kernel keeps the KE passes
+        return
+    assert len(wt) >= 2 and wt[0, 0] == 0 and wt[-1, 0] == n
+    start = wt[:, 0]
+    assert np.all(np.diff(start) > 0) and np.all(np.diff(start) <= 64)
+    tile_of = np.searchsorted(start, np.arange(n), side="right") - 1
+    assert np.all(tile_of[s.pair_drude] == tile_of[s.pair_parent])
+    w = t.topology(10).view(np.uint32)
+    assert np.array_equal(np.flatnonzero((w & 3) == 1), np.sort(s.pair_drude))
+    assert np.array_equal(np.flatnonzero((w & 3) == 2), np.sort(s.pair_parent))
+    assert np.array_equal(((w >> 2) & 255).astype(np.int32), g)
+    off = ((w >> 10) & 127).astype(np.int64) - 64
+    assert np.array_equal((np.arange(n) + off)[s.pair_drude], s.pair_parent)
+    assert np.array_equal((np.arange(n) + off)[s.pair_parent], s.pair_drude)
+    assert np.all(off[(w & 3) == 0] == 0)
+    pos, size = ((w >> 17) & 63).astype(np.int64), ((w >> 23) & 63).astype(np.int64) + 1
+    if com:
+        first = np.r_[0, np.flatnonzero(np.diff(s.resid)) + 1]
+        count = np.diff(np.r_[first, n])
+        mol = np.cumsum(np.r_[0, np.diff(s.resid) != 0])
+        assert np.array_equal(pos, np.arange(n) - first[mol]) and np.array_equal(size, count[mol])
+        assert np.all(tile_of[first] == tile_of[first + count - 1])             # no molecule is cut
+        for k in range(len(wt) - 1):
+            assert wt[k, 1] == size[start[k]:start[k + 1]].max()
+    else:
+        assert np.all(pos == 0) and np.all(size == 1) and np.all(wt[:-1, 1] == 1)
+
+
 @pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
 @pytest.mark.parametrize("com,chains,drude_chains,cmm", [(True, 1, True, False), (True, 3, False, True), (False, 4, True, True),
                                                          (True, 6, True, False)])

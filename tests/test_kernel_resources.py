@@ -27,5 +27,14 @@ def test_hot_kernels_keep_their_occupancy():
         for gb in (1, 4, 8):
             for kind in range(5):        # a whole deferred step; the halves of the reference's structure, fused and split
                 assert rows[f"step_kernel<{prec},{gb},{kind}>"][0] <= 168, (prec, gb, kind, rows[f"step_kernel<{prec},{gb},{kind}>"])   # 3 work-groups per CU
-            assert rows[f"tile_kernel<{prec},71,1>"][0] <= 168 and rows[f"tile_kernel<{prec},7,1>"][0] <= 168      # (no KE bins: one instantiation)
-            assert rows[f"tile_kernel<{prec},138,{gb}>"][0] <= 96, rows[f"tile_kernel<{prec},138,{gb}>"]   # 5 work-groups per CU
+            assert rows[f"tile_kernel<{prec},71,1,false>"][0] <= 168 and rows[f"tile_kernel<{prec},7,1,false>"][0] <= 168      # (no KE bins: one instantiation)
+            assert rows[f"tile_kernel<{prec},138,{gb},false>"][0] <= 96, rows[f"tile_kernel<{prec},138,{gb},false>"]   # 5 work-groups per CU
+            # the wave-tile kernels: the KE passes at >= 5 wavefronts per SIMD, the whole-step kernel at 4 (its one-link
+            # instantiation; the one for chains of 2-4 links carries the links' registers and runs at 2)
+            for ops in (8, 10, 138):
+                assert rows[f"wke_kernel<{prec},{ops},{gb}>"][0] <= 102, rows[f"wke_kernel<{prec},{ops},{gb}>"]
+            assert rows[f"wstep_kernel<{prec},{gb},false>"][0] <= 128, rows[f"wstep_kernel<{prec},{gb},false>"]
+            assert rows[f"wstep_kernel<{prec},{gb},true>"][0] <= 256, rows[f"wstep_kernel<{prec},{gb},true>"]
+        for ops in (1, 7, 71, 65, 19):          # the rescale launches: one-link chains at 3 work-groups per CU, 2-4 links at 2
+            assert rows[f"tile_kernel<{prec},{ops},1,false>"][0] <= 168, (prec, ops)
+            assert rows[f"tile_kernel<{prec},{ops},1,true>"][0] <= 256, (prec, ops)
