@@ -340,17 +340,19 @@ def csrc_sha():
 def pmc_traffic(precision, slots, variant):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     --pmc WRITE_SIZE in separate runs, gfx950 correction applied; tools/profile_round.py writes
-    profiles/r02_pmc_traffic.json and stamps it with the hash of csrc/).  PMC counters cannot be collected from
+    profiles/rNN_pmc_traffic.json and stamps it with the hash of csrc/).  PMC counters cannot be collected from
     inside this process, so the figure is the profiled one -- quoted only when it was taken from THIS binary
     (same source hash), the same workload and the same step variant; otherwise None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    try:
-        d = json.load(open(path))
-        if d.get("slots") != slots or d.get("csrc_sha") != csrc_sha() or d.get("variant") != variant:
-            return None, path
-        return d["kernels"]["dominant"]["hbm_bytes_per_launch"], path
-    except Exception:
-        return None, path
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")), reverse=True)
+    for path in paths:                                   # the newest round's file that was taken from this binary and workload
+        try:
+            d = json.load(open(path))
+            if d.get("slots") == slots and d.get("csrc_sha") == csrc_sha() and d.get("variant") == variant:
+                return d["kernels"]["dominant"]["hbm_bytes_per_launch"], path
+        except Exception:
+            continue
+    return None, (paths[0] if paths else None)
 
 
 def cpu_baseline(args, system, group, ngroups):

@@ -36,10 +36,17 @@ SQ = ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_AN
 
 
 def pretty(n):
-    m = re.search(r"tile_kernel<(\d), (\d+), (\d)>", n)
+    m = re.search(r"tile_kernel<(\d), (\d+), (\d)(, (true|false))?>", n)
     if m:
         ops = int(m.group(2))
-        return "tile<%s,%s>" % (PREC[int(m.group(1))], "+".join(v for k, v in OPS.items() if ops & k))
+        return "tile<%s,%s>%s" % (PREC[int(m.group(1))], "+".join(v for k, v in OPS.items() if ops & k), " (chains of 2-4 links)" if m.group(5) == "true" else "")
+    m = re.search(r"wke_kernel<(\d), (\d+), (\d)>", n)
+    if m:
+        ops = int(m.group(2))
+        return "wke<%s,%s>" % (PREC[int(m.group(1))], "+".join(v for k, v in OPS.items() if ops & k))
+    m = re.search(r"wstep_kernel<(\d), (\d), (true|false)>", n)
+    if m:
+        return "wstep_kernel<%s,deferred step>%s" % (PREC[int(m.group(1))], " (chains of 2-4 links)" if m.group(3) == "true" else "")
     m = re.search(r"step_kernel<(\d), (\d), (\d)>", n)
     if m:
         return "step_kernel<%s,%s>" % (PREC[int(m.group(1))], STEP_KINDS[int(m.group(3))])
@@ -100,7 +107,7 @@ def main():
     rows = list(csv.DictReader(open(stats)))
     prec = line["config"]["precision"]
     if line["roofline"]["kernel"] == "step_kernel":
-        dom = f"step_kernel<{prec},{'deferred step' if variant == 'resident' else 'plain begin half'}>"
+        dom = f"wstep_kernel<{prec},deferred step>" if variant == "resident" else f"step_kernel<{prec},plain begin half>"
     else:
         dom = f"tile<{prec},{'prekick+' if variant == 'defer' else ''}rescale+kick+drift>"
     with open(os.path.join(prof, f"{a.tag}_summary.md"), "w") as f:
