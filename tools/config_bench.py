@@ -10,12 +10,15 @@ CFG = [("C1 nacl", synth.nacl, 0.02), ("C2 SWM4 32k", lambda: synth.water_box(64
        ("C3 ionic liquid 100k", lambda: synth.ionic_liquid(2222), 0.0),
        ("C4 mixed 500k + hard wall", lambda: synth.mixed(60000, 4444), 0.02),
        ("C5 SWM4 2M", lambda: synth.water_box(400000), 0.0), ("metric SWM4 1M pairs", lambda: synth.water_box(1000000), 0.02)]
-print("| config | N slots | pairs | groups | precision | variant | steps/s eager | steps/s hipGraph | B_step model | GB/s vs model |")
-print("|---|---|---|---|---|---|---|---|---|---|")
+print("| config | N slots | pairs | groups | precision | variant | numNHChains | steps/s eager | steps/s hipGraph | B_step model | GB/s vs model |")
+print("|---|---|---|---|---|---|---|---|---|---|---|")
 for name, build, hw in CFG:
     s, g, ng = build()
-    for prec, var in (("mixed", "defer"), ("mixed", "resident"), ("single", "resident" if s.num_particles < 2000000 else "defer")):
-        it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, 1, True, True)
+    runs = [("mixed", "defer", 1), ("mixed", "resident", 1), ("single", "resident" if s.num_particles < 2000000 else "defer", 1)]
+    if name.startswith("C2") or name.startswith("metric"):       # longer chains: 3 links (in-kernel below 2 M slots) and the reference test's own 10
+        runs += [("mixed", "resident", 3), ("mixed", "defer", 3), ("mixed", "resident", 10), ("mixed", "defer", 10)]
+    for prec, var, chains in runs:
+        it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, chains, True, True)
         it.setMaxDrudeDistance(hw)
         for _ in range(ng): it.addTempGroup()
         it._particleTempGroup = g.astype("int32")
@@ -29,5 +32,5 @@ for name, build, hw in CFG:
         torch.cuda.synchronize(); graph = n / (time.perf_counter() - t0)
         V = 16 if prec == "single" else 32
         b = s.num_particles * (7 * V + 48 + 2 * V)
-        print(f"| {name} | {s.num_particles} | {s.num_pairs} | {ng} | {prec} | {var} | {eager:.0f} | {graph:.0f} | {b/1e6:.1f} MB | {b*max(eager,graph)/1e9:.0f} |", flush=True)
+        print(f"| {name} | {s.num_particles} | {s.num_pairs} | {ng} | {prec} | {var} | {chains} | {eager:.0f} | {graph:.0f} | {b/1e6:.1f} MB | {b*max(eager,graph)/1e9:.0f} |", flush=True)
         ctx.close()
