@@ -60,6 +60,12 @@ enum { TGNH_FLAG_DEFER_SCALE = 2 };    /* the end-of-step rescale AND the second
                                         * into the next step's first pass: between tgnh_step_end and the next
                                         * tgnh_step_begin velm lags and the force buffer must stay as it is; tgnh_flush
                                         * makes velm the reference's end-of-step state.  (1 is reserved.) */
+enum { TGNH_FLAG_WAVE_TILES = 8 };     /* run the kinetic-energy passes and the one-launch deferred step over wave tiles (one
+                                        * wavefront = <= 64 slots) whenever the topology has them -- every molecule and
+                                        * pair inside a wavefront, <= 8 temperature groups -- whatever their fill.  Without the
+                                        * flag the library takes them only where they are >= 90 % full (60-slot water tiles: yes;
+                                        * 35-slot cations: no, the 512-slot tile kernels are faster there).  Same integrator
+                                        * either way. */
 enum { TGNH_FLAG_RESIDENT_STEP = 4 };  /* whole thermostat halves in ONE launch whose work-groups meet on the device
                                         * (step_kernel).  Alone: the reference's pass structure, two launches per
                                         * step (KE + chain + rescale, kick, drift | kick + KE + chain + rescale), velocities

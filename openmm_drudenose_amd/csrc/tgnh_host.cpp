@@ -520,7 +520,8 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     // tile ends where a molecule does, so 35-slot cations leave 45 of 64 lanes busy and the 512-slot tiles, cut the same way but
     // eight times as long, win (ionic liquid 100 k: 42.0 k steps/s on the tile kernels, 40.3 k on wave tiles; 60-slot water
     // tiles: 94 % full)
-    c->wave_ke = !c->wave_tile.empty() && c->gb != 0 && (double)d->num_particles >= 0.9 * WAVE_SLOTS * (double)c->num_wtiles;
+    c->wave_ke = !c->wave_tile.empty() && c->gb != 0 &&
+                 ((d->flags & TGNH_FLAG_WAVE_TILES) || (double)d->num_particles >= 0.9 * WAVE_SLOTS * (double)c->num_wtiles);
 #ifdef TGNH_TUNING
     if (const char* e = getenv("TGNH_WAVE_KE")) c->wave_ke = c->wave_ke && e[0] != '0';
 #endif
