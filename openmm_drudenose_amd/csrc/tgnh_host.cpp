@@ -583,6 +583,13 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         HIP_OK(hipMalloc(&c->d_scalar, sizeof(double) * (1 + PLAIN_KE_PARTS)));
         HIP_OK(hipMalloc(&c->d_sync, 4 * sizeof(unsigned int)));
         HIP_OK(hipMemset(c->d_sync, 0, 4 * sizeof(unsigned int)));
+        if (c->wave_ke && !(c->d.flags & TGNH_FLAG_RESIDENT_STEP)) {      // the tagged rows of wke_kernel's tail sum
+            const size_t rb = sizeof(unsigned long long) * 2 * (size_t)GRID_CAP * CHAIN_INLINE_SUM_NT;
+            void* p = nullptr;
+            HIP_OK(hipExtMallocWithFlags(&p, rb, TGNH_MEETING_MEM));
+            c->d_rows = static_cast<unsigned long long*>(p);
+            HIP_OK(hipMemset(c->d_rows, 0, rb));
+        }
         if (c->d.flags & TGNH_FLAG_RESIDENT_STEP) {
             // step_kernel's meeting place: the work-groups' tagged rows, and a private one-rank mailbox that carries the
             // sums from work-group 0 to all the others when no sharded exchange is attached.  Both stay on this device:
@@ -1099,6 +1106,11 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
         h->stage_pending = false;
     }
     if (ops & OP_KE) {
+        // wave tiles: where a launch that only sums the partial rows would follow (an all-reduce waits for the sums, or the
+        // system is too large for the next rescale launch to sum them in its prologue), work-group 0 of this launch does it
+        h->tail_summed = wave && h->d_rows && !h->xchg_on && h->L.NT <= CHAIN_INLINE_SUM_NT &&
+                         !(h->inline_chain && !h->allreduce && (grid + h->num_big <= h->inline_sum_rows || h->inline_sum_all));
+        if (h->tail_summed) { a.tail_sum = 1; a.rows = h->d_rows; a.sync = h->d_sync; a.ke_red = h->d_state + h->L.off_ke_red; }
         h->ke_parts = grid;
         if (h->num_big && a.use_com) {
             // COM velocity of every big molecule for the velocities this launch reduces: the current ones, or the
@@ -1168,9 +1180,11 @@ static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
         h->chain_pending = true; h->sum_pending = true; h->chain_pending_twice = twice;
         return TGNH_OK;
     }
+    const bool summed = h->tail_summed;       // wke_kernel's tail sum: ke_red is complete, no row-sum launch (and nothing staged: a KE launch commits)
+    h->tail_summed = false;
     if (h->inline_chain) {           // sum (and all-reduce) now, the chain itself inside the next rescale launch
         a.do_sum = 1; a.do_chain = 0;
-        { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
+        if (!summed) { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
         if (h->allreduce && h->allreduce(h->d_state + h->L.off_ke_red, h->L.NT, (void*)s, h->allreduce_user) != 0)
             return fail(TGNH_ERR_HIP, "all-reduce hook failed");
         h->chain_pending = true; h->chain_pending_twice = twice;
@@ -1178,13 +1192,13 @@ static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
     }
     if (h->allreduce) {
         a.do_sum = 1; a.do_chain = 0;
-        { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
+        if (!summed) { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
         if (h->allreduce(h->d_state + h->L.off_ke_red, h->L.NT, (void*)s, h->allreduce_user) != 0)
             return fail(TGNH_ERR_HIP, "all-reduce hook failed");
         a.do_sum = 0; a.do_chain = 1; a.commit = 0;
         { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
     } else {
-        a.do_sum = 1; a.do_chain = 1;
+        a.do_sum = summed ? 0 : 1; a.do_chain = 1;
         Timed t(h, s, KID_CHAIN);
         HIP_OK(launch_chain(a, s));
     }
@@ -1615,7 +1629,8 @@ extern "C" tgnh_status tgnh_compute_kinetic_energies(tgnh_handle h, void* stream
     ChainArgs a = chain_args(h);
     a.do_sum = 1; a.do_chain = 0;
     if (h->xchg_on) { a.x_send = 1; a.x_wait = 1; }
-    HIP_OK(launch_chain(a, s));
+    if (!h->tail_summed) HIP_OK(launch_chain(a, s));       // (summed by the KE launch itself where the step's own KE launch is: the same bits)
+    h->tail_summed = false;
     if (!h->xchg_on && h->allreduce && h->allreduce(h->d_state + h->L.off_ke_red, h->L.NT, (void*)s, h->allreduce_user) != 0)
         return fail(TGNH_ERR_HIP, "all-reduce hook failed");
     HIP_OK(hipMemcpyAsync(h->d_state + h->L.off_ke, h->d_state + h->L.off_ke_red, sizeof(double) * h->L.NT,

@@ -184,6 +184,10 @@ struct TileArgs {
     const int2* wave_tile;     // [num_wtiles + 1]: (first slot, slots of the tile's largest molecule); the next entry's first slot ends it
     const uint32_t* wmeta;     // per-slot word of the wave tiles (pack_wmeta)
     int num_wtiles;
+    // wke_kernel, tail sum: the rows go out as tagged cells (`rows`, `sync`, as in step_kernel) and work-group 0, when its own
+    // tiles are done, collects them in row order and leaves the sums in ke_red -- the launch that only summed the rows is gone
+    int tail_sum;
+    double* ke_red;            // [NT] the thermostat block's summed kinetic energies
     int num_tiles;
     int reverse;               // walk the tiles last-to-first: start where the previous launch ended (its lines are still in the Infinity Cache)
     int padded;
@@ -282,6 +286,7 @@ struct tgnh_context {
     int num_wtiles = 0;
     int2* d_wave_tile = nullptr;
     uint32_t* d_wmeta = nullptr;
+    bool tail_summed = false;         // the last KE launch summed its rows itself (wke_kernel's tail sum): no row-sum launch
     bool wave_ke = false;             // the KE passes run over the wave tiles (wke_kernel)
     // dof bookkeeping (A2)
     std::vector<double> local_terms, global_terms;   // per thermostat, before CMM correction

@@ -813,6 +813,10 @@ __device__ __forceinline__ void wave_load(const TileArgs& a, const int ws, const
     }
 }
 
+template <int GB, bool LEAN, int NTH>
+__device__ __forceinline__ bool collect_rows(const TileArgs& a, const int tid, const int grid, const int NT, const unsigned long long want,
+                                             double (&acc)[GB + 2]);
+
 template <int PREC, int OPS, int GB>
 __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileArgs a) {
     typedef typename Prec<PREC>::mixed mixed;
@@ -835,6 +839,8 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileAr
     double ke_g[GB], ke_com = 0.0, ke_drude = 0.0;
 #pragma unroll
     for (int b = 0; b < GB; b++) ke_g[b] = 0.0;
+    // tail sum: this launch's number (the tag of its rows), read before anything is handed in
+    const unsigned gen0 = a.tail_sum ? __hip_atomic_load(&a.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 
     // Wave tile of wavefront wv in round r: (r gridDim.x + blockIdx.x) 4 + wv -- a work-group streams 4 consecutive wave
     // tiles.  Everything about WHICH tile is wavefront-uniform (scalar registers, scalar loads): the bounds of the tile after
@@ -935,58 +941,54 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileAr
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < TBLOCK / 64; k++) t += sred[k][tid];
-        double* row = a.partials + (size_t)blockIdx.x * (G + 2);
-        if (tid < GB) { if (tid < G) row[tid] = t; }
-        else row[G + (tid - GB)] = t;
+        const int b = tid < GB ? tid : G + (tid - GB);                 // thermostat of this thread's sum
+        if (tid >= GB || tid < G) {
+            if (a.tail_sum) {                                            // a tagged cell: data and "it is there" in one 8-byte store, two per double
+                unsigned long long* cell = a.rows + row_word((int)blockIdx.x, 2 * b);
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(t), tg = (unsigned long long)(gen0 + 1u) << 32;
+                __hip_atomic_store(cell, tg | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(cell + 64, tg | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else a.partials[(size_t)blockIdx.x * (G + 2) + b] = t;
+        }
+    }
+    // ---- tail sum: work-group 0 -- which therefore ends last -- collects every work-group's row in row order (fixed order:
+    // reproducible bits) and leaves the sums where the row-sum launch would have.  Only it waits, so the grid need not be
+    // resident at once; the polling is bounded (status bit 3, as step_kernel's).
+    if (a.tail_sum && blockIdx.x == 0) {
+        __shared__ double s_tail[TBLOCK / 64][GB + 2];
+        const int NT = G + 2;
+        double acc[GB + 2];
+#pragma unroll
+        for (int b = 0; b < GB + 2; b++) acc[b] = 0.0;
+        const bool ok = collect_rows<GB, false, TBLOCK>(a, tid, (int)gridDim.x, NT, (unsigned long long)(gen0 + 1u), acc);
+        if (!ok) atomicOr(a.status, 8u);
+#pragma unroll
+        for (int b = 0; b < GB + 2; b++) {
+            if (b < NT) {
+                const double t = wave_sum(acc[b]);
+                if (lane == 0) s_tail[wv][b] = t;
+            }
+        }
+        __syncthreads();
+        if (tid < NT) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < TBLOCK / 64; k++) t += s_tail[k][tid];
+            a.ke_red[tid] = t;
+        }
+        if (tid == 0) a.sync[1] = gen0 + 1u;                             // the next launch's rows carry the next tag
     }
 }
 
-// The meeting of step_kernel / wstep_kernel: every work-group hands in its row of kinetic-energy sums (tagged cells), work-group 0
-// collects them in a fixed order and sends the sums to the mailbox of every rank, one wavefront of every work-group waits for all
-// ranks' sums and runs both chain halves (the scale factors land in sh.s_scale).  `prefetch` is called between handing in the
-// row and the wait: the loads the second pass will need.  Returns false when an exchange timed out (nothing may be stored).
-struct MeetShared {
-    double* s_scale;                                  // [MAX_GROUPS + 2]
-    double (*s_part)[CHAIN_INLINE_SUM_NT];            // [TBLOCK / 64]
-    double* s_x;                                      // [64 + XCHG_MAX_WORLD * CHAIN_INLINE_SUM_NT]
-    int* s_go_p; unsigned* s_gen_p; unsigned long long* s_seq1_p;
-    const double* s_block;                            // MULTI: the thermostat block as it was at kernel entry (chains of 2-4 links)
-};
-template <int PREC, int GB, bool LEAN = false, int NTH = TBLOCK, bool MULTI = false, typename Prefetch>
-__device__ __forceinline__ bool step_meet(const TileArgs& a, TileEnv<PREC, GB>& e, const unsigned gen0, const unsigned long long seq0,
-                                          Chain1Regs& creg, const MeetShared& sh, Prefetch&& prefetch) {
-    double* const s_scale = sh.s_scale; double (*const s_part)[CHAIN_INLINE_SUM_NT] = sh.s_part; double* const s_x = sh.s_x;
-    int& s_go = *sh.s_go_p; unsigned& s_gen = *sh.s_gen_p; unsigned long long& s_seq1 = *sh.s_seq1_p;
-    const int tid = threadIdx.x, G = a.num_groups, NT = G + 2, grid = (int)gridDim.x;
-    const bool chain_wave = tid < 64, leader = blockIdx.x == 0;
-    const int itg = tid & 63;
-    const ChainLayout& L = a.chain.L;
-    // the thermostat block has been read (its values are in registers) before this work-group's row is stored
-    if (chain_wave) asm volatile("" :: "v"(creg.eta), "v"(creg.etaDot0), "v"(creg.etaDot1), "v"(creg.etaDotDot), "v"(creg.etaMass), "v"(creg.nkbt) : "memory");
-    ke_reduce<PREC, GB, true, NTH>(a, e, gen0 + 1u, s_x);
-    TRACE(2);
-    // what the second pass needs of the held tile beyond what is in registers (its positions): issued now, needed after the meeting
-    prefetch();
-    // ... and what the chain can form without the sums (index map, constants, 1/Q, expfac): done while the others still work
-    // (single precision: its 16 registers there would cost the kernel its fourth work-group per compute unit)
-    constexpr bool EARLY_PRE = PREC != TGNH_PREC_SINGLE && !LEAN;      // (LEAN: wstep_kernel, which lives on a small register count)
-    Chain1Pre cpre{};
-    if (EARLY_PRE && chain_wave && !L.c1_quirk && !(MULTI && L.C > 1)) cpre = chain1_prepare(a.chain, creg, itg);
-
-    // ---- meet: work-group 0 collects the rows.  Thread t owns rows t, t + 256, ...: it polls their cells until all
-    // carry this launch's tag and adds them in row order; then 64-lane sums and one LDS hop, fixed order throughout.
-    if (tid == 0) { s_gen = gen0; s_seq1 = seq0 + 1ull; }
-    __syncthreads();
-    const unsigned long long want = (unsigned long long)(s_gen + 1u);
-    if (leader) {
-        unsigned long long* const my_peer = xchg_peer_of(a.chain.x, tid);   // for the send: fetched before the collection, not after
-        constexpr int NTM = GB + 2;                        // NT = G + 2 <= GB + 2: the register arrays follow the instantiation
-        double acc[NTM];
-#pragma unroll
-        for (int b = 0; b < NTM; b++) acc[b] = 0.0;
-        bool ok = true;
-        TRACE(6);
-        // RB rows of this thread per batch of loads (all of them for the resident grid of 768 when G = 1): once the last row
+// Work-group 0 collects the tagged rows of a launch (ke_reduce<TAGGED>): thread t owns rows t, t + NTH, ...: it polls their cells
+// until all carry `want` and adds them in row order into acc[] (fixed order: reproducible bits).  Returns false when a row
+// never came (bounded polling).
+template <int GB, bool LEAN, int NTH>
+__device__ __forceinline__ bool collect_rows(const TileArgs& a, const int tid, const int grid, const int NT, const unsigned long long want,
+                                             double (&acc)[GB + 2]) {
+    constexpr int NTM = GB + 2;
+    bool ok = true;
+    // RB rows of this thread per batch of loads (all of them for the resident grid of 768 when G = 1): once the last row
         // is there, one more round trip sees everything -- polled row after row, a thread whose first row came last paid
         // a round trip for each of the others behind it.  CH thermostats of a row per batch: the registers a batch takes
         // (2 x CH x RB words) do not grow with the number of temperature groups.  A row seen complete is not read again: a
@@ -1036,6 +1038,55 @@ __device__ __forceinline__ bool step_meet(const TileArgs& a, TileEnv<PREC, GB>& 
                         }
             }
         }
+    return ok;
+}
+
+// The meeting of step_kernel / wstep_kernel: every work-group hands in its row of kinetic-energy sums (tagged cells), work-group 0
+// collects them in a fixed order and sends the sums to the mailbox of every rank, one wavefront of every work-group waits for all
+// ranks' sums and runs both chain halves (the scale factors land in sh.s_scale).  `prefetch` is called between handing in the
+// row and the wait: the loads the second pass will need.  Returns false when an exchange timed out (nothing may be stored).
+struct MeetShared {
+    double* s_scale;                                  // [MAX_GROUPS + 2]
+    double (*s_part)[CHAIN_INLINE_SUM_NT];            // [TBLOCK / 64]
+    double* s_x;                                      // [64 + XCHG_MAX_WORLD * CHAIN_INLINE_SUM_NT]
+    int* s_go_p; unsigned* s_gen_p; unsigned long long* s_seq1_p;
+    const double* s_block;                            // MULTI: the thermostat block as it was at kernel entry (chains of 2-4 links)
+};
+template <int PREC, int GB, bool LEAN = false, int NTH = TBLOCK, bool MULTI = false, typename Prefetch>
+__device__ __forceinline__ bool step_meet(const TileArgs& a, TileEnv<PREC, GB>& e, const unsigned gen0, const unsigned long long seq0,
+                                          Chain1Regs& creg, const MeetShared& sh, Prefetch&& prefetch) {
+    double* const s_scale = sh.s_scale; double (*const s_part)[CHAIN_INLINE_SUM_NT] = sh.s_part; double* const s_x = sh.s_x;
+    int& s_go = *sh.s_go_p; unsigned& s_gen = *sh.s_gen_p; unsigned long long& s_seq1 = *sh.s_seq1_p;
+    const int tid = threadIdx.x, G = a.num_groups, NT = G + 2, grid = (int)gridDim.x;
+    const bool chain_wave = tid < 64, leader = blockIdx.x == 0;
+    const int itg = tid & 63;
+    const ChainLayout& L = a.chain.L;
+    // the thermostat block has been read (its values are in registers) before this work-group's row is stored
+    if (chain_wave) asm volatile("" :: "v"(creg.eta), "v"(creg.etaDot0), "v"(creg.etaDot1), "v"(creg.etaDotDot), "v"(creg.etaMass), "v"(creg.nkbt) : "memory");
+    ke_reduce<PREC, GB, true, NTH>(a, e, gen0 + 1u, s_x);
+    TRACE(2);
+    // what the second pass needs of the held tile beyond what is in registers (its positions): issued now, needed after the meeting
+    prefetch();
+    // ... and what the chain can form without the sums (index map, constants, 1/Q, expfac): done while the others still work
+    // (single precision: its 16 registers there would cost the kernel its fourth work-group per compute unit)
+    constexpr bool EARLY_PRE = PREC != TGNH_PREC_SINGLE && !LEAN;      // (LEAN: wstep_kernel, which lives on a small register count)
+    Chain1Pre cpre{};
+    if (EARLY_PRE && chain_wave && !L.c1_quirk && !(MULTI && L.C > 1)) cpre = chain1_prepare(a.chain, creg, itg);
+
+    // ---- meet: work-group 0 collects the rows.  Thread t owns rows t, t + 256, ...: it polls their cells until all
+    // carry this launch's tag and adds them in row order; then 64-lane sums and one LDS hop, fixed order throughout.
+    if (tid == 0) { s_gen = gen0; s_seq1 = seq0 + 1ull; }
+    __syncthreads();
+    const unsigned long long want = (unsigned long long)(s_gen + 1u);
+    if (leader) {
+        unsigned long long* const my_peer = xchg_peer_of(a.chain.x, tid);   // for the send: fetched before the collection, not after
+        constexpr int NTM = GB + 2;                        // NT = G + 2 <= GB + 2: the register arrays follow the instantiation
+        double acc[NTM];
+#pragma unroll
+        for (int b = 0; b < NTM; b++) acc[b] = 0.0;
+        bool ok = true;
+        TRACE(6);
+        ok = collect_rows<GB, LEAN, NTH>(a, tid, grid, NT, want, acc);
         TRACE(10);
         if (!ok) {                                         // a work-group never handed in its row: nobody goes on (no send below)
             atomicOr(a.status, 8u);
