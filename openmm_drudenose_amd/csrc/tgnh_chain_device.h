@@ -837,6 +837,89 @@ __device__ __forceinline__ void run_dualnh(const ChainArgs& a, const double* st_
     }
 }
 
+// ---- chains of 5-16 links (TGNH): the links of a thermostat across the lanes of a 16-lane row --------------------------------
+// run_tgnh<0> keeps such a chain in LDS (dynamic indexing rules registers out): every access is a ~100-cycle round trip on a
+// path that is serial by nature -- ~180 us per time step for the ten links of the reference's own test
+// (TestReferenceDrudeTGNHIntegrator.cpp:166).  Here lane l of a row holds link l of the row's thermostat in REGISTERS and the
+// sweeps of Cu :566-571 / :586-592 run as C steps in which every lane forms its candidate update from its neighbour's current
+// value (one DPP row shift) and the lane whose turn it is commits it: same arithmetic, same order per link, no memory on the
+// path.  16 thermostats per 256-thread work-group and batch.  exp(-dtc/8 etaDot[i+1]) of the ascending sweep is the factor
+// the descending sweep left in the lane (etaDot[i+1] has not moved in between): taken once, as in chain_real_core<CC >= 2>.
+template <int CTRL> __device__ __forceinline__ double chain_dpp(const double x) {      // row_shl:1 = 0x101 (lane + 1), row_shr:1 = 0x111 (lane - 1); 0 at a row's end
+    const int xl = __double2loint(x), xh = __double2hiint(x);
+    const int lo = __builtin_amdgcn_update_dpp(xl, xl, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(xh, xh, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void chain_lanes_run(const ChainArgs& a, double* st, const int tid, const int nthreads, const double* s_ke) {
+    const ChainLayout& L = a.L;
+    const int C = L.C, NT = L.NT, link = tid & 15;
+    const double dtc = a.dt / a.S;                                   // Cu :440-443
+    const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
+    const int reps = a.chain_twice ? 2 : 1;
+    for (int t0 = 0; t0 < NT; t0 += nthreads / 16) {                 // (uniform trip count: every lane runs every batch)
+        const int t = t0 + (tid >> 4);
+        const bool valid = t < NT && link < C;
+        const bool drude = t == NT - 1;
+        const int tt = t < NT ? t : NT - 1;                          // (idle rows shadow the last thermostat, store nothing)
+        const int li = link < C ? link : C - 1;
+        double eta = st[L.off_eta + tt * C + li], ed = st[L.off_etaDot + tt * (C + 1) + li], edd = st[L.off_etaDotDot + tt * C + li];
+        const double Q = st[L.off_etaMass + tt * C + li], dummy = st[L.off_etaDot + tt * (C + 1) + C];
+        const double nkbt = st[L.off_nkbt + tt], kbT = drude ? a.drudekbT : a.realkbT;
+        const bool live = drude || Q > 0;                            // (asked of link 0: Cu :561 vs :605)
+        const int nmove = (drude && !L.use_drude_chains) ? 1 : C;    // Cu :607-614, :633-641: the Drude thermostat's higher links only with useDrudeNHChains
+        const bool mine = valid && link < nmove;
+        const double invQ = Q > 0 ? 1.0 / Q : 0.0;
+        const double Qprev = chain_dpp<0x111>(Q);
+        double ke = s_ke[tt];
+        if (valid && link == 0) st[L.off_ke + t] = ke;               // KE before the chain (Cu :490)
+        double total = 1.0, ef = 1.0;
+        for (int rep = 0; rep < reps; rep++) {
+            double scale = 1.0;
+            if (link == 0 && live) edd = (ke - nkbt) * invQ;         // Cu :561-563, :605
+            for (int iter = 0; iter < a.S; iter++) {
+                for (int i = C - 1; i >= 0; i--) {                   // Cu :566-571 / :607-618
+                    const double nb = chain_dpp<0x101>(ed);
+                    const double efn = chain_exp<false>(-dtc8 * (link == C - 1 ? dummy : nb));
+                    double cand = ed * efn;
+                    cand += edd * dtc4;
+                    cand *= efn;
+                    if (mine && link == i) { ed = cand; ef = efn; }
+                }
+                {                                                    // Cu :573-577 / :620-623
+                    const double e = chain_exp<false>(-dtc2 * ed);
+                    if (link == 0) { scale *= e; ke *= e * e; }
+                }
+                if (mine) eta += dtc2 * ed;
+                if (link == 0 && live) edd = (ke - nkbt) * invQ;     // Cu :579-581 / :629
+                if (mine && link == 0) { ed *= ef; ed += edd * dtc4; ed *= ef; }       // Cu :583-585 / :630-632 (link 0's expfac reused)
+                for (int i = 1; i < C; i++) {                        // Cu :586-592 / :633-641
+                    const double prev = chain_dpp<0x111>(ed);
+                    if (mine && link == i) {
+                        ed *= ef;
+                        edd = (Qprev * prev * prev - kbT) * invQ;
+                        ed += edd * dtc4;
+                        ed *= ef;
+                    }
+                }
+            }
+            if (valid && link == 0) {
+                if (rep == 0) { st[L.off_scale_a + t] = scale; st[L.off_ke_post + t] = ke; }
+                else st[L.off_scale_b + t] = scale;
+            }
+            total *= scale;
+        }
+        if (valid) {
+            st[L.off_eta + t * C + link] = eta; st[L.off_etaDot + t * (C + 1) + link] = ed; st[L.off_etaDotDot + t * C + link] = edd;
+            if (link == 0) {
+                if (reps == 1) st[L.off_scale_b + t] = 1.0;
+                st[L.off_scale + t] = total;
+            }
+        }
+    }
+}
+
 // Chains of 2-4 links inside a streaming launch (the one-link chains have chain1_run): called by the 64 lanes of one
 // wavefront, converged; lane itg < NT holds its thermostat's summed kinetic energy `ke`.  TGNH: lane itg runs its thermostat
 // (run_tgnh, register-resident links; the real thermostats and the Drude thermostat are two code paths of one wavefront

@@ -1701,7 +1701,14 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
     chain_prologue(a, sred, s_chain, s_ke);
     if (!a.do_chain) return;
     if (!a.do_sum) __syncthreads();
-    if (L.mode == TGNH_MODE_TGNH) {
+    if (L.mode == TGNH_MODE_TGNH && L.C > 4 && L.C <= 16) {
+        chain_lanes_run(a, st, tid, BLOCK, s_ke);                    // 5-16 links: a link per lane, in registers
+        if (tid == 0) {                                              // Cu :493-497
+            double s = 0.0;
+            for (int i = 0; i < NT; i++) s += s_ke[i];
+            st[L.off_kesum] = 0.5 * s;
+        }
+    } else if (L.mode == TGNH_MODE_TGNH) {
         // real thermostats on lanes 0..NT-2 of wave 0, the Drude thermostat on lane 0 of wave 1: the two code
         // paths then run side by side on two SIMDs instead of one after the other under one exec mask
         int itg = -1;

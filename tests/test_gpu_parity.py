@@ -183,6 +183,13 @@ CASES = [
     ("polymer", "TGNH", 1, True, True, 0.0),              # molecule longer than a tile: COM from big_com_kernel
     ("polymer", "TGNH", 3, True, True, 0.0),
     ("polymer", "dualNH", 1, True, True, 0.0),
+    ("mixed", "TGNH", 10, True, True, 0.0),               # chains of 5-16 links: a link per lane (chain_lanes_run); 10 = the reference test's value
+    ("mixed", "TGNH", 6, False, True, 0.02),              # ... the Drude thermostat's higher links frozen
+    ("groups12", "TGNH", 7, True, True, 0.0),             # ... 14 thermostats: one batch of 16 rows
+    ("groups32", "TGNH", 5, True, False, 0.0),            # ... 34 thermostats: three batches; COM thermostat inert (Q = 0)
+    ("water27", "TGNH", 16, True, True, 0.0),             # ... a full row
+    ("water27", "TGNH", 17, True, True, 0.0),             # longer still: the LDS-resident chain
+    ("water27", "dualNH", 10, False, True, 0.0),          # the Reference platform's own test setting (LDS-resident, quirk coupling)
     ("water27", "dualNH", 1, True, True, 0.02),           # dualNH one-link chains: the in-kernel chain's code path
     ("mixed", "dualNH", 1, True, True, 0.0),
 ]
