@@ -157,6 +157,7 @@ struct ChainArgs {
     int do_sum;                // sum partials -> ke_red
     int do_chain;              // run the chain from ke_red
     int chain_twice;           // DEFER_SCALE: second half of step n and first half of step n+1 back to back
+    int lanes;                 // chains of 5-16 links (TGNH): a link per lane (chain_lanes_run) instead of LDS-resident links
     double dt;
     int S;
     double dtc, inv_dtc;       // dt / S and its reciprocal, formed on the host (a division is a dozen fp64 instructions of the chain wavefront)

@@ -1701,7 +1701,7 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
     chain_prologue(a, sred, s_chain, s_ke);
     if (!a.do_chain) return;
     if (!a.do_sum) __syncthreads();
-    if (L.mode == TGNH_MODE_TGNH && L.C > 4 && L.C <= 16) {
+    if (L.mode == TGNH_MODE_TGNH && L.C > 4 && L.C <= 16 && a.lanes) {
         chain_lanes_run(a, st, tid, BLOCK, s_ke);                    // 5-16 links: a link per lane, in registers
         if (tid == 0) {                                              // Cu :493-497
             double s = 0.0;
