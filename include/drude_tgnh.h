@@ -277,6 +277,10 @@ tgnh_status tgnh_half_kick(tgnh_handle h, void* stream);                        
  * written in OpenMM's fixed-point layout into `force_out` (int64 [3*padded]). */
 tgnh_status tgnh_harness_force(tgnh_handle h, const void* x0, double k_drude, double k_tether,
                                void* force_out, void* stream);
+/* Packs the sites once (synchronous; x0 as above, its writes complete): the tethered slots' sites only, 12 or 24 B each,
+ * and one byte per slot in place of the meta word.  Afterwards tgnh_harness_force / tgnh_run_harness* accept x0 = NULL
+ * and read the packed form (the same forces bit for bit). */
+tgnh_status tgnh_harness_pack_sites(tgnh_handle h, const void* x0);
 /* nsteps x { step_begin, harness force into the bound force buffer, step_end }
  * enqueued back to back with no host synchronisation. */
 tgnh_status tgnh_run_harness(tgnh_handle h, const void* x0, double k_drude, double k_tether,

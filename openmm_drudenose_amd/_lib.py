@@ -86,6 +86,7 @@ SIGNATURES = {
     "tgnh_compute_kinetic_energies": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_half_kick": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_harness_force": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "tgnh_harness_pack_sites": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_run_harness": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "tgnh_harness_set_clusters": (C.c_int, [C.c_void_p, C.c_int, c_i32p, c_f64p]),
     "tgnh_harness_shake_positions": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),

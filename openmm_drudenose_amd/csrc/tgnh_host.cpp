@@ -451,6 +451,9 @@ static void free_device(tgnh_context* c) {
     if (c->d_res_table) (void)hipFree(c->d_res_table);
     if (c->d_wave_tile) (void)hipFree(c->d_wave_tile);
     if (c->d_wmeta) (void)hipFree(c->d_wmeta);
+    if (c->d_sflag) (void)hipFree(c->d_sflag);
+    if (c->d_sbase) (void)hipFree(c->d_sbase);
+    if (c->d_sites) (void)hipFree(c->d_sites);
     if (c->d_big_table) (void)hipFree(c->d_big_table);
     if (c->d_big_com) (void)hipFree(c->d_big_com);
     if (c->d_partials) (void)hipFree(c->d_partials);
@@ -1647,9 +1650,11 @@ extern "C" tgnh_status tgnh_compute_kinetic_energies(tgnh_handle h, void* stream
 extern "C" tgnh_status tgnh_harness_force(tgnh_handle h, const void* x0, double k_drude, double k_tether,
                                           void* force_out, void* stream) {
     tgnh_status rc = entry(h, true); if (rc) return rc;
-    if (!x0 || !force_out) return fail(TGNH_ERR_ARG, "null x0 / force_out");
+    if (!force_out) return fail(TGNH_ERR_ARG, "null force_out");
+    if (!x0 && !h->d_sflag) return fail(TGNH_ERR_ARG, "null x0 and no packed sites (tgnh_harness_pack_sites)");
     ForceArgs a{};
     a.posq = h->posq; a.posq_corr = h->posq_corr; a.x0 = x0; a.meta = h->d_meta;
+    if (!x0) { a.sflag = h->d_sflag; a.sbase = h->d_sbase; a.sites = h->d_sites; }
     a.force = reinterpret_cast<long long*>(force_out);
     a.n = h->d.num_particles; a.padded = h->d.padded_num_particles;
     a.k_drude = k_drude; a.k_tether = k_tether;
@@ -1657,6 +1662,44 @@ extern "C" tgnh_status tgnh_harness_force(tgnh_handle h, const void* x0, double 
     if (h->alternate_sweeps) h->sweep_reverse ^= 1;
     Timed t(h, (hipStream_t)stream, KID_FORCE);
     HIP_OK(launch_force(h->d.precision, a, (hipStream_t)stream));
+    return TGNH_OK;
+}
+
+// The sites the force kernel needs, without what it does not: x0 spends 16-32 B on every slot for a site only the tethered
+// ones have (3 of 5 in SWM4 water), and the meta word 4 B for two bits and a small offset.  Host-side, once.
+extern "C" tgnh_status tgnh_harness_pack_sites(tgnh_handle h, const void* x0) {
+    tgnh_status rc = entry(h, false); if (rc) return rc;
+    if (h->host_only) return fail(TGNH_ERR_STATE, "host-only handle");
+    if (!x0) return fail(TGNH_ERR_ARG, "null x0");
+    const int N = h->d.num_particles;
+    const size_t rs = h->d.precision == TGNH_PREC_DOUBLE ? sizeof(double) : sizeof(float);
+    std::vector<unsigned char> raw((size_t)std::max(N, 1) * 4 * rs);
+    HIP_OK(hipMemcpy(raw.data(), x0, (size_t)N * 4 * rs, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> flag((size_t)std::max(N, 1), 0);
+    std::vector<uint32_t> base((size_t)(N + 63) / 64 + 1, 0);
+    std::vector<unsigned char> sites;
+    sites.reserve((size_t)N * 3 * rs);
+    uint32_t count = 0;
+    for (int i = 0; i < N; i++) {
+        if ((i & 63) == 0) base[i >> 6] = count;
+        const unsigned char* rec = raw.data() + (size_t)i * 4 * rs;
+        const bool tethered = rs == sizeof(double) ? reinterpret_cast<const double*>(rec)[3] != 0.0 : reinterpret_cast<const float*>(rec)[3] != 0.0f;
+        const uint32_t m = h->meta[i], role = m & 3u;
+        const int off = (int)((m >> 10) & 2047u) - 1024;
+        const uint32_t o5 = role == ROLE_NORMAL ? 16u : (off >= -15 && off <= 15 ? (uint32_t)(off + 16) : 0u);
+        flag[i] = (uint8_t)(role | (tethered && role != ROLE_DRUDE ? 4u : 0u) | (o5 << 3));
+        if (flag[i] & 4u) { sites.insert(sites.end(), rec, rec + 3 * rs); count++; }
+    }
+    if (h->d_sflag) (void)hipFree(h->d_sflag);
+    if (h->d_sbase) (void)hipFree(h->d_sbase);
+    if (h->d_sites) (void)hipFree(h->d_sites);
+    h->d_sflag = nullptr; h->d_sbase = nullptr; h->d_sites = nullptr;
+    HIP_OK(hipMalloc(&h->d_sflag, flag.size()));
+    HIP_OK(hipMalloc(&h->d_sbase, base.size() * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&h->d_sites, std::max(sites.size(), (size_t)16) + 16));    // (+16: a 12-byte record may be fetched as four dwords)
+    HIP_OK(hipMemcpy(h->d_sflag, flag.data(), flag.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(h->d_sbase, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!sites.empty()) HIP_OK(hipMemcpy(h->d_sites, sites.data(), sites.size(), hipMemcpyHostToDevice));
     return TGNH_OK;
 }
 

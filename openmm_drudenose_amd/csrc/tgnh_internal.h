@@ -236,6 +236,12 @@ struct ForceArgs {
     int n, padded;
     int reverse;
     double k_drude, k_tether;
+    // packed sites (tgnh_harness_pack_sites): one byte per slot -- role | tethered << 2 | (partner offset + 16) << 3, 0 in the
+    // upper five bits = "read the meta word" --, the number of tethered slots before each 64-slot chunk, and the sites of the
+    // tethered slots only, three reals each.  65 B per slot of a mixed-precision water box instead of 77.
+    const uint8_t* sflag;
+    const uint32_t* sbase;
+    const void* sites;
 };
 
 // A launcher reports THIS launch's error: whatever an earlier call left behind (e.g. a stream capture the caller
@@ -345,6 +351,9 @@ struct tgnh_context {
     void* rccl_comm = nullptr;        // ncclComm_t: the library enqueues ncclAllReduce itself (tgnh_rccl_init / tgnh_set_rccl_comm)
     bool rccl_owned = false;
     unsigned long long* d_x_stat = nullptr;   // mailbox wait statistics (XchgArgs::stat)
+    uint8_t* d_sflag = nullptr;               // harness: packed tether sites (ForceArgs::sflag / sbase / sites), tgnh_harness_pack_sites
+    uint32_t* d_sbase = nullptr;
+    void* d_sites = nullptr;
     // mailbox exchange (tgnh_exchange_*): replaces the hook when attached
     tgnh::XchgArgs x{};
     bool xchg_on = false, xwait_pending = false;

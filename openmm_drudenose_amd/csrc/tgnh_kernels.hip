@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, G = a.num_groups, NT = G + 2;
     const int grid = (int)gridDim.x;
-    const bool chain_wave = tid < 64, leader = blockIdx.x == 0;
+    const bool chain_wave = tid < 64;
     const int itg = tid & 63;
     if (a.census) {
         // One-time check at tgnh_create that a grid of this size really is resident all at once (the occupancy API can be
@@ -1237,7 +1237,6 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
     // same wavefront issues -- the order is program order plus a data dependency, not a matter of latencies.
     unsigned gen0 = 0;
     unsigned long long seq0 = 0;
-    const ChainLayout& L = a.chain.L;
     Chain1Regs creg{};
     if (chain_wave) {
         gen0 = __hip_atomic_load(&a.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2097,10 +2096,82 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// The same forces from the packed sites (ForceArgs::sflag): every load of a slot is issued before the first is used, the
+// site comes from the compact array (its index: the chunk's base + the tethered lanes before this one), the meta word is
+// read only by a slot whose partner is more than 15 slots away.
+template <int PREC>
+__global__ __launch_bounds__(BLOCK) void force_packed_kernel(const ForceArgs a) {
+    typedef typename Prec<PREC>::real real;
+    typedef typename Prec<PREC>::real4 real4;
+    typedef typename Prec<PREC>::mixed mixed;
+    const real4* __restrict__ posq = reinterpret_cast<const real4*>(a.posq);
+    const float4* __restrict__ pcorr = reinterpret_cast<const float4*>(a.posq_corr);
+    const real* __restrict__ sites = reinterpret_cast<const real*>(a.sites);
+    const mixed kd = (mixed)a.k_drude, kt = (mixed)a.k_tether;
+    const int lane = threadIdx.x & 63;
+    const int nround = (a.n + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
+    for (int rr = 0; rr < nround; rr++) {
+        const int r = a.reverse ? nround - 1 - rr : rr;
+        const int blk = a.reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+        const int i = (r * gridDim.x + blk) * BLOCK + threadIdx.x;           // (a wavefront covers one aligned 64-slot chunk)
+        const bool in = i < a.n;
+        uint32_t b = 0;
+        real4 p = {}; float4 c = {};
+        if (in) {
+            b = a.sflag[i];
+            p = posq[i];
+            if (PREC == TGNH_PREC_MIXED) c = pcorr[i];
+        }
+        const bool tethered = (b & 4u) != 0;
+        const unsigned long long before = __ballot(tethered) & ((1ull << lane) - 1ull);
+        real s0 = 0, s1 = 0, s2 = 0;
+        if (tethered) {
+            const real* rec = sites + 3 * (size_t)(a.sbase[i >> 6] + (uint32_t)__popcll(before));
+            s0 = rec[0]; s1 = rec[1]; s2 = rec[2];
+        }
+        mixed x = p.x, y = p.y, z = p.z;
+        if (PREC == TGNH_PREC_MIXED) { x += (mixed)c.x; y += (mixed)c.y; z += (mixed)c.z; }
+        const uint32_t role = b & 3u;
+        int off = (int)(b >> 3) - 16;
+        if (in && (b >> 3) == 0) off = (int)((a.meta[i] >> 10) & 2047u) - 1024;
+        const int pl = lane + off;
+        const int src = (pl >= 0 && pl < 64) ? pl : lane;
+        mixed ox = __shfl(x, src, 64), oy = __shfl(y, src, 64), oz = __shfl(z, src, 64);
+        mixed fx = 0, fy = 0, fz = 0;
+        if (in) {
+            if (tethered) { fx = -kt * (x - (mixed)s0); fy = -kt * (y - (mixed)s1); fz = -kt * (z - (mixed)s2); }
+            if (role != ROLE_NORMAL) {
+                if (src != pl) {
+                    const int j = i + off;
+                    const real4 q = posq[j];
+                    ox = q.x; oy = q.y; oz = q.z;
+                    if (PREC == TGNH_PREC_MIXED) { const float4 cq = pcorr[j]; ox += (mixed)cq.x; oy += (mixed)cq.y; oz += (mixed)cq.z; }
+                }
+                const bool is_d = role == ROLE_DRUDE;
+                const mixed sgn = is_d ? (mixed)-1 : (mixed)1;
+                const mixed sx = is_d ? x - ox : ox - x, sy = is_d ? y - oy : oy - y, sz = is_d ? z - oz : oz - z;
+                fx += sgn * kd * sx; fy += sgn * kd * sy; fz += sgn * kd * sz;
+            }
+            a.force[i] = (long long)(fx * (mixed)4294967296.0);
+            a.force[i + a.padded] = (long long)(fy * (mixed)4294967296.0);
+            a.force[i + 2 * a.padded] = (long long)(fz * (mixed)4294967296.0);
+        }
+    }
+}
+
 hipError_t launch_force(int precision, const ForceArgs& a, hipStream_t s) {
     int grid = (a.n + BLOCK - 1) / BLOCK;
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
+    if (a.sflag) {
+        switch (precision) {
+            case TGNH_PREC_SINGLE: TGNH_LAUNCH((force_packed_kernel<TGNH_PREC_SINGLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+            case TGNH_PREC_MIXED: TGNH_LAUNCH((force_packed_kernel<TGNH_PREC_MIXED>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+            case TGNH_PREC_DOUBLE: TGNH_LAUNCH((force_packed_kernel<TGNH_PREC_DOUBLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (precision) {
         case TGNH_PREC_SINGLE: TGNH_LAUNCH((force_kernel<TGNH_PREC_SINGLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
         case TGNH_PREC_MIXED: TGNH_LAUNCH((force_kernel<TGNH_PREC_MIXED>), dim3(grid), dim3(BLOCK), 0, s, a); break;

@@ -294,6 +294,8 @@ class HipContext(_HandleQueries):
         self.force = torch.zeros(3 * self.padded, dtype=torch.int64, device=self.dev)
         self.pos_delta = torch.zeros((n, 4), dtype=mdt, device=self.dev)
         self.x0 = torch.zeros((n, 4), dtype=rdt, device=self.dev)        # harness tether sites, w = tether flag
+        self.sites_packed = False
+        self.unpacked_sites = False                                      # (tests: the harness force from x0 itself, the round-1 kernel)
         inv = np.where(system.mass == 0.0, 0.0, 1.0 / np.where(system.mass == 0.0, 1.0, system.mass))
         self.velm[:, 3] = torch.from_numpy(inv).to(self.dev, mdt)
         _check(self.lib.tgnh_bind_buffers(self.h, self.posq.data_ptr(),
@@ -499,6 +501,13 @@ class HipContext(_HandleQueries):
         flag = (self.system.mass > 0)
         flag[self.system.pair_drude] = False
         self.x0[:, 3] = self.torch.from_numpy(flag.astype(np.float64)).to(self.dev, self.rdt)
+        self.torch.cuda.synchronize(self.dev)
+        _check(self.lib.tgnh_harness_pack_sites(self.h, self.x0.data_ptr()))
+        self.sites_packed = True
+
+    def _x0_arg(self):
+        """None (NULL: the library reads its packed copy) once set_sites has packed them, else the float4 / double4 array"""
+        return None if self.sites_packed and not self.unpacked_sites else self.x0.data_ptr()
 
     def sites(self):
         """The tether sites exactly as the harness kernel sees them (for the oracle)."""
@@ -536,7 +545,7 @@ class HipContext(_HandleQueries):
         if self.force_fn is not None:
             self.force_fn(self)
         else:
-            _check(self.lib.tgnh_harness_force(self.h, self.x0.data_ptr(), self.k_drude, self.k_tether,
+            _check(self.lib.tgnh_harness_force(self.h, self._x0_arg(), self.k_drude, self.k_tether,
                                                self.force.data_ptr(), self._stream()))
 
     def step_begin(self):
@@ -548,13 +557,13 @@ class HipContext(_HandleQueries):
 
     def step(self, steps):
         if self.force_fn is None and self.constrained:
-            _check(self.lib.tgnh_run_harness_constrained(self.h, self.x0.data_ptr(), self.k_drude, self.k_tether,
+            _check(self.lib.tgnh_run_harness_constrained(self.h, self._x0_arg(), self.k_drude, self.k_tether,
                                                          self.integrator.getConstraintTolerance(), int(steps), self._stream()))
             if steps > 0:
                 self.ke_sum_valid = True
             return
         if self.force_fn is None:
-            _check(self.lib.tgnh_run_harness(self.h, self.x0.data_ptr(), self.k_drude, self.k_tether, int(steps), self._stream()))
+            _check(self.lib.tgnh_run_harness(self.h, self._x0_arg(), self.k_drude, self.k_tether, int(steps), self._stream()))
             if steps > 0:
                 self.ke_sum_valid = True
             return
@@ -603,7 +612,7 @@ class HipContext(_HandleQueries):
         def record():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                _check(self.lib.tgnh_run_harness(self.h, self.x0.data_ptr(), self.k_drude, self.k_tether, int(steps), self._stream()))
+                _check(self.lib.tgnh_run_harness(self.h, self._x0_arg(), self.k_drude, self.k_tether, int(steps), self._stream()))
             return g
         for _ in range(4):
             owed_before = self.pending_state() & 0xff

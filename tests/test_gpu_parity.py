@@ -1110,6 +1110,27 @@ def test_1000_step_mixed_precision_gate(flags):
     ctx.close()
 
 
+@pytest.mark.parametrize("precision", ["single", "mixed", "double"])
+@pytest.mark.parametrize("sysname", ["water27", "water1000", "mixed", "il40", "polymer", "ragged6", "pair+normal+massless"])
+def test_packed_sites_give_the_same_forces(sysname, precision):
+    """The harness force reads the sites in packed form (tgnh_harness_pack_sites: one byte per slot, the tethered slots' sites
+    only) -- bit for bit the forces of the kernel that reads x0 and the meta word, partners near and far."""
+    s, g, ng, it, ctx = make(sysname, "TGNH", precision)
+    rng = np.random.default_rng(5)
+    ctx.setPositions(s.positions + rng.normal(0, 0.01, s.positions.shape))
+    assert ctx.sites_packed
+    ctx.compute_forces()
+    packed = ctx.force.clone()
+    ctx.force.zero_()
+    ctx.unpacked_sites = True
+    ctx.compute_forces()
+    assert ctx.torch.equal(packed, ctx.force) and int(packed.abs().max()) > 0
+    meta = ctx.topology(8).view(np.uint32)
+    off = ((meta >> 10) & 2047).astype(np.int64) - 1024
+    print(sysname, precision, "partners more than 15 slots away:", int(np.sum((np.abs(off) > 15) & ((meta & 3) != 0))))
+    ctx.close()
+
+
 @pytest.mark.parametrize("flags", [0, FLAG_RESIDENT_STEP])
 @pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
 def test_kinetic_energy_query(mode, flags):
