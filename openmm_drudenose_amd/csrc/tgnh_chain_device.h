@@ -9,6 +9,9 @@
 #define TGNH_CHAIN_DEVICE_H_
 
 namespace tgnh {
+#ifdef TGNH_TRACE
+__device__ double g_chain_dbg[4];   // largest exponent argument seen by the real / Drude fast paths, times each left the polynomial's range
+#endif
 
 // Contraction is left on: every a*b+c below may become one fma (<= 1 ulp per operation away from the separately
 // rounded reference arithmetic; the chain is smooth, the parity gate is 1e-6 and is met at 1e-12).
@@ -22,6 +25,30 @@ namespace tgnh {
 // lanes are live, so what counts is the *number of instructions*: Horner (an Estrin form, 14 operations at depth 5,
 // measured 40 % slower), and the degree is chosen for the whole wavefront so that thermostats on different sides of
 // the switch do not execute both polynomials.
+// exp(x) for |x| < 1 in 17 instructions and no branch: the degree-14 Taylor polynomial of x/4 (truncation (1/4)^15/15! < 2^-70),
+// squared twice (<= 5 ulp).  A thermostat far from equilibrium -- Drude particles much hotter than their 1 K, as in the
+// synthetic boxes of bench.py, where -dtc/2*etaDot reaches 0.3 -- leaves the short polynomials' range at every sub-step.
+__device__ __forceinline__ double chain_exp_wide(const double x) {
+    const double y = 0.25 * x;
+    double p = 1.0 / 87178291200.0;
+    p = fma(p, y, 1.0 / 6227020800.0);
+    p = fma(p, y, 1.0 / 479001600.0);
+    p = fma(p, y, 1.0 / 39916800.0);
+    p = fma(p, y, 1.0 / 3628800.0);
+    p = fma(p, y, 1.0 / 362880.0);
+    p = fma(p, y, 1.0 / 40320.0);
+    p = fma(p, y, 1.0 / 5040.0);
+    p = fma(p, y, 1.0 / 720.0);
+    p = fma(p, y, 1.0 / 120.0);
+    p = fma(p, y, 1.0 / 24.0);
+    p = fma(p, y, 1.0 / 6.0);
+    p = fma(p, y, 0.5);
+    p = fma(p, y, 1.0);
+    p = fma(p, y, 1.0);
+    p *= p;
+    return p * p;
+}
+
 template <bool LIBM = true>
 __device__ __forceinline__ double chain_exp(double x) {
     const double ax = fabs(x);
@@ -34,7 +61,7 @@ __device__ __forceinline__ double chain_exp(double x) {
         p = fma(p, x, 1.0);
         return fma(p, x, 1.0);
     }
-    if (ax < 0.03125) {
+    if (LIBM ? ax < 0.03125 : !__any(ax >= 0.03125)) {
         double p = 1.0 / 39916800.0;
         p = fma(p, x, 1.0 / 3628800.0);
         p = fma(p, x, 1.0 / 362880.0);
@@ -49,25 +76,13 @@ __device__ __forceinline__ double chain_exp(double x) {
         return fma(p, x, 1.0);
     }
     if (LIBM) return exp(x);
-    // no libm call (the tile kernel's in-kernel chain: ocml's exp would cost it ~30 VGPRs): halve the argument
-    // into the polynomial's range, then square back; k <= 11 squarings for |x| < 64, error <= 2^k ulp
-    int k = 0;
-    double y = x;
-    while (fabs(y) >= 0.03125 && k < 40) { y *= 0.5; k++; }
-    double p = 1.0 / 39916800.0;
-    p = fma(p, y, 1.0 / 3628800.0);
-    p = fma(p, y, 1.0 / 362880.0);
-    p = fma(p, y, 1.0 / 40320.0);
-    p = fma(p, y, 1.0 / 5040.0);
-    p = fma(p, y, 1.0 / 720.0);
-    p = fma(p, y, 1.0 / 120.0);
-    p = fma(p, y, 1.0 / 24.0);
-    p = fma(p, y, 1.0 / 6.0);
-    p = fma(p, y, 0.5);
-    p = fma(p, y, 1.0);
-    p = fma(p, y, 1.0);
-    for (int i = 0; i < k; i++) p *= p;
-    return p;
+    if (!__any(ax >= 1.0)) return chain_exp_wide(x);
+    // no libm call (the streaming kernels' in-kernel chains: ocml's exp would cost them ~30 VGPRs): x = n ln 2 + r with
+    // |r| <= 0.35, exp(r) from chain_exp_wide, the power of two by ldexp; <= 6 ulp for every argument exp() itself can take
+    const double n = rint(x * 1.4426950408889634);
+    double r = fma(n, -0.693147180369123816490, x);                  // ln 2 in two pieces (the first with 21 trailing zero bits: n * hi is exact)
+    r = fma(n, -1.90821492927058770002e-10, r);
+    return ldexp(chain_exp_wide(r), (int)fmax(-2000.0, fmin(2000.0, n)));
 }
 
 // a * b + c as exactly one v_fma_f64 on three vector registers
@@ -114,6 +129,88 @@ struct ChainConst {
     int S;
 };
 
+// The S sub-steps of a register-resident chain of CC >= 2 links with the exponentials that repeat taken once (see
+// chain_real_core) and no range test inside the loop: WIDE = false evaluates them with the depth-3 polynomial (|x| < 2^-6),
+// WIDE = true with chain_exp_wide (|x| < 1).  Returns the largest |x| met; the caller repeats the call with the next wider
+// form if that left the range.  `live`: the etaMass > 0 guard of link 0 (Cu :561, :579; the Drude thermostat has none).
+template <int CC, bool WIDE>
+__device__ __forceinline__ double chain_fast_loop(double* eta, double* etaDot, double* etaDotDot, const double* etaMass,
+                                                  const double* invM, const ChainConst k, const double nkbt, const double kbT,
+                                                  const bool live, const double invQ0, const double ef_top, double& ke, double& scale) {
+    double ef[CC], xmax = 0.0;
+    ef[CC - 1] = ef_top;                                             // the dummy link never moves: constant of the call
+    for (int iter = 0; iter < k.S; iter++) {
+#pragma unroll
+        for (int i = CC - 1; i >= 0; i--) {                          // Cu :566-571 / :607-618
+            if (i < CC - 1) { const double x = -k.dtc8 * etaDot[i + 1]; xmax = fmax(xmax, fabs(x)); ef[i] = WIDE ? chain_exp_wide(x) : chain_exp7(x); }
+            etaDot[i] *= ef[i];
+            etaDot[i] += etaDotDot[i] * k.dtc4;
+            etaDot[i] *= ef[i];
+        }
+        { const double x = -k.dtc2 * etaDot[0]; xmax = fmax(xmax, fabs(x)); const double e = WIDE ? chain_exp_wide(x) : chain_exp7(x); scale *= e; ke *= e * e; }   // Cu :573-574 / :620-621
+#pragma unroll
+        for (int i = 0; i < CC; i++) eta[i] += k.dtc2 * etaDot[i];   // Cu :575-577 / :623
+        if (live) etaDotDot[0] = (ke - nkbt) * invQ0;                // Cu :579-581 / :629
+        etaDot[0] *= ef[0];                                          // Cu :583-585 / :630-632
+        etaDot[0] += etaDotDot[0] * k.dtc4;
+        etaDot[0] *= ef[0];
+#pragma unroll
+        for (int i = 1; i < CC; i++) {                               // Cu :586-592 / :633-641, expfac as in the descending loop
+            etaDot[i] *= ef[i];
+            etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - kbT) * invM[i];
+            etaDot[i] += etaDotDot[i] * k.dtc4;
+            etaDot[i] *= ef[i];
+        }
+    }
+    return xmax;
+}
+
+// Fast forms first (chain_fast_loop), the transcription last: true when one of the fast forms held its range and the chain
+// is done.  The form is chosen for the whole wavefront from the exponents at entry, with a factor two of room.
+template <int CC, bool LIBM>
+__device__ __forceinline__ bool chain_fast(double* eta, double* etaDot, double* etaDotDot, const double* etaMass, const double* invM,
+                                           const ChainConst k, const double nkbt, const double kbT, const bool live,
+                                           const double invQ0, double& ke, double& scale, const int which) {
+    double s_eta[CC], s_ed[CC + 1], s_edd[CC];
+#pragma unroll
+    for (int i = 0; i < CC; i++) { s_eta[i] = eta[i]; s_ed[i] = etaDot[i]; s_edd[i] = etaDotDot[i]; }
+    s_ed[CC] = etaDot[CC];
+    const double ke_in = ke;
+    const double ef_top = chain_exp<LIBM>(-k.dtc8 * etaDot[CC]);
+    double x0 = fabs(k.dtc2 * etaDot[0]);
+#pragma unroll
+    for (int i = 1; i < CC; i++) x0 = fmax(x0, fabs(k.dtc8 * etaDot[i]));
+    bool wide = __any(x0 >= 0.0078125);
+    double xmax = 0.0;
+    if (!wide) {
+        xmax = chain_fast_loop<CC, false>(eta, etaDot, etaDotDot, etaMass, invM, k, nkbt, kbT, live, invQ0, ef_top, ke, scale);
+#ifdef TGNH_TRACE
+        if (blockIdx.x == 0) { g_chain_dbg[which] = fmax(g_chain_dbg[which], xmax); if (xmax >= 0.015625) g_chain_dbg[2 + which] += 1.0; }
+#endif
+        if (__builtin_expect(!__any(xmax >= 0.015625), 1)) return true;
+        wide = true;
+    } else {
+        xmax = 1.0;                                                  // (nothing run yet: fall into the wide form)
+    }
+    // restore and run the wide form
+#pragma unroll
+    for (int i = 0; i < CC; i++) { eta[i] = s_eta[i]; etaDot[i] = s_ed[i]; etaDotDot[i] = s_edd[i]; }
+    etaDot[CC] = s_ed[CC];
+    ke = ke_in; scale = 1.0;
+    if (live) etaDotDot[0] = (ke - nkbt) * invQ0;
+    xmax = chain_fast_loop<CC, true>(eta, etaDot, etaDotDot, etaMass, invM, k, nkbt, kbT, live, invQ0, ef_top, ke, scale);
+#ifdef TGNH_TRACE
+    if (blockIdx.x == 0) { g_chain_dbg[which] = fmax(g_chain_dbg[which], xmax); if (xmax >= 1.0) g_chain_dbg[2 + which] += 1000.0; }
+#endif
+    if (__builtin_expect(!__any(xmax >= 1.0), 1)) return true;
+#pragma unroll
+    for (int i = 0; i < CC; i++) { eta[i] = s_eta[i]; etaDot[i] = s_ed[i]; etaDotDot[i] = s_edd[i]; }
+    etaDot[CC] = s_ed[CC];
+    ke = ke_in; scale = 1.0;
+    if (live) etaDotDot[0] = (ke - nkbt) * invQ0;
+    return false;
+}
+
 // One real (temperature-group or COM) thermostat.  Cu :560-595.  CC > 0: compile-time chain length.
 template <int CC, bool LIBM = true>
 __device__ __forceinline__ void chain_real_core(double* eta, double* etaDot, double* etaDotDot, const double* etaMass,
@@ -150,50 +247,15 @@ __device__ __forceinline__ void chain_real_core(double* eta, double* etaDot, dou
         // Register-resident chains: the same arithmetic with the exponentials that repeat taken once.  Per sub-step
         // the reference evaluates expfac = exp(-dtc8*etaDot[i+1]) in the descending loop (Cu :566-571) and AGAIN in
         // the ascending loop (Cu :586-592), where etaDot[i+1] still holds the descending loop's value: same argument,
-        // same result, computed once here (C instead of 2C exponentials per sub-step, none for the top link, whose
-        // neighbour is the constant dummy).  exp() is the depth-3 polynomial without a range test; the largest
-        // argument seen is checked once after the loop and the call repeated with the careful code below if the
-        // polynomial's range was ever left (never in practice).
-        double s_eta[CC], s_ed[CC + 1], s_edd[CC];
-#pragma unroll
-        for (int i = 0; i < CC; i++) { s_eta[i] = eta[i]; s_ed[i] = etaDot[i]; s_edd[i] = etaDotDot[i]; }
-        s_ed[CC] = etaDot[CC];
-        const double ke_in = ke;
-        double ef[CC], xmax = 0.0;
-        ef[CC - 1] = chain_exp<LIBM>(-k.dtc8 * etaDot[CC]);          // the dummy link never moves: constant of the call
-        for (int iter = 0; iter < k.S; iter++) {
-#pragma unroll
-            for (int i = CC - 1; i >= 0; i--) {                      // Cu :566-571
-                if (i < CC - 1) { const double x = -k.dtc8 * etaDot[i + 1]; xmax = fmax(xmax, fabs(x)); ef[i] = chain_exp7(x); }
-                etaDot[i] *= ef[i];
-                etaDot[i] += etaDotDot[i] * k.dtc4;
-                etaDot[i] *= ef[i];
-            }
-            { const double x = -k.dtc2 * etaDot[0]; xmax = fmax(xmax, fabs(x)); const double e = chain_exp7(x); scale *= e; ke *= e * e; }   // Cu :573-574
-#pragma unroll
-            for (int i = 0; i < CC; i++) eta[i] += k.dtc2 * etaDot[i];    // Cu :575-577
-            if (live) etaDotDot[0] = (ke - nkbt) * invQ0;            // Cu :579-581
-            etaDot[0] *= ef[0];                                      // Cu :583-585
-            etaDot[0] += etaDotDot[0] * k.dtc4;
-            etaDot[0] *= ef[0];
-#pragma unroll
-            for (int i = 1; i < CC; i++) {                           // Cu :586-592, expfac as in the descending loop
-                etaDot[i] *= ef[i];
-                etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - kbT) * invM[i];
-                etaDot[i] += etaDotDot[i] * k.dtc4;
-                etaDot[i] *= ef[i];
-            }
-        }
-        if (__builtin_expect(!__any(xmax >= 0.015625), 1)) {
+        // same result, computed once (C instead of 2C exponentials per sub-step, none for the top link, whose
+        // neighbour is the constant dummy).  exp() is a polynomial without a range test (chain_fast_loop); the largest
+        // argument seen is checked once after the loop and the call repeated with the next wider form, last of all with
+        // the careful code below (|x| >= 1: never in practice).
+        if (chain_fast<CC, LIBM>(eta, etaDot, etaDotDot, etaMass, invM, k, nkbt, kbT, live, invQ0, ke, scale, 0)) {
             *scale_out = scale;
             *ke_out = ke;
             return;
         }
-#pragma unroll
-        for (int i = 0; i < CC; i++) { eta[i] = s_eta[i]; etaDot[i] = s_ed[i]; etaDotDot[i] = s_edd[i]; }
-        etaDot[CC] = s_ed[CC];
-        ke = ke_in; scale = 1.0;
-        if (live) etaDotDot[0] = (ke - nkbt) * invQ0;
     }
     for (int iter = 0; iter < k.S; iter++) {
 #pragma unroll
@@ -254,48 +316,14 @@ __device__ __forceinline__ void chain_drude_core(double* eta, double* etaDot, do
         return;
     }
     if constexpr (CC >= 2) {                                         // as in chain_real_core: repeated exponentials once
-        double s_eta[CC], s_ed[CC + 1], s_edd[CC];
-#pragma unroll
-        for (int i = 0; i < CC; i++) { s_eta[i] = eta[i]; s_ed[i] = etaDot[i]; s_edd[i] = etaDotDot[i]; }
-        s_ed[CC] = etaDot[CC];
-        const double ke_in = ke;
-        double invM[CC], ef[CC], xmax = 0.0;
+        double invM[CC];
 #pragma unroll
         for (int i = 0; i < CC; i++) invM[i] = 1.0 / etaMass[i];
-        ef[CC - 1] = chain_exp<LIBM>(-k.dtc8 * etaDot[CC]);
-        for (int iter = 0; iter < k.S; iter++) {                     // Cu :606-642
-#pragma unroll
-            for (int i = CC - 1; i >= 0; i--) {                      // Cu :607-618
-                if (i < CC - 1) { const double x = -k.dtc8 * etaDot[i + 1]; xmax = fmax(xmax, fabs(x)); ef[i] = chain_exp7(x); }
-                etaDot[i] *= ef[i];
-                etaDot[i] += etaDotDot[i] * k.dtc4;
-                etaDot[i] *= ef[i];
-            }
-            { const double x = -k.dtc2 * etaDot[0]; xmax = fmax(xmax, fabs(x)); const double e = chain_exp7(x); scale *= e; ke *= e * e; }   // Cu :620-621
-#pragma unroll
-            for (int i = 0; i < CC; i++) eta[i] += k.dtc2 * etaDot[i];
-            etaDotDot[0] = (ke - nkbt) * invQ0;
-            etaDot[0] *= ef[0];
-            etaDot[0] += etaDotDot[0] * k.dtc4;
-            etaDot[0] *= ef[0];
-#pragma unroll
-            for (int i = 1; i < CC; i++) {                           // Cu :633-641
-                etaDot[i] *= ef[i];
-                etaDotDot[i] = (etaMass[i - 1] * etaDot[i - 1] * etaDot[i - 1] - kbT) * invM[i];
-                etaDot[i] += etaDotDot[i] * k.dtc4;
-                etaDot[i] *= ef[i];
-            }
-        }
-        if (__builtin_expect(!__any(xmax >= 0.015625), 1)) {
+        if (chain_fast<CC, LIBM>(eta, etaDot, etaDotDot, etaMass, invM, k, nkbt, kbT, true, invQ0, ke, scale, 1)) {
             *scale_out = scale;
             *ke_out = ke;
             return;
         }
-#pragma unroll
-        for (int i = 0; i < CC; i++) { eta[i] = s_eta[i]; etaDot[i] = s_ed[i]; etaDotDot[i] = s_edd[i]; }
-        etaDot[CC] = s_ed[CC];
-        ke = ke_in; scale = 1.0;
-        etaDotDot[0] = (ke - nkbt) * invQ0;
     }
     for (int iter = 0; iter < k.S; iter++) {                         // Cu :606-642
 #pragma unroll
@@ -624,30 +652,48 @@ __device__ __forceinline__ void chain1_finish(const ChainArgs& a, const Chain1Re
             double y = y_0, sy = 0.0;
             TRACE(rep ? 16 : 14);
             unsigned ymax = 0u;                                      // largest |y| seen, as the high word of the double (monotone in |y|)
-            const double k720 = 1.0 / 720.0, k120 = 1.0 / 120.0, k24 = 1.0 / 24.0, k6 = 1.0 / 6.0;
-            for (int iter = 0; iter < a.S; iter++) {
-                ymax = max(ymax, (unsigned)__double2hiint(y) & 0x7fffffffu);     // two 32-bit operations (fmax on doubles: three fp64 ones)
-                double p = fma3(k720, y, k120);                      // (fma3: exactly one v_fma_f64 each -- left to itself the
-                p = fma3(p, y, k24);                                 //  compiler copies every constant into the accumulator of a
-                p = fma3(p, y, k6);                                  //  two-address fmac first: four more fp64-rate moves per sub-step)
-                p = fma(p, y, 0.5);
-                p = fma(p, y, 1.0);
-                p = fma(p, y, 1.0);
-                ke *= p;                                             // Cu :574, :621
-                sy += y;
-                edd = fma3(ke, invQ0, c0);                           // Cu :579-581, :629
-                y = fma3(edd, ky, y);                                // Cu :583-585 / :630-632 and the next :568-570
-            }
-            TRACE(rep ? 11 : 16);
-            if (__builtin_expect(__any(ymax >= 0x3f900000u), 0)) {   // some |y| >= 2^-6, out of the short polynomial's range: again, carefully
-                ke = ke_0; y = y_0; sy = 0.0;
+            // Which polynomial: the short one while every |y| stays below 2^-6 -- a thermostat near equilibrium --, chain_exp_wide
+            // (|y| < 1) otherwise.  Chosen for the whole wavefront from the exponents at entry (with a factor two of room) and
+            // checked after the loop: leaving the chosen range costs a second pass, it is never wrong.
+            bool wide = __any(((unsigned)__double2hiint(y_0) & 0x7fffffffu) >= 0x3f800000u);          // some |y_0| >= 2^-7
+            if (!wide) {
+                const double k720 = 1.0 / 720.0, k120 = 1.0 / 120.0, k24 = 1.0 / 24.0, k6 = 1.0 / 6.0;
                 for (int iter = 0; iter < a.S; iter++) {
-                    ke *= fabs(y) < 0.25 ? chain_exp12(y) : chain_exp<false>(y);
+                    ymax = max(ymax, (unsigned)__double2hiint(y) & 0x7fffffffu);     // two 32-bit operations (fmax on doubles: three fp64 ones)
+                    double p = fma3(k720, y, k120);                      // (fma3: exactly one v_fma_f64 each -- left to itself the
+                    p = fma3(p, y, k24);                                 //  compiler copies every constant into the accumulator of a
+                    p = fma3(p, y, k6);                                  //  two-address fmac first: four more fp64-rate moves per sub-step)
+                    p = fma(p, y, 0.5);
+                    p = fma(p, y, 1.0);
+                    p = fma(p, y, 1.0);
+                    ke *= p;                                             // Cu :574, :621
+                    sy += y;
+                    edd = fma3(ke, invQ0, c0);                           // Cu :579-581, :629
+                    y = fma3(edd, ky, y);                                // Cu :583-585 / :630-632 and the next :568-570
+                }
+                if (__builtin_expect(__any(ymax >= 0x3f900000u), 0)) {   // some |y| >= 2^-6: again, with the long polynomial
+                    ke = ke_0; y = y_0; sy = 0.0; ymax = 0u; wide = true;
+                }
+            }
+            if (wide) {
+                for (int iter = 0; iter < a.S; iter++) {
+                    ymax = max(ymax, (unsigned)__double2hiint(y) & 0x7fffffffu);
+                    ke *= chain_exp_wide(y);
                     sy += y;
                     edd = fma(ke, invQ0, c0);
                     y = fma(edd, ky, y);
                 }
+                if (__builtin_expect(__any(ymax >= 0x3ff00000u), 0)) {   // some |y| >= 1: again, with the range reduction
+                    ke = ke_0; y = y_0; sy = 0.0;
+                    for (int iter = 0; iter < a.S; iter++) {
+                        ke *= chain_exp<false>(y);
+                        sy += y;
+                        edd = fma(ke, invQ0, c0);
+                        y = fma(edd, ky, y);
+                    }
+                }
             }
+            TRACE(rep ? 11 : 16);
             const double ed1 = fma(y - y_0, -a.inv_dtc, ed1_0);      // etaDot1 advanced by the same kicks as y
             ed = fma(edd, -dtc4, ed1);                               // ed1 is one quarter-kick ahead
             scale = chain_exp<false>(0.5 * sy);                      // prod exp(-dtc/2 ed1)      (Cu :573, :620)

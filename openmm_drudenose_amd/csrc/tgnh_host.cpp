@@ -567,9 +567,15 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         // dualNH qualifies too: with useDrudeNHChains its real and Drude chains are independent (Chain1Map), without
         // them coupled through one shuffle per sub-step (chain1q_run)
         // Chains of 2-4 links too, but in instantiations of their own that hold two work-groups per compute unit where the
-        // one-link kernels hold three (the links' registers): taken below 2 M slots, where a step is bound by its launches and
-        // the chain launch it saves; beyond, the streaming launches are bandwidth-bound and keep their occupancy
-        c->inline_chain = want && (c->L.C == 1 || (c->L.C <= 4 && d->num_particles < 2000000));
+        // one-link kernels hold three (the links' registers): taken below 1 M slots, where an eager step is bound by its launches
+        // and the chain launch it saves (under a hipGraph the two forms are within 5 % of each other from 32 k to 625 k slots);
+        // beyond, the streaming launches are bandwidth-bound and keep their occupancy -- chain_kernel's 18 us cost less
+        // (profiles/r03_chain_cost.md)
+        int inline_multi_max = 1000000;
+#ifdef TGNH_TUNING
+        if (const char* e6 = getenv("TGNH_INLINE_MULTI_MAX")) inline_multi_max = atoi(e6);
+#endif
+        c->inline_chain = want && (c->L.C == 1 || (c->L.C <= 4 && d->num_particles < inline_multi_max));
         if (c->L.total > 256 && c->L.C > 1) c->inline_chain = c->inline_chain && false;     // (wstep_kernel parks the block in 256 doubles)
     }
     auto alloc = [&]() -> tgnh_status {
@@ -1139,9 +1145,12 @@ static ChainArgs chain_args(tgnh_handle h) {
     a.dt = h->d.step_size; a.S = h->d.drude_steps_per_real_step;
     a.dtc = a.dt / a.S; a.inv_dtc = 1.0 / a.dtc;                               // Cu :440-443
     a.realkbT = h->realkbT; a.drudekbT = h->drudekbT;
-    // a link per lane below 2 M slots (ten links at 32 k slots: 67 us per step against 180 with LDS-resident links); at the metric
-    // size, where a lone wavefront gets a third of its instruction rate, the LDS form measured 8 % faster (2 203 against 2 026 steps/s)
-    a.lanes = h->d.num_particles < 2000000 ? 1 : 0;
+    // chains of 5-16 links: a link per lane (chain_lanes_run) -- ten links at 32 k slots 63 us per step against 172 with LDS-resident
+    // links, at the metric size 99 against 183 (profiles/r03_chain_cost.md)
+    a.lanes = 1;
+#ifdef TGNH_TUNING
+    if (const char* e = getenv("TGNH_CHAIN_LANES")) a.lanes = e[0] != '0';
+#endif
     a.stage = h->d_stage;
     if (h->xchg_on) a.x = h->x;
     a.commit = h->stage_pending ? 1 : 0;     // every chain_kernel launch takes over a staged block first

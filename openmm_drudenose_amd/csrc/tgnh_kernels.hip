@@ -33,9 +33,16 @@ extern "C" int tgnh_debug_clear_trace() {
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_trace)) != hipSuccess) return 1;
     return (int)hipMemset(p, 0, sizeof(unsigned long long) * GRID_CAP * 16);
 }
+// chain_kernel's own clocks (tools/micro/chain_inside.py): wall_clock64 and clock64 at entry, after the prologue and at exit
+__device__ unsigned long long g_chain_trace[8];
+#define CHAIN_TRACE(slot) do { if (threadIdx.x == 0) { g_chain_trace[2 * (slot)] = wall_clock64(); g_chain_trace[2 * (slot) + 1] = clock64(); } } while (0)
+extern "C" int tgnh_debug_read_chain_trace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_trace), sizeof(unsigned long long) * 8);
+}
 #else
 #define TRACE(slot) do {} while (0)
 #define TRACE_WAIT() do {} while (0)
+#define CHAIN_TRACE(slot) do {} while (0)
 #endif
 }
 #include "tgnh_chain_device.h"
@@ -1697,9 +1704,11 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
     const ChainLayout& L = a.L;
     const int NT = L.NT, tid = threadIdx.x;
     double* st = a.st;
+    CHAIN_TRACE(0);
     chain_prologue(a, sred, s_chain, s_ke);
     if (!a.do_chain) return;
     if (!a.do_sum) __syncthreads();
+    CHAIN_TRACE(1);
     if (L.mode == TGNH_MODE_TGNH && L.C > 4 && L.C <= 16 && a.lanes) {
         chain_lanes_run(a, st, tid, BLOCK, s_ke);                    // 5-16 links: a link per lane, in registers
         if (tid == 0) {                                              // Cu :493-497
@@ -1745,6 +1754,7 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
             default: run_dualnh<0>(a, a.st, a.st, true, nullptr, s_chain, s_ke[0], s_ke[1], s_ke[2]); break;               // host checked 4*(2C+2) <= CHAIN_LDS_DOUBLES
         }
     }
+    CHAIN_TRACE(2);
 }
 #pragma clang fp contract(fast)
 
@@ -2093,6 +2103,11 @@ int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds, bool multi) {
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
     if (!a.do_chain) TGNH_LAUNCH(rowsum_kernel, dim3(1), dim3(BLOCK), 0, s, a);
     else TGNH_LAUNCH(chain_kernel, dim3(1), dim3(BLOCK), 0, s, a);
+#ifdef TGNH_TUNING
+    // timing experiment only (the thermostat advances twice): the same launch again, its code now in the caches
+    static const int again = getenv("TGNH_CHAIN_REPEAT") ? atoi(getenv("TGNH_CHAIN_REPEAT")) : 0;
+    for (int r = 0; r < again && a.do_chain; r++) { ChainArgs b = a; b.do_sum = 0; b.commit = 0; b.x_send = 0; b.x_wait = 0; TGNH_LAUNCH(chain_kernel, dim3(1), dim3(BLOCK), 0, s, b); }
+#endif
     return hipGetLastError();
 }
 
@@ -2199,3 +2214,9 @@ hipError_t launch_plain_ke(int precision, const void* velm, const long long* for
 }
 
 }  // namespace tgnh
+
+#ifdef TGNH_TRACE
+extern "C" int tgnh_debug_read_chain_dbg(double* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgnh::g_chain_dbg), sizeof(double) * 4);
+}
+#endif
