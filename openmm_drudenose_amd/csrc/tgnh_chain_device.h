@@ -79,10 +79,11 @@ __device__ __forceinline__ double chain_exp(double x) {
     if (!__any(ax >= 1.0)) return chain_exp_wide(x);
     // no libm call (the streaming kernels' in-kernel chains: ocml's exp would cost them ~30 VGPRs): x = n ln 2 + r with
     // |r| <= 0.35, exp(r) from chain_exp_wide, the power of two by ldexp; <= 6 ulp for every argument exp() itself can take
+    x = fmax(-750.0, fmin(750.0, x));                                // (exp(+-inf) = inf, 0 as libm's: a chain that has overflowed goes on as the reference's does)
     const double n = rint(x * 1.4426950408889634);
     double r = fma(n, -0.693147180369123816490, x);                  // ln 2 in two pieces (the first with 21 trailing zero bits: n * hi is exact)
     r = fma(n, -1.90821492927058770002e-10, r);
-    return ldexp(chain_exp_wide(r), (int)fmax(-2000.0, fmin(2000.0, n)));
+    return ldexp(chain_exp_wide(r), (int)n);
 }
 
 // a * b + c as exactly one v_fma_f64 on three vector registers

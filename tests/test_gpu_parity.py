@@ -231,6 +231,52 @@ def test_100_step_parity(sysname, mode, chains, drude_chains, com, hardwall, pre
     ctx.close()
 
 
+FAR_CASES = [   # (mode, links, flags): every form of the chain -- chain_kernel's, the in-kernel ones, a link per lane, LDS-resident links
+    ("TGNH", 1, 0), ("TGNH", 1, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP), ("TGNH", 1, FLAG_DEFER_SCALE),
+    ("TGNH", 3, 0), ("TGNH", 3, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP), ("TGNH", 3, FLAG_DEFER_SCALE), ("TGNH", 2, 0), ("TGNH", 4, FLAG_DEFER_SCALE),
+    ("TGNH", 10, 0), ("TGNH", 17, 0),
+    ("dualNH", 1, 0), ("dualNH", 1, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP), ("dualNH", 3, 0), ("dualNH", 3, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP),
+]
+
+
+@pytest.mark.parametrize("amp", [800.0, 8000.0, 60000.0])
+@pytest.mark.parametrize("mode,chains,flags", FAR_CASES)
+def test_chain_far_from_equilibrium(mode, chains, flags, amp):
+    """Thermostats far from equilibrium (Cu :566-592: exp(-dtc/8 etaDot[i+1]), exp(-dtc/2 etaDot[0])): with etaDot set to +-amp
+    ps^-1 the exponents per sub-step are 0.02 (outside the short polynomials: chain_exp_wide), 0.2 and 1.5 (beyond it: the
+    ln 2 reduction), on every form of the chain.  An equilibrating box of a million pairs sits in the first two regimes
+    (profiles/r03_chain_cost.md); the parity cases elsewhere stay inside the short polynomial."""
+    s, g, ng, it, ctx = make("mixed", mode, "double", chains=chains, flags=flags, tiles="lds")
+    o = make_oracle(s, g, ng, mode, it)
+    ed = ctx.thermostat_state(1)
+    assert np.all(ed == 0) and np.array_equal(o.chain(1), ed)
+    if mode == "TGNH":
+        live = np.ones(len(ed), bool)
+        live[chains::chains + 1] = False                     # every thermostat's dummy link stays at 0 (Cu :252)
+    else:
+        live = np.arange(len(ed)) < len(ed) - 2              # the interleaved vectors' two dummies (Ref :215)
+    rng = np.random.default_rng(int(amp) + chains)
+    ed[live] = amp * rng.choice([-1.0, 1.0], live.sum()) * rng.uniform(0.5, 1.0, live.sum())
+    ctx.set_thermostat_state(1, ed)
+    o.set_chain(1, ed)
+    pos_o, vel_o = oracle_run(o, s, 3, x0=ctx.sites())
+    if not (np.isfinite(vel_o).all() and np.isfinite(o.chain(1)).all()):
+        ctx.close()
+        pytest.skip("the reference arithmetic itself overflows here (long chain, links driven by amp^2)")
+    ctx.step(3)
+    vscale = max(np.abs(vel_o).max(), 1e-3 * np.abs(s.velocities).max())     # (a thermostat this far out freezes the box within a step: compare against what is left, not against 1e-12 nm/ps)
+    ep, ev = rel_err(ctx.getPositions(), pos_o), np.abs(ctx.getVelocities() - vel_o).max() / vscale
+    if flags & FLAG_DEFER_SCALE:                             # (deferred: the library's chain has run the coming step's first half already)
+        o.propagate_nhc(vel_o.copy())
+    worst = 0.0
+    for which in (0, 1, 2):
+        a, b = ctx.thermostat_state(which), o.chain(which)
+        worst = max(worst, np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+    print(f"{mode} {chains} links flags {flags} amp {amp:g}: pos {ep:.2e} vel {ev:.2e} thermostat {worst:.2e} |v|max {np.abs(vel_o).max():.3g}")
+    assert ep <= 1e-10 and ev <= 1e-10 and worst <= 1e-10 and ctx.check() == 0
+    ctx.close()
+
+
 @pytest.mark.parametrize("precision", ["mixed", "double"])
 @pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
 def test_100_step_parity_hardwall(mode, precision):
