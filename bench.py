@@ -541,10 +541,12 @@ def main():
     from openmm_drudenose_amd import synth, _lib
     system, group, ngroups = synth.water_box(args.molecules)
     if args.variant == "auto":
-        # One launch per step (step_kernel) pays where a work-group walks a handful of tiles: +4-5 % from 2.5 M slots per
-        # GPU down, i.e. for the shards of a 2-, 4- or 8-GPU run (profiles/r02_scaling_ceiling.md).  At 5 M slots it is
-        # within 2 % of the three-launch structure (its first pass runs at the occupancy of the second), which is kept there.
-        args.variant = "resident" if system.num_particles / world < 3_000_000 else "defer"
+        # One launch per step (wstep_kernel on a water box): +4-10 % from 2.5 M slots per GPU down, i.e. for the shards of a
+        # 2-, 4- or 8-GPU run (profiles/r03_scaling_ceiling.md), and since the wave tiles of identical molecules stopped reading
+        # per-slot words also +3 % at 5 M slots (interleaved on one box: 3 866 / 3 869 / 3 875 against 3 745 / 3 740 / 3 727 for the
+        # three-launch structure, tools/micro/variant_ab.sh).  A handle that cannot hold the step resident falls back by itself
+        # (`variant_ran`).
+        args.variant = "resident"
 
     use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
     gsteps = args.graph_steps if use_graph else 0
@@ -635,7 +637,7 @@ def main():
     if mailbox_info:
         extra["mailbox"] = dict(extra.get("mailbox", {}), **mailbox_info)
     if world == 1 and not args.no_extra:
-        for prec, var in ((args.precision, "plain"), (args.precision, "plain-resident"), (args.precision, "resident"), ("single", args.variant)):
+        for prec, var in ((args.precision, "plain"), (args.precision, "plain-resident"), (args.precision, "defer"), (args.precision, "resident"), ("single", args.variant)):
             if (prec, var) == (args.precision, args.variant):
                 continue
             c2 = build_context(args, system, group, ngroups, rank, world, prec, var)

@@ -264,7 +264,11 @@ tgnh_status tgnh_set_thermostat_state(tgnh_handle h, int which, void* stream, co
 /* Topology the kernels were built from, for bit-exact index parity (A1).
  * which: 0 normalParticles, 1 pair drude, 2 pair parent, 3 particleTempGroup,
  * 4 particleResId, 5 particlesInResidues.count, 6 particlesInResidues.first,
- * 7 tile starts (num_tiles+1), 8 packed per-slot meta words. */
+ * 7 tile starts (num_tiles+1), 8 packed per-slot meta words, 9 wave tiles as (first slot, largest molecule) pairs
+ * (one more than tiles; none: a molecule or pair longer than a wavefront), 10 the wave tiles' per-slot words,
+ * 11 per 512-slot tile: period | molecules per period << 8 | pattern << 16, 12 per wave tile: period | pattern << 8, where
+ * the tile repeats one kind of molecule (or a few) and its kernels form the per-slot words from a pattern instead of
+ * reading them (0: they read them), 13 / 14 the patterns of the two, 64 words each. */
 tgnh_status tgnh_get_topology_len(tgnh_handle h, int which, int* len);
 tgnh_status tgnh_get_topology(tgnh_handle h, int which, int32_t* out);
 

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -253,8 +254,64 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
             c->wave_tile = wt;
         }
     }
+    // tiles of identical molecules (PATTERN_WORDS, tgnh_internal.h)
+    {
+        std::map<std::vector<uint32_t>, uint32_t> ids, wids;
+        auto intern = [&](std::map<std::vector<uint32_t>, uint32_t>& m, std::vector<uint32_t>& store, const uint32_t* w, int P,
+                          uint32_t limit, uint32_t* id) {
+            std::vector<uint32_t> key(w, w + P);
+            auto it = m.find(key);
+            if (it == m.end()) {
+                if (m.size() >= limit) return false;
+                it = m.emplace(key, (uint32_t)m.size()).first;
+                key.resize(PATTERN_WORDS, 0u);
+                store.insert(store.end(), key.begin(), key.end());
+            }
+            *id = it->second;
+            return true;
+        };
+        c->tile_pat.assign(std::max(c->num_tiles, 1), 0u); c->pattern.clear();
+        for (int t = 0; t < c->num_tiles; t++) {
+            const int ts = c->tile_start[t], n = c->tile_start[t + 1] - ts;
+            // the smallest period that reproduces the tile (a wrong one fails within a few slots); the molecules it spans are
+            // read off the molecule index of the slot one period in (a cation and its anion: 2; ten waters, one tagged: 10)
+            for (int P = 1; P <= PATTERN_WORDS && P < n; P++) {
+                const uint32_t mols = com ? (c->meta[ts + P] >> 21) - (c->meta[ts] >> 21) : 0u;
+                if (mols > 255u) break;
+                bool same = true;
+                for (int k = 0; k < n && same; k++)
+                    same = c->meta[ts + k] == c->meta[ts + k % P] + (((uint32_t)(k / P) * mols) << 21);
+                if (!same) continue;
+                uint32_t id;
+                if (intern(ids, c->pattern, c->meta.data() + ts, P, 1u << 16, &id))
+                    c->tile_pat[t] = (uint32_t)P | (mols << 8) | (id << 16);
+                break;
+            }
+        }
+        c->wtile_pat.assign(std::max(c->num_wtiles, 1), 0u); c->wpattern.clear();
+        for (int t = 0; t < c->num_wtiles; t++) {
+            const int ws = c->wave_tile[t].x, n = c->wave_tile[t + 1].x - ws;
+            for (int P = 1; P <= PATTERN_WORDS && P < n; P++) {
+                bool same = true;
+                for (int k = 0; k < n && same; k++) same = c->wmeta[ws + k] == c->wmeta[ws + k % P];
+                if (!same) continue;
+                uint32_t id;
+                if (intern(wids, c->wpattern, c->wmeta.data() + ws, P, 1u << 16, &id))
+                    c->wtile_pat[t] = (uint32_t)P | (id << 8);
+                break;
+            }
+        }
+        if (c->pattern.empty()) c->pattern.assign(PATTERN_WORDS, 0u);
+        if (c->wpattern.empty()) c->wpattern.assign(PATTERN_WORDS, 0u);
+    }
     if (c->host_only) return TGNH_OK;
     // device copies
+    HIP_OK(hipMalloc(&c->d_tile_pat, sizeof(uint32_t) * c->tile_pat.size()));
+    HIP_OK(hipMemcpy(c->d_tile_pat, c->tile_pat.data(), sizeof(uint32_t) * c->tile_pat.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc(&c->d_pattern, sizeof(uint32_t) * c->pattern.size()));
+    HIP_OK(hipMemcpy(c->d_pattern, c->pattern.data(), sizeof(uint32_t) * c->pattern.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc(&c->d_wpattern, sizeof(uint32_t) * c->wpattern.size()));
+    HIP_OK(hipMemcpy(c->d_wpattern, c->wpattern.data(), sizeof(uint32_t) * c->wpattern.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMalloc(&c->d_meta, sizeof(uint32_t) * std::max(N, 1)));
     HIP_OK(hipMemcpy(c->d_meta, c->meta.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
     HIP_OK(hipMalloc(&c->d_tile_start, sizeof(int) * c->tile_start.size()));
@@ -264,8 +321,10 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
     HIP_OK(hipMalloc(&c->d_res_table, sizeof(int2) * c->res_entries.size()));
     HIP_OK(hipMemcpy(c->d_res_table, c->res_entries.data(), sizeof(int2) * c->res_entries.size(), hipMemcpyHostToDevice));
     if (!c->wave_tile.empty()) {
-        HIP_OK(hipMalloc(&c->d_wave_tile, sizeof(int2) * c->wave_tile.size()));
-        HIP_OK(hipMemcpy(c->d_wave_tile, c->wave_tile.data(), sizeof(int2) * c->wave_tile.size(), hipMemcpyHostToDevice));
+        std::vector<int2> packed = c->wave_tile;           // device copy: y = largest molecule | period << 8 | pattern << 16
+        for (int t = 0; t < c->num_wtiles; t++) packed[t].y |= (int)(c->wtile_pat[t] << 8);
+        HIP_OK(hipMalloc(&c->d_wave_tile, sizeof(int2) * packed.size()));
+        HIP_OK(hipMemcpy(c->d_wave_tile, packed.data(), sizeof(int2) * packed.size(), hipMemcpyHostToDevice));
         HIP_OK(hipMalloc(&c->d_wmeta, sizeof(uint32_t) * N));
         HIP_OK(hipMemcpy(c->d_wmeta, c->wmeta.data(), sizeof(uint32_t) * N, hipMemcpyHostToDevice));
     }
@@ -451,6 +510,9 @@ static void free_device(tgnh_context* c) {
     if (c->d_res_table) (void)hipFree(c->d_res_table);
     if (c->d_wave_tile) (void)hipFree(c->d_wave_tile);
     if (c->d_wmeta) (void)hipFree(c->d_wmeta);
+    if (c->d_tile_pat) (void)hipFree(c->d_tile_pat);
+    if (c->d_pattern) (void)hipFree(c->d_pattern);
+    if (c->d_wpattern) (void)hipFree(c->d_wpattern);
     if (c->d_sflag) (void)hipFree(c->d_sflag);
     if (c->d_sbase) (void)hipFree(c->d_sbase);
     if (c->d_sites) (void)hipFree(c->d_sites);
@@ -1035,6 +1097,7 @@ static TileArgs tile_args(tgnh_handle h, const double* scale) {
     a.num_tiles = h->num_tiles; a.padded = h->d.padded_num_particles; a.num_groups = h->L.G;
     a.reverse = h->sweep_reverse;
     a.wave_tile = h->d_wave_tile; a.wmeta = h->d_wmeta; a.num_wtiles = h->num_wtiles;
+    a.tile_pat = h->d_tile_pat; a.pattern = h->d_pattern; a.wpattern = h->d_wpattern;
     a.use_com = (h->d.mode == TGNH_MODE_TGNH && h->d.use_com_temp_group) ? 1 : 0;
     a.hardwall = h->d.max_drude_distance > 0 ? 1 : 0;                         // Ref :299, Cu :372
     a.dt = h->d.step_size; a.max_dist = h->d.max_drude_distance;
@@ -1616,6 +1679,10 @@ extern "C" tgnh_status tgnh_get_topology_len(tgnh_handle h, int which, int* len)
     if (which == 8) { *len = (int)h->meta.size(); return TGNH_OK; }
     if (which == 9) { *len = 2 * (int)h->wave_tile.size(); return TGNH_OK; }      // wave tiles: (first slot, largest molecule) pairs, one more than tiles; 0 = none
     if (which == 10) { *len = (int)h->wmeta.size(); return TGNH_OK; }
+    if (which == 11) { *len = (int)h->tile_pat.size(); return TGNH_OK; }        // per 512-slot tile: period | pattern << 8 (0: per-slot words)
+    if (which == 12) { *len = (int)h->wtile_pat.size(); return TGNH_OK; }       // ... per wave tile
+    if (which == 13) { *len = (int)h->pattern.size(); return TGNH_OK; }         // the patterns, 64 words each
+    if (which == 14) { *len = (int)h->wpattern.size(); return TGNH_OK; }
     const std::vector<int>* v = topo_vec(h, which);
     if (!v) return fail(TGNH_ERR_ARG, "bad topology array id");
     *len = (int)v->size();
@@ -1626,6 +1693,10 @@ extern "C" tgnh_status tgnh_get_topology(tgnh_handle h, int which, int32_t* out)
     if (which == 8) { std::memcpy(out, h->meta.data(), sizeof(uint32_t) * h->meta.size()); return TGNH_OK; }
     if (which == 9) { std::memcpy(out, h->wave_tile.data(), sizeof(int2) * h->wave_tile.size()); return TGNH_OK; }
     if (which == 10) { std::memcpy(out, h->wmeta.data(), sizeof(uint32_t) * h->wmeta.size()); return TGNH_OK; }
+    if (which == 11) { std::memcpy(out, h->tile_pat.data(), sizeof(uint32_t) * h->tile_pat.size()); return TGNH_OK; }
+    if (which == 12) { std::memcpy(out, h->wtile_pat.data(), sizeof(uint32_t) * h->wtile_pat.size()); return TGNH_OK; }
+    if (which == 13) { std::memcpy(out, h->pattern.data(), sizeof(uint32_t) * h->pattern.size()); return TGNH_OK; }
+    if (which == 14) { std::memcpy(out, h->wpattern.data(), sizeof(uint32_t) * h->wpattern.size()); return TGNH_OK; }
     const std::vector<int>* v = topo_vec(h, which);
     if (!v) return fail(TGNH_ERR_ARG, "bad topology array id");
     std::copy(v->begin(), v->end(), out);

@@ -60,6 +60,13 @@ inline uint32_t pack_wmeta(uint32_t role, uint32_t group, int partner_off, uint3
     return role | (group << 2) | ((uint32_t)(partner_off + 64) << 10) | (pos_in_mol << 17) | (mol_slots_m1 << 23);
 }
 
+// ---- tiles of identical molecules ------------------------------------------------------------------------------------
+// A box is mostly one kind of small molecule (water), and for a tile that holds nothing else the per-slot word is a function
+// of the slot's position in the tile: word(k) = pattern[k mod P] (+ (k div P) * molecules per period << 21 for the 512-slot
+// tiles' molecule index), P = the molecule's slots or a few molecules' (every tenth water tagged: ten).  Such a tile is marked at create and its kernels read the P words of the pattern (a few cache
+// lines for the whole launch) instead of 4 B per slot from HBM: 20 MB per launch at 5 M slots.
+constexpr int PATTERN_WORDS = 64;       // longest period
+
 // ---- operation mask of the tile kernel --------------------------------------
 enum : int {
     OP_SCALE = 1,      // A6  velocity rescale          (K integrateDrudeTGNHChain)
@@ -184,6 +191,11 @@ struct TileArgs {
     // wave tiles (wke_kernel)
     const int2* wave_tile;     // [num_wtiles + 1]: (first slot, slots of the tile's largest molecule); the next entry's first slot ends it
     const uint32_t* wmeta;     // per-slot word of the wave tiles (pack_wmeta)
+    // Tiles of identical molecules carry no per-slot words (PATTERN_* below): tile_pat[t] = period | molecules per period << 8 |
+    // pattern << 16 (0: read meta); the wave tiles' period | pattern << 8 in the high bits of wave_tile[t].y; the patterns, 64 words each
+    const uint32_t* tile_pat;
+    const uint32_t* pattern;
+    const uint32_t* wpattern;
     int num_wtiles;
     // wke_kernel, tail sum: the rows go out as tagged cells (`rows`, `sync`, as in step_kernel) and work-group 0, when its own
     // tiles are done, collects them in row order and leaves the sums in ke_red -- the launch that only summed the rows is gone
@@ -290,6 +302,9 @@ struct tgnh_context {
     std::vector<uint32_t> meta;
     std::vector<int2> wave_tile;      // wave tiles (empty: some molecule or pair does not fit a wavefront)
     std::vector<uint32_t> wmeta;
+    std::vector<uint32_t> tile_pat, wtile_pat;    // per 512-slot tile: period | molecules << 8 | pattern << 16; per wave tile: period | pattern << 8; 0 = none
+    std::vector<uint32_t> pattern, wpattern;      // 64 words per pattern
+    uint32_t *d_tile_pat = nullptr, *d_pattern = nullptr, *d_wpattern = nullptr;
     int num_wtiles = 0;
     int2* d_wave_tile = nullptr;
     uint32_t* d_wmeta = nullptr;

@@ -208,13 +208,24 @@ __device__ __forceinline__ void tile_load(const TileArgs& a, const int t, TileIn
         in.rs = a.tile_res[t]; in.nres = a.tile_res[t + 1] - in.rs;
         if ((O::DO_SCALE || O::DO_KE) && a.use_com && tid < in.nres) in.rt = a.res_table[in.rs + tid];
     }
+    // a tile of identical molecules: the slot's word from its position (PATTERN_WORDS, tgnh_internal.h), no 4 B per slot from HBM
+    const uint32_t pat = KEEP_VF ? 0u : a.tile_pat[t];
+    const int period = (int)(pat & 255u), mols = (int)((pat >> 8) & 255u);
+    const uint32_t* __restrict__ words = a.pattern + (size_t)(pat >> 16) * PATTERN_WORDS;
+    const float rperiod = period ? __builtin_amdgcn_rcpf((float)period) : 0.0f;
 #pragma unroll
     for (int k = 0; k < SPT; k++) {
         const int idx = in.ts + k * TBLOCK + tid;
         if (idx < in.te) {
             if (!KEEP_VF) {
                 in.v[k] = velm[idx];
-                in.meta[k] = a.meta[idx];
+                if (period) {
+                    const int pos = k * TBLOCK + tid;
+                    const int q = (int)(((float)pos + 0.5f) * rperiod);      // pos div period (pos < 512, period <= 64: never within rounding of an integer)
+                    in.meta[k] = words[pos - q * period] + (a.use_com ? (uint32_t)(q * mols) << 21 : 0u);
+                } else {
+                    in.meta[k] = a.meta[idx];
+                }
             }
             if (LOAD_F) {
                 in.fx[k] = a.force[idx];
@@ -799,25 +810,43 @@ __device__ __forceinline__ double force_as(const long long f, double) {
 }
 __device__ __forceinline__ float force_as(const long long f, float) { return (float)f; }
 
+// Wave tiles of identical molecules (PATTERN_WORDS, tgnh_internal.h): a lane's position in the pattern is the same in every such
+// tile (they all start on a molecule), so the lane keeps its word in a register and fetches it again only when a tile of another
+// pattern comes by -- for a water box once per launch.  pat = period | pattern << 8, 0 = this tile's words are read from wmeta.
+struct PatternWord {
+    uint32_t pat = 0u, word = 0u;
+    __device__ __forceinline__ bool of(const TileArgs& a, const uint32_t p, const int lane) {     // wavefront-uniform
+        if ((p & 255u) == 0u) return false;
+        if (p != pat) {
+            const int period = (int)(p & 255u);
+            const int q = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)period));     // lane div period (never within rounding of an integer)
+            word = a.wpattern[(p >> 8) * PATTERN_WORDS + (uint32_t)(lane - q * period)];
+            pat = p;
+        }
+        return true;
+    }
+};
+
 template <int PREC, int OPS>
-__device__ __forceinline__ void wave_load(const TileArgs& a, const int ws, const int n, const int lane, WaveIn<PREC>& in) {
+__device__ __forceinline__ void wave_load(const TileArgs& a, const int ws, const int n, const bool patterned, const uint32_t pword, const int lane, WaveIn<PREC>& in) {
     typedef typename Prec<PREC>::mixed mixed;
     typedef typename Prec<PREC>::mixed4 mixed4;
     const mixed4* __restrict__ velm = reinterpret_cast<const mixed4*>(a.velm);
     const int idx = ws + lane;
+    mixed4 v = mk4((mixed)0, (mixed)0, (mixed)0, (mixed)0);      // a padding lane: massless, role normal, a molecule of its own -- contributes nothing
+    uint32_t meta = 64u << 10;
+    long long fx = 0, fy = 0, fz = 0;
     if (lane < n) {
-        in.v = velm[idx];
-        in.meta = a.wmeta[idx];
+        v = velm[idx];
+        if (!patterned) meta = a.wmeta[idx];
         if (OPS & OP_KICK) {
-            in.fx = a.force[idx];
-            in.fy = a.force[idx + a.padded];
-            in.fz = a.force[idx + 2 * a.padded];
+            fx = a.force[idx];
+            fy = a.force[idx + a.padded];
+            fz = a.force[idx + 2 * a.padded];
         }
-    } else {
-        in.v = mk4((mixed)0, (mixed)0, (mixed)0, (mixed)0);      // massless, role normal, a molecule of its own: contributes nothing
-        in.meta = 64u << 10;
-        in.fx = in.fy = in.fz = 0;
     }
+    if (patterned && lane < n) meta = pword;
+    in.v = v; in.meta = meta; in.fx = fx; in.fy = fy; in.fz = fz;
 }
 
 template <int GB, bool LEAN, int NTH>
@@ -853,10 +882,10 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileAr
     // tiles.  Everything about WHICH tile is wavefront-uniform (scalar registers, scalar loads): the bounds of the tile after
     // next are fetched while this one is worked on, so the vector loads of the next tile never wait for an index.
     const int nw = a.num_wtiles, stride = (int)gridDim.x * (TBLOCK / 64);
-    struct Bounds { int ws, maxn, n; };
+    struct Bounds { int ws, y, n; };        // y = the tile's largest molecule | pattern word << 8 (wave_word)
     auto bounds = [&](const int ww, Bounds& b) {
         const int2* t = a.wave_tile + (a.reverse ? nw - 1 - ww : ww);
-        b.ws = t[0].x; b.maxn = t[0].y; b.n = t[1].x - b.ws;
+        b.ws = t[0].x; b.y = t[0].y; b.n = t[1].x - b.ws;
     };
     auto work = [&](const WaveIn<PREC>& cur, const Bounds& bd) {
         mixed4 v = cur.v;
@@ -882,7 +911,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileAr
             const int j = (int)((m >> 17) & 63u), n1 = (int)((m >> 23) & 63u);
             const int first = lane - j;
             mixed px = 0, py = 0, pz = 0, pm = 0;
-            for (int k = 0; k < bd.maxn; k++) {                          // (bd.maxn: the tile's largest molecule, a scalar)
+            for (int k = 0; k < (bd.y & 255); k++) {                          // (bd.maxn: the tile's largest molecule, a scalar)
                 if (k <= n1) {
                     const mixed um = im[first + k];
                     px += ix[first + k] * um; py += iy[first + k] * um; pz += iz[first + k] * um; pm += um;
@@ -918,16 +947,21 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileAr
     int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (TBLOCK / 64) + wv);
     Bounds b0{}, b1{}, b2{};
     WaveIn<PREC> A, B;
-    if (w < nw) { bounds(w, b0); wave_load<PREC, OPS>(a, b0.ws, b0.n, lane, A); }
+    PatternWord pw;
+    auto load = [&](const Bounds& b, WaveIn<PREC>& in) {
+        const bool patterned = pw.of(a, (uint32_t)b.y >> 8, lane);
+        wave_load<PREC, OPS>(a, b.ws, b.n, patterned, pw.word, lane, in);
+    };
+    if (w < nw) { bounds(w, b0); load(b0, A); }
     if (w + stride < nw) bounds(w + stride, b1);
     while (w < nw) {                                                     // two tiles per trip: the register images alternate
         if (w + 2 * stride < nw) bounds(w + 2 * stride, b2);
-        if (w + stride < nw) wave_load<PREC, OPS>(a, b1.ws, b1.n, lane, B);   // in flight while A is worked on
+        if (w + stride < nw) load(b1, B);                                // in flight while A is worked on
         work(A, b0);
         w += stride;
         if (w >= nw) break;
         if (w + 2 * stride < nw) bounds(w + 2 * stride, b0);
-        if (w + stride < nw) wave_load<PREC, OPS>(a, b2.ws, b2.n, lane, A);
+        if (w + stride < nw) load(b2, A);
         work(B, b1);
         w += stride;
         b1 = b0; b0 = b2;                                                // (scalar moves)
@@ -1366,22 +1400,25 @@ __global__ __launch_bounds__(WBLOCK) void wstep_kernel(const TileArgs a) {
     if (MULTI && a.chain.L.C > 1 && tid < a.chain.L.total) s_block[tid] = a.st_in[tid];
 
     const int nw = a.num_wtiles, stride = (int)gridDim.x * (WBLOCK / 64);
-    struct Bounds { int ws, maxn, n; };
+    struct Bounds { int ws, y, n; };        // y = the tile's largest molecule | pattern word << 8 (wave_word)
     auto bounds = [&](const int ww, Bounds& b) {
         const int2* t = a.wave_tile + (a.reverse ? nw - 1 - ww : ww);
-        b.ws = t[0].x; b.maxn = t[0].y; b.n = t[1].x - b.ws;
+        b.ws = t[0].x; b.y = t[0].y; b.n = t[1].x - b.ws;
     };
+    PatternWord pw;
     auto load_vf = [&](const Bounds& b, WStepIn<PREC>& in) {          // what pass 1 needs
         const int idx = b.ws + lane;
+        const bool patterned = pw.of(a, (uint32_t)b.y >> 8, lane);
+        mixed4 v = mk4((mixed)0, (mixed)0, (mixed)0, (mixed)0);
+        uint32_t meta = 64u << 10;
+        long long fx = 0, fy = 0, fz = 0;
         if (lane < b.n) {
-            in.v = reinterpret_cast<const mixed4*>(a.velm)[idx];
-            in.meta = a.wmeta[idx];
-            in.fx = a.force[idx]; in.fy = a.force[idx + a.padded]; in.fz = a.force[idx + 2 * a.padded];
-        } else {
-            in.v = mk4((mixed)0, (mixed)0, (mixed)0, (mixed)0);
-            in.meta = 64u << 10;
-            in.fx = in.fy = in.fz = 0;
+            v = reinterpret_cast<const mixed4*>(a.velm)[idx];
+            if (!patterned) meta = a.wmeta[idx];
+            fx = a.force[idx]; fy = a.force[idx + a.padded]; fz = a.force[idx + 2 * a.padded];
         }
+        if (patterned && lane < b.n) meta = pw.word;
+        in.v = v; in.meta = meta; in.fx = fx; in.fy = fy; in.fz = fz;
     };
     auto load_x = [&](const Bounds& b, WStepIn<PREC>& in) {           // ... and what pass 2 needs on top
         const int idx = b.ws + lane;
@@ -1409,7 +1446,7 @@ __global__ __launch_bounds__(WBLOCK) void wstep_kernel(const TileArgs a) {
             const int j = (int)((m >> 17) & 63u), n1 = (int)((m >> 23) & 63u);
             const int first = lane - j;
             mixed px = 0, py = 0, pz = 0, pm = 0;
-            for (int k = 0; k < bd.maxn; k++) {
+            for (int k = 0; k < (bd.y & 255); k++) {
                 if (k <= n1) {
                     const mixed um = im[first + k];
                     px += ix[first + k] * um; py += iy[first + k] * um; pz += iz[first + k] * um; pm += um;

@@ -95,6 +95,52 @@ def test_wave_tiles_and_their_words(name, com):
         assert np.all(pos == 0) and np.all(size == 1) and np.all(wt[:-1, 1] == 1)
 
 
+@pytest.mark.parametrize("name,com", [("pnm", True), ("nacl", True), ("il", True), ("mixed", True), ("water", True), ("mixed", False),
+                                      ("water", False), ("polymer", True), ("polymer", False)])
+def test_tiles_of_identical_molecules_need_no_per_slot_words(name, com):
+    """A tile that repeats one kind of molecule (or a few) is marked at create (topology 11 / 12) and its kernels form the
+    per-slot word from the slot's position -- pattern[k mod P], plus the molecule's index (k div P) * molecules per period << 21
+    in the 512-slot tiles -- instead of reading 4 B per slot.  Every marked tile's pattern reproduces its words exactly; a water box is marked
+    throughout, the mixed boxes where their waters are."""
+    s, g, ng = synth.polymer_in_water(150, 40) if name == "polymer" else BUILDERS[name]()
+    it = integ(group=g, ngroups=ng, com=com)
+    t = HostTopology(s, it, mode="TGNH")
+    n = s.num_particles
+    meta, starts = t.topology(8).view(np.uint32), t.topology(7)
+    pat, words = t.topology(11).view(np.uint32), t.topology(13).view(np.uint32).reshape(-1, 64)
+    assert len(pat) == max(len(starts) - 1, 1)
+    marked = 0
+    for k in range(len(starts) - 1):
+        ts, m = starts[k], starts[k + 1] - starts[k]
+        P, mols, pid = int(pat[k] & 255), int((pat[k] >> 8) & 255), int(pat[k] >> 16)
+        if P == 0:
+            continue
+        marked += m
+        pos = np.arange(m)
+        made = words[pid][pos % P] + (((pos // P) * mols).astype(np.uint32) << 21 if com else 0)
+        assert np.array_equal(made.astype(np.uint32), meta[ts:ts + m]), (name, com, k)
+    wt = t.topology(9).reshape(-1, 2)
+    wmarked = 0
+    if len(wt):
+        wmeta = t.topology(10).view(np.uint32)
+        wpat, wwords = t.topology(12).view(np.uint32), t.topology(14).view(np.uint32).reshape(-1, 64)
+        assert len(wpat) == len(wt) - 1
+        for k in range(len(wt) - 1):
+            ws, m = wt[k, 0], wt[k + 1, 0] - wt[k, 0]
+            P, pid = int(wpat[k] & 255), int(wpat[k] >> 8)
+            if P == 0:
+                continue
+            wmarked += m
+            assert np.array_equal(wwords[pid][np.arange(m) % P], wmeta[ws:ws + m]), (name, com, k)
+    print(name, com, "slots in marked tiles:", marked, "of", n, "; in marked wave tiles:", wmarked)
+    if name == "water":
+        assert marked == n and wmarked == n
+        if com:
+            assert len(words) == 1 and len(wwords) == 1      # one kind of molecule, tiles cut between molecules: one pattern
+    if name == "mixed":                                      # (every tenth water in a group of its own: periods of ten molecules)
+        assert 0 < marked < n and 0 < wmarked < n
+
+
 @pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
 @pytest.mark.parametrize("com,chains,drude_chains,cmm", [(True, 1, True, False), (True, 3, False, True), (False, 4, True, True),
                                                          (True, 6, True, False)])
