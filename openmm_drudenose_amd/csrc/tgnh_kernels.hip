@@ -190,7 +190,8 @@ template <int OPS> struct OpsOf {
 
 // issue the global loads of tile t for a pass with operations OPS.  HAVE != 0: `in` already holds what a pass with
 // operations HAVE loaded for this very tile (velocities, index words, and its forces if it needed them): fetch the rest.
-template <int PREC, int OPS, int HAVE = 0>
+// PATTERN = false: always the per-slot words (tile_kernel's read-only KE passes, at their register budget of 5 work-groups per CU).
+template <int PREC, int OPS, int HAVE = 0, bool PATTERN = true>
 __device__ __forceinline__ void tile_load(const TileArgs& a, const int t, TileIn<PREC>& in) {
     constexpr bool KEEP_VF = HAVE != 0;
     constexpr bool LOAD_F = OpsOf<OPS>::NEED_F && !(KEEP_VF && OpsOf<HAVE>::NEED_F);
@@ -209,7 +210,7 @@ __device__ __forceinline__ void tile_load(const TileArgs& a, const int t, TileIn
         if ((O::DO_SCALE || O::DO_KE) && a.use_com && tid < in.nres) in.rt = a.res_table[in.rs + tid];
     }
     // a tile of identical molecules: the slot's word from its position (PATTERN_WORDS, tgnh_internal.h), no 4 B per slot from HBM
-    const uint32_t pat = KEEP_VF ? 0u : a.tile_pat[t];
+    const uint32_t pat = (KEEP_VF || !PATTERN) ? 0u : a.tile_pat[t];
     const int period = (int)(pat & 255u), mols = (int)((pat >> 8) & 255u);
     const uint32_t* __restrict__ words = a.pattern + (size_t)(pat >> 16) * PATTERN_WORDS;
     const float rperiod = period ? __builtin_amdgcn_rcpf((float)period) : 0.0f;
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
     const int G = a.num_groups;
     TileEnv<PREC, GB> e;
     e.init(a, smem, s_scale, POS && a.hardwall != 0);
-    auto load_tile = [&](int tt, TileIn<PREC>& in) { tile_load<PREC, OPS>(a, a.reverse ? a.num_tiles - 1 - tt : tt, in); };
+    auto load_tile = [&](int tt, TileIn<PREC>& in) { tile_load<PREC, OPS, 0, OpsOf<OPS>::POS || OpsOf<OPS>::VEL_W>(a, a.reverse ? a.num_tiles - 1 - tt : tt, in); };
 
     TileIn<PREC> cur;
     TRACE(0);
