@@ -129,6 +129,14 @@ template <int PREC> struct TileIn {
     int2 rt;                 // this lane's molecule entry (lane r < nres): fetched with the tile, not after the first barrier
 };
 
+// Tiles of identical molecules (PATTERN_WORDS, tgnh_internal.h): a thread's slots sit at the same positions in every tile, so the
+// words it forms for one tile of a pattern are the words of the next -- kept in registers, formed again when the pattern changes
+// (a water box: once per launch; the pattern's lines would otherwise be fetched by every wavefront of the chip for every tile).
+struct TilePattern {
+    uint32_t pat = 0u;
+    uint32_t word[SPT] = {};
+};
+
 // What a work-group carries through a launch: the LDS carve, its KE accumulators, launch constants.
 template <int PREC, int GB> struct TileEnv {
     typedef typename Prec<PREC>::mixed mixed;
@@ -192,7 +200,7 @@ template <int OPS> struct OpsOf {
 // operations HAVE loaded for this very tile (velocities, index words, and its forces if it needed them): fetch the rest.
 // PATTERN = false: always the per-slot words (tile_kernel's read-only KE passes, at their register budget of 5 work-groups per CU).
 template <int PREC, int OPS, int HAVE = 0, bool PATTERN = true>
-__device__ __forceinline__ void tile_load(const TileArgs& a, const int t, TileIn<PREC>& in) {
+__device__ __forceinline__ void tile_load(const TileArgs& a, const int t, TileIn<PREC>& in, TilePattern& tp) {
     constexpr bool KEEP_VF = HAVE != 0;
     constexpr bool LOAD_F = OpsOf<OPS>::NEED_F && !(KEEP_VF && OpsOf<HAVE>::NEED_F);
     typedef typename Prec<PREC>::mixed mixed;
@@ -209,24 +217,28 @@ __device__ __forceinline__ void tile_load(const TileArgs& a, const int t, TileIn
         in.rs = a.tile_res[t]; in.nres = a.tile_res[t + 1] - in.rs;
         if ((O::DO_SCALE || O::DO_KE) && a.use_com && tid < in.nres) in.rt = a.res_table[in.rs + tid];
     }
-    // a tile of identical molecules: the slot's word from its position (PATTERN_WORDS, tgnh_internal.h), no 4 B per slot from HBM
+    // a tile of identical molecules: the slot's word from its position (TilePattern), no 4 B per slot from HBM
     const uint32_t pat = (KEEP_VF || !PATTERN) ? 0u : a.tile_pat[t];
-    const int period = (int)(pat & 255u), mols = (int)((pat >> 8) & 255u);
-    const uint32_t* __restrict__ words = a.pattern + (size_t)(pat >> 16) * PATTERN_WORDS;
-    const float rperiod = period ? __builtin_amdgcn_rcpf((float)period) : 0.0f;
+    if (pat != 0u && pat != tp.pat) {                             // (work-group-uniform)
+        const int period = (int)(pat & 255u), mols = (int)((pat >> 8) & 255u);
+        const uint32_t* __restrict__ words = a.pattern + (size_t)(pat >> 16) * PATTERN_WORDS;
+        const float rperiod = __builtin_amdgcn_rcpf((float)period);
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            const int pos = k * TBLOCK + tid;
+            const int q = (int)(((float)pos + 0.5f) * rperiod);          // pos div period (pos < 512, period <= 64: never within rounding of an integer)
+            tp.word[k] = words[pos - q * period] + (a.use_com ? (uint32_t)(q * mols) << 21 : 0u);
+        }
+        tp.pat = pat;
+    }
 #pragma unroll
     for (int k = 0; k < SPT; k++) {
         const int idx = in.ts + k * TBLOCK + tid;
         if (idx < in.te) {
             if (!KEEP_VF) {
                 in.v[k] = velm[idx];
-                if (period) {
-                    const int pos = k * TBLOCK + tid;
-                    const int q = (int)(((float)pos + 0.5f) * rperiod);      // pos div period (pos < 512, period <= 64: never within rounding of an integer)
-                    in.meta[k] = words[pos - q * period] + (a.use_com ? (uint32_t)(q * mols) << 21 : 0u);
-                } else {
-                    in.meta[k] = a.meta[idx];
-                }
+                if (pat == 0u) in.meta[k] = a.meta[idx];
+                else in.meta[k] = tp.word[k];
             }
             if (LOAD_F) {
                 in.fx[k] = a.force[idx];
@@ -656,7 +668,8 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
     const int G = a.num_groups;
     TileEnv<PREC, GB> e;
     e.init(a, smem, s_scale, POS && a.hardwall != 0);
-    auto load_tile = [&](int tt, TileIn<PREC>& in) { tile_load<PREC, OPS, 0, OpsOf<OPS>::POS || OpsOf<OPS>::VEL_W>(a, a.reverse ? a.num_tiles - 1 - tt : tt, in); };
+    TilePattern tp;
+    auto load_tile = [&](int tt, TileIn<PREC>& in) { tile_load<PREC, OPS, 0, OpsOf<OPS>::POS || OpsOf<OPS>::VEL_W>(a, a.reverse ? a.num_tiles - 1 - tt : tt, in, tp); };
 
     TileIn<PREC> cur;
     TRACE(0);
@@ -1290,17 +1303,18 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
     TRACE(0);
     TileIn<PREC> cur;
     int tt = blockIdx.x;                                   // grid <= num_tiles: every work-group has a tile
-    tile_load<PREC, STEP_OPS1>(a, tile_of(tt), cur);
+    TilePattern tp;
+    tile_load<PREC, STEP_OPS1>(a, tile_of(tt), cur, tp);
     for (;;) {
         tile_body<PREC, STEP_OPS1, GB>(a, e, cur, 4);      // (trace slots >= 16: not recorded)
         if (tt + grid >= a.num_tiles) break;
         tt += grid;
-        tile_load<PREC, STEP_OPS1>(a, tile_of(tt), cur);
+        tile_load<PREC, STEP_OPS1>(a, tile_of(tt), cur, tp);
     }
     const int tt_last = tt;                                // stays in `cur`; its velocity image and COM table stay in LDS
     TRACE(1);
     MeetShared sh{s_scale, s_part, s_x, &s_go, &s_gen, &s_seq1, nullptr};
-    if (!step_meet<PREC, GB>(a, e, gen0, seq0, creg, sh, [&] { tile_load<PREC, STEP_OPS2, STEP_OPS1>(a, tile_of(tt_last), cur); }))
+    if (!step_meet<PREC, GB>(a, e, gen0, seq0, creg, sh, [&] { tile_load<PREC, STEP_OPS2, STEP_OPS1>(a, tile_of(tt_last), cur, tp); }))
         return;                                            // an exchange timed out: reported by the status word; nothing is stored
     e.s_com = (mixed)s_scale[G]; e.s_drude = (mixed)s_scale[G + 1];
     TRACE(9);
@@ -1311,7 +1325,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
         tile_body<PREC, STEP_OPS2, GB>(a, e, cur, 0, held);  // the held tile: image and COM table of pass 1
         if (tt - grid < 0) break;
         tt -= grid;
-        tile_load<PREC, STEP_OPS2>(a, tile_of(tt), cur);
+        tile_load<PREC, STEP_OPS2>(a, tile_of(tt), cur, tp);
     }
     TRACE(15);
 }
