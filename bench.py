@@ -545,8 +545,9 @@ def main():
         # 2-, 4- or 8-GPU run (profiles/r03_scaling_ceiling.md), and since the wave tiles of identical molecules stopped reading
         # per-slot words also +3 % at 5 M slots (interleaved on one box: 3 866 / 3 869 / 3 875 against 3 745 / 3 740 / 3 727 for the
         # three-launch structure, tools/micro/variant_ab.sh).  A handle that cannot hold the step resident falls back by itself
-        # (`variant_ran`).
-        args.variant = "resident"
+        # (`variant_ran`).  Single precision at the metric size stays with three launches (6 331 against 5 671 steps/s on one box:
+        # its passes are short enough for the one-launch step's serial section to show).
+        args.variant = "defer" if args.precision == "single" and system.num_particles / world >= 3_000_000 else "resident"
 
     use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
     gsteps = args.graph_steps if use_graph else 0
@@ -637,7 +638,8 @@ def main():
     if mailbox_info:
         extra["mailbox"] = dict(extra.get("mailbox", {}), **mailbox_info)
     if world == 1 and not args.no_extra:
-        for prec, var in ((args.precision, "plain"), (args.precision, "plain-resident"), (args.precision, "defer"), (args.precision, "resident"), ("single", args.variant)):
+        for prec, var in ((args.precision, "plain"), (args.precision, "plain-resident"), (args.precision, "defer"), (args.precision, "resident"),
+                          ("single", "defer" if system.num_particles / world >= 3_000_000 else args.variant)):
             if (prec, var) == (args.precision, args.variant):
                 continue
             c2 = build_context(args, system, group, ngroups, rank, world, prec, var)
