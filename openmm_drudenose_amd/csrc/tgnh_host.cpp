@@ -1690,13 +1690,14 @@ extern "C" tgnh_status tgnh_get_topology_len(tgnh_handle h, int which, int* len)
 }
 extern "C" tgnh_status tgnh_get_topology(tgnh_handle h, int which, int32_t* out) {
     CHECK_H(h);
-    if (which == 8) { std::memcpy(out, h->meta.data(), sizeof(uint32_t) * h->meta.size()); return TGNH_OK; }
-    if (which == 9) { std::memcpy(out, h->wave_tile.data(), sizeof(int2) * h->wave_tile.size()); return TGNH_OK; }
-    if (which == 10) { std::memcpy(out, h->wmeta.data(), sizeof(uint32_t) * h->wmeta.size()); return TGNH_OK; }
-    if (which == 11) { std::memcpy(out, h->tile_pat.data(), sizeof(uint32_t) * h->tile_pat.size()); return TGNH_OK; }
-    if (which == 12) { std::memcpy(out, h->wtile_pat.data(), sizeof(uint32_t) * h->wtile_pat.size()); return TGNH_OK; }
-    if (which == 13) { std::memcpy(out, h->pattern.data(), sizeof(uint32_t) * h->pattern.size()); return TGNH_OK; }
-    if (which == 14) { std::memcpy(out, h->wpattern.data(), sizeof(uint32_t) * h->wpattern.size()); return TGNH_OK; }
+    auto put = [&](const void* src, size_t bytes) { if (bytes) std::memcpy(out, src, bytes); return TGNH_OK; };     // (an empty array has no data())
+    if (which == 8) return put(h->meta.data(), sizeof(uint32_t) * h->meta.size());
+    if (which == 9) return put(h->wave_tile.data(), sizeof(int2) * h->wave_tile.size());
+    if (which == 10) return put(h->wmeta.data(), sizeof(uint32_t) * h->wmeta.size());
+    if (which == 11) return put(h->tile_pat.data(), sizeof(uint32_t) * h->tile_pat.size());
+    if (which == 12) return put(h->wtile_pat.data(), sizeof(uint32_t) * h->wtile_pat.size());
+    if (which == 13) return put(h->pattern.data(), sizeof(uint32_t) * h->pattern.size());
+    if (which == 14) return put(h->wpattern.data(), sizeof(uint32_t) * h->wpattern.size());
     const std::vector<int>* v = topo_vec(h, which);
     if (!v) return fail(TGNH_ERR_ARG, "bad topology array id");
     std::copy(v->begin(), v->end(), out);

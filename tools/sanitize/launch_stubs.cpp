@@ -5,10 +5,14 @@
 
 namespace tgnh {
 hipError_t launch_tile(int, int, int, const TileArgs&, int, size_t, hipStream_t) { return hipErrorNoDevice; }
-int tile_blocks_per_cu(int, int, int, size_t) { return 2; }
+int tile_blocks_per_cu(int, int, int, size_t, bool) { return 2; }
 hipError_t launch_step(int, int, int, const TileArgs&, int, size_t, hipStream_t) { return hipErrorNoDevice; }
 int step_blocks_per_cu(int, int, int, size_t) { return 2; }
 int step_kind_ops2(int) { return 0; }
+hipError_t launch_wstep(int, int, bool, const TileArgs&, int, hipStream_t) { return hipErrorNoDevice; }
+int wstep_blocks_per_cu(int, int, bool) { return 2; }
+hipError_t launch_wke(int, int, int, const TileArgs&, int, hipStream_t) { return hipErrorNoDevice; }
+int wke_blocks_per_cu(int, int, int) { return 5; }
 hipError_t launch_chain(const ChainArgs&, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_big_com(int, const BigComArgs&, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_force(int, const ForceArgs&, hipStream_t) { return hipErrorNoDevice; }
