@@ -1171,6 +1171,16 @@ def test_packed_sites_give_the_same_forces(sysname, precision):
     ctx.unpacked_sites = True
     ctx.compute_forces()
     assert ctx.torch.equal(packed, ctx.force) and int(packed.abs().max()) > 0
+    # other sites: packed again, the forces follow (and differ from the first set's)
+    ctx.unpacked_sites = False
+    ctx.set_sites(s.positions + rng.normal(0, 0.02, s.positions.shape))
+    ctx.compute_forces()
+    repacked = ctx.force.clone()
+    ctx.unpacked_sites = True
+    ctx.compute_forces()
+    assert ctx.torch.equal(repacked, ctx.force)
+    if (s.mass > 0).sum() > len(s.pair_drude):               # (some slot is tethered)
+        assert not ctx.torch.equal(repacked, packed)
     meta = ctx.topology(8).view(np.uint32)
     off = ((meta >> 10) & 2047).astype(np.int64) - 1024
     print(sysname, precision, "partners more than 15 slots away:", int(np.sum((np.abs(off) > 15) & ((meta & 3) != 0))))
