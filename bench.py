@@ -8,7 +8,8 @@ state resident in HBM.  The force call-out (OpenMM's calcForcesAndEnergy in a re
 the harness spring kernel and is INSIDE the timed region.  N > 1 shards whole molecules over the
 ranks (strong scaling: the 1 M-pair system is fixed) with one all-reduce of the per-thermostat
 kinetic-energy sums per thermostat half step.  The headline value of a sharded run uses RCCL
-(torch.distributed all_reduce on the library's device buffer, captured into the step's hipGraph), as
+(the library's own ncclAllReduce on its device buffer, captured into the step's hipGraph; torch.distributed's
+all_reduce through the hook where that cannot be had), as
 BASELINE.json's north_star names it; the library's mailbox exchange (stores into every peer's mailbox
 over xGMI, waited for inside the rescale launch) is measured right after it and reported beside it as
 `extra.mailbox`, together with its validation verdict against the RCCL run.
@@ -52,7 +53,7 @@ def parse():
                         "defer with the whole step in ONE launch whose work-groups meet on the device (step_kernel; with the "
                         "RCCL hook it steps the defer way); plain = the reference's pass structure (what the OpenMM glue "
                         "runs); plain-resident = that structure with each thermostat half one step_kernel launch; "
-                        "auto = resident below 3 M slots per GPU, else defer (DESIGN.md)")
+                        "auto = resident (single precision from 3 M slots per GPU: defer) (DESIGN.md)")
     p.add_argument("--chains", type=int, default=1)
     p.add_argument("--drude-steps", type=int, default=20, help="drudeStepsPerRealStep (reference default 20)")
     p.add_argument("--hardwall", type=float, default=0.02, help="maxDrudeDistance nm (example/nacl_tg.py:22); 0 = off")
