@@ -77,6 +77,22 @@ enum { TGNH_FLAG_RESIDENT_STEP = 4 };  /* whole thermostat halves in ONE launch 
                                         * With a mailbox exchange attached and DEFER_SCALE, state queries between steps are
                                         * collective over the ranks. */
 
+enum { TGNH_FLAG_TRUST_STATE_CHANGED = 16 };  /* The reference's pass structure (velocities never lag, no TGNH_FLAG_DEFER_SCALE)
+                                        * without the first half step's kinetic-energy pass: after the end half's rescale every bin
+                                        * is exactly s^2 times the bin its chain started from, and the chain has tracked that product
+                                        * (CudaDrudeTGNHKernels.cpp:574), so the next tgnh_step_begin / _begin_kick starts its chain
+                                        * from it -- one launch instead of KE + chain + rescale.  The caller vouches that NOTHING
+                                        * writes velm between tgnh_step_end / _end_thermo and the next begin without
+                                        * tgnh_state_changed (DrudeTGNHIntegrator.cpp:166-170): setVelocities does call it, OpenMM's
+                                        * CMMotionRemover and AndersenThermostat edit velocities in updateContextState without -- the
+                                        * glue sets the flag only for a System that holds neither.  Invalidated (the next half
+                                        * recomputes) by tgnh_state_changed, tgnh_bind_buffers, tgnh_set_thermostat_state,
+                                        * tgnh_set_global_dof_terms, the split entry points that write velocities, attaching an
+                                        * exchange; ignored when sharded (hook, RCCL, mailboxes), with DEFER_SCALE, and for a topology
+                                        * in which a molecule spans two temperature groups (tgnh_get_pending_state bit 9 shows
+                                        * whether the next half will carry over).  A hipGraph of steps recorded while carrying over
+                                        * holds no KE pass: replay it only while the promise holds. */
+
 typedef struct tgnh_desc {
     uint32_t struct_size;         /* sizeof(tgnh_desc), ABI check */
     int32_t mode;                 /* TGNH_MODE_* */
@@ -227,7 +243,8 @@ tgnh_status tgnh_note_replayed_steps(tgnh_handle h, int nsteps);
  * bit 0 the end half of the last step waits for the next tgnh_step_begin (RESIDENT_STEP), 1 velm lags by the scale factors,
  * 2 velm lags by the second half kick, 3 the next step's first thermostat half has already run (DEFER_SCALE), 4 the summed
  * kinetic energies wait for the next rescale launch to run the chain, 5 the partial rows are not summed yet, 6 an exchange is
- * sent but not yet waited for, 7 the advanced thermostat block sits in the staging copy, 8 direction of the next sweep. */
+ * sent but not yet waited for, 7 the advanced thermostat block sits in the staging copy, 8 direction of the next sweep,
+ * 9 the next thermostat half step starts from the kinetic energies the last one left (TGNH_FLAG_TRUST_STATE_CHANGED). */
 tgnh_status tgnh_get_pending_state(tgnh_handle h, uint32_t* bits);
 /* Restore the clock of a checkpointed run (time, stepCount: ReferenceDrudeTGNHKernels.cpp:413-414, CudaDrudeTGNHKernels.cpp:405-406). */
 tgnh_status tgnh_set_time(tgnh_handle h, double time, int64_t step_count);
@@ -271,6 +288,13 @@ tgnh_status tgnh_set_thermostat_state(tgnh_handle h, int which, void* stream, co
  * reading them (0: they read them), 13 / 14 the patterns of the two, 64 words each. */
 tgnh_status tgnh_get_topology_len(tgnh_handle h, int which, int* len);
 tgnh_status tgnh_get_topology(tgnh_handle h, int which, int32_t* out);
+/* The sizes the launches of this handle are bound by, against the sizes of what the library allocated for them (inspection;
+ * also answered by a host-only handle, for the largest grid any device could give it).  The library checks the same figures
+ * before every launch (TGNH_ERR_STATE "internal: ..." instead of a launch that would run off a buffer).  out[8]:
+ *   0 512-slot tiles, 1 wave tiles, 2 entries of the wave-tile table (wave tiles + 1; 0: none), 3 the largest grid a streaming
+ *   launch of this handle takes, 4 partial rows allocated for such launches, 5 words allocated for tagged rows (0: none),
+ *   6 words a launch of grid [3] with this handle's thermostats may write there (0: it never does), 7 thermostats NT. */
+tgnh_status tgnh_get_launch_bounds(tgnh_handle h, int32_t out[8]);
 
 /* Pieces of the step, exposed for parity tests of the single kernels. */
 tgnh_status tgnh_compute_kinetic_energies(tgnh_handle h, void* stream);          /* A3/A4 only -> last_kinetic_energies */

@@ -9,7 +9,7 @@ TGNH_OK = 0
 ERR_ARG, ERR_GROUP_MISMATCH, ERR_HARDWALL, ERR_UNSUPPORTED, ERR_HIP, ERR_STATE = -1, -2, -3, -4, -5, -6
 MODE_DUALNH, MODE_TGNH = 0, 1
 PREC_SINGLE, PREC_MIXED, PREC_DOUBLE = 0, 1, 2
-FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES = 2, 4, 8
+FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES, FLAG_TRUST_STATE_CHANGED = 2, 4, 8, 16
 KID_SKD, KID_KICK_KE, KID_SCALE, KID_KE, KID_CHAIN, KID_FORCE, KID_OTHER, KID_STEP = range(8)
 KERNEL_NAMES = {KID_SKD: "scale+kick+drift", KID_KICK_KE: "kick+KE", KID_SCALE: "rescale", KID_KE: "KE",
                 KID_CHAIN: "chain", KID_FORCE: "harness force", KID_OTHER: "other", KID_STEP: "resident step"}
@@ -83,6 +83,7 @@ SIGNATURES = {
     "tgnh_set_thermostat_state": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, c_f64p]),
     "tgnh_get_topology_len": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "tgnh_get_topology": (C.c_int, [C.c_void_p, C.c_int, c_i32p]),
+    "tgnh_get_launch_bounds": (C.c_int, [C.c_void_p, c_i32p]),
     "tgnh_compute_kinetic_energies": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_half_kick": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_harness_force": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),

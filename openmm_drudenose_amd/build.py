@@ -39,15 +39,42 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _object_key(src, flags):
+    """what an object file depends on: its source, every header of csrc/ and the ABI header, the compiler line"""
+    import hashlib
+    h = hashlib.sha1(" ".join(flags).encode())
+    for path in [os.path.join(CSRC, src)] + [os.path.join(CSRC, x) for x in HEADERS]:
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
-    """Compile the library if it is missing or older than its sources."""
+    """Compile the library if it is missing or older than its sources: one hipcc per source file, side by side, objects kept
+    under build/ by content hash (an edit of the host code does not recompile the kernels), then one link."""
     if not force and not _stale():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-x", "hip"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-ldl", "-o", LIB]       # (RCCL is bound with dlopen at the first tgnh_rccl_* call: tgnh_host.cpp)
+    flags = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-x", "hip"]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, f"{os.path.splitext(src)[0]}.{_object_key(src, flags)}.o")
+        if force or not os.path.exists(obj):
+            cmd = flags + ["-c", os.path.join(CSRC, src), "-o", obj + ".tmp"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+            os.replace(obj + ".tmp", obj)
+        return obj
+
+    with ThreadPoolExecutor(len(SOURCES)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    for name in os.listdir(objdir):                      # objects of earlier source states
+        if name.endswith(".o") and os.path.join(objdir, name) not in objs:
+            os.remove(os.path.join(objdir, name))
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB]   # (RCCL is bound with dlopen at the first tgnh_rccl_* call: tgnh_host.cpp)
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -562,11 +562,16 @@ __device__ __forceinline__ void chain_sum_rows(const ChainArgs& a, const int lan
     *mine = m; *kesum = s;
 }
 
+// Where a chain that sums nothing itself finds its kinetic energies: the summed (and all-reduced) bins, or -- carried over,
+// TGNH_FLAG_TRUST_STATE_CHANGED -- what the last chain left as KE * prod exp(-dtc etaDot) (Cu :574): every bin of the velocities
+// its rescale produced is exactly s^2 times the bin before, so no pass over the velocities is needed to know them.
+__device__ __forceinline__ int chain_ke_src(const ChainArgs& a) { return a.ke_carry ? a.L.off_ke_post : a.L.off_ke_red; }
+
 __device__ __forceinline__ Chain1Regs chain1_load(const ChainArgs& a, const double* st_in, const int itg) {
     const ChainLayout& L = a.L;
     const Chain1Map m = chain1_map(L, itg);
     Chain1Regs r{};
-    r.ke = st_in[L.off_ke_red + itg];
+    r.ke = st_in[chain_ke_src(a) + itg];
     if (!m.used) { r.etaMass = 1.0; return r; }
     r.eta = st_in[L.off_eta + m.eta];
     r.etaDot0 = st_in[L.off_etaDot + m.ed0];

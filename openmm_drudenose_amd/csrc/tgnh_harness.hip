@@ -338,6 +338,7 @@ extern "C" tgnh_status tgnh_harness_shake_positions(tgnh_handle h, double tol, v
 
 extern "C" tgnh_status tgnh_harness_shake_velocities(tgnh_handle h, double tol, void* stream) {
     tgnh_status rc = harness_ready(h); if (rc) return rc;
+    h->ke_carry = false;                 // velocities are about to change behind the integrator (TRUST_STATE_CHANGED: recompute)
     if (h->num_clusters == 0) return TGNH_OK;
     H_HIP(hipSetDevice(h->device));
     H_HIP(launch_shake<true>(h->d.precision, cluster_args(h, tol), (hipStream_t)stream));
@@ -414,6 +415,7 @@ extern "C" tgnh_status tgnh_harness_water_force(tgnh_handle h, double box, doubl
 
 extern "C" tgnh_status tgnh_harness_remove_cm_motion(tgnh_handle h, void* stream) {
     tgnh_status rc = harness_ready(h); if (rc) return rc;
+    h->ke_carry = false;                 // (OpenMM's CMMotionRemover does not tell the integrator: the glue does not set TRUST_STATE_CHANGED beside one)
     H_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     switch (h->d.precision) {

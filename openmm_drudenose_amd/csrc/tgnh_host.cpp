@@ -442,7 +442,7 @@ static tgnh_status finalize_thermostat(tgnh_context* c) {
         HIP_OK(hipMemcpy(c->d_state, st.data(), sizeof(double) * L.total, hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(c->d_stage, st.data(), sizeof(double) * L.total, hipMemcpyHostToDevice));
     }
-    c->chain_pending = false; c->stage_pending = false;
+    c->chain_pending = false; c->stage_pending = false; c->carry_pending = false; c->ke_carry = false;
     c->scale_pending = false; c->kick_pending = false; c->first_half_done = false; c->end_pending = false;
     return TGNH_OK;
 }
@@ -590,17 +590,24 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
 #ifdef TGNH_TUNING
     if (const char* e = getenv("TGNH_WAVE_KE")) c->wave_ke = c->wave_ke && e[0] != '0';
 #endif
-    if ((d->flags & TGNH_FLAG_DEFER_SCALE) && d->mode == TGNH_MODE_TGNH && d->use_com_temp_group) {
-        // s^2 KE is the exact post-rescale KE only if no molecule spans two temperature groups
-        for (int r = 0; r < d->num_residues; r++) {
-            int g0 = -1;
-            for (int j = 0; j < c->res_count[r]; j++) {
-                const int i = c->res_first[r] + j;
-                if (c->mass[i] == 0.0) continue;
-                if (g0 == -1) g0 = c->group[i];
-                else if (g0 != c->group[i]) { free_device(c); delete c; return fail(TGNH_ERR_UNSUPPORTED, "DEFER_SCALE needs every molecule inside one temperature group"); }
+    {   // s^2 KE is the exact post-rescale KE only if no molecule spans two temperature groups: v_rel = v - v_com of such a
+        // molecule is scaled by two different factors, which moves its centre of mass (K :260-300)
+        bool inside = true;
+        if (d->mode == TGNH_MODE_TGNH && d->use_com_temp_group) {
+            for (int r = 0; r < d->num_residues && inside; r++) {
+                int g0 = -1;
+                for (int j = 0; j < c->res_count[r]; j++) {
+                    const int i = c->res_first[r] + j;
+                    if (c->mass[i] == 0.0) continue;
+                    if (g0 == -1) g0 = c->group[i];
+                    else if (g0 != c->group[i]) { inside = false; break; }
+                }
             }
         }
+        if ((d->flags & TGNH_FLAG_DEFER_SCALE) && !inside) { free_device(c); delete c; return fail(TGNH_ERR_UNSUPPORTED, "DEFER_SCALE needs every molecule inside one temperature group"); }
+        // TRUST_STATE_CHANGED (the reference's pass structure without the begin half's KE pass) asks the same of the topology;
+        // where it does not hold the flag is ignored -- the handle recomputes, as without it (tgnh_get_pending_state bit 9 never shows)
+        c->carry_ok = (d->flags & TGNH_FLAG_TRUST_STATE_CHANGED) && !(d->flags & TGNH_FLAG_DEFER_SCALE) && inside;
     }
     local_dof_terms(c);
     c->global_terms = c->local_terms;
@@ -745,6 +752,29 @@ extern "C" tgnh_status tgnh_bind_buffers(tgnh_handle h, void* posq, void* posq_c
     if (h->d.precision == TGNH_PREC_MIXED && !posq_correction) return fail(TGNH_ERR_ARG, "mixed precision needs posqCorrection");
     if ((h->kick_pending || h->end_pending) && (velm != h->velm || force != h->force))
         return fail(TGNH_ERR_STATE, "tgnh_bind_buffers: velm / force may not be rebound while a deferred half kick is pending (tgnh_flush first)");
+    if (posq == h->posq && posq_correction == h->posq_corr && velm == h->velm && force == h->force && pos_delta == h->pos_delta)
+        return TGNH_OK;                                   // (the glue binds at every step: the same arrays, nothing to do)
+    {   // Every kernel indexes these arrays by slot without a bound of its own: an allocation shorter than N slots (or 3 planes
+        // of `padded`) would be a write off its end on the device.  Where the runtime knows the allocation a pointer lies in,
+        // what is left of it behind the pointer must cover what the launches touch (a sub-allocation of a caching allocator
+        // passes with its block's size: a lower bound, but the gross cases -- a float4 array bound as double4, N for padded --
+        // are caught here, on the host, with a message).
+        HIP_OK(hipSetDevice(h->device));
+        const size_t N = (size_t)h->d.num_particles, P = (size_t)h->d.padded_num_particles;
+        const size_t r4 = h->d.precision == TGNH_PREC_DOUBLE ? 32 : 16, m4 = h->d.precision == TGNH_PREC_SINGLE ? 16 : 32;
+        struct { const void* p; size_t need; const char* name; } bufs[] = {
+            {posq, N * r4, "posq"}, {posq_correction, N * 16, "posqCorrection"}, {velm, N * m4, "velm"},
+            {force, 3 * P * sizeof(long long), "force"}, {pos_delta, N * m4, "posDelta"}};
+        for (const auto& b : bufs) {
+            if (!b.p) continue;
+            hipDeviceptr_t base = nullptr; size_t size = 0;
+            if (hipMemGetAddressRange(&base, &size, const_cast<void*>(b.p)) != hipSuccess) { (void)hipGetLastError(); continue; }   // not known to the runtime (mapped by other means): the caller's word is taken
+            const size_t left = size - (size_t)(static_cast<const char*>(b.p) - static_cast<const char*>(base));
+            if (left < b.need)
+                return fail(TGNH_ERR_ARG, std::string("tgnh_bind_buffers: ") + b.name + " has " + std::to_string(left) + " bytes behind the pointer, the launches touch " + std::to_string(b.need));
+        }
+    }
+    h->ke_carry = false;                                  // (other buffers: nothing computed from the old ones carries over)
     h->posq = posq; h->posq_corr = posq_correction; h->velm = velm; h->force = force; h->pos_delta = pos_delta;
     return TGNH_OK;
 }
@@ -842,6 +872,7 @@ extern "C" tgnh_status tgnh_exchange_attach(tgnh_handle h, const void* ipc_handl
     if (!h->x_mailbox) return fail(TGNH_ERR_STATE, "tgnh_exchange_create first");
     if (!ipc_handles) return fail(TGNH_ERR_ARG, "null handles");
     tgnh_status rc = deferred_guard(h, "tgnh_exchange_attach"); if (rc) return rc;
+    h->ke_carry = false;
     HIP_OK(hipSetDevice(h->device));
     std::vector<unsigned long long*> peers(h->x_world, nullptr);
     for (int r = 0; r < h->x_world; r++) {
@@ -861,6 +892,7 @@ extern "C" tgnh_status tgnh_exchange_attach_pointers(tgnh_handle h, void* const*
     if (!h->x_mailbox) return fail(TGNH_ERR_STATE, "tgnh_exchange_create first");
     if (!mailboxes) return fail(TGNH_ERR_ARG, "null mailboxes");
     tgnh_status rc = deferred_guard(h, "tgnh_exchange_attach_pointers"); if (rc) return rc;
+    h->ke_carry = false;
     HIP_OK(hipSetDevice(h->device));
     std::vector<unsigned long long*> peers(h->x_world, nullptr);
     for (int r = 0; r < h->x_world; r++) {
@@ -897,6 +929,7 @@ extern "C" tgnh_status tgnh_exchange_detach(tgnh_handle h) {
 extern "C" tgnh_status tgnh_set_allreduce(tgnh_handle h, tgnh_allreduce_fn fn, void* user) {
     CHECK_H(h);
     tgnh_status rc = deferred_guard(h, "tgnh_set_allreduce"); if (rc) return rc;
+    h->ke_carry = false;
     if (h->rccl_comm) { rc = tgnh_rccl_shutdown(h); if (rc) return rc; }
     h->allreduce = fn; h->allreduce_user = user;
     return TGNH_OK;
@@ -963,6 +996,7 @@ extern "C" tgnh_status tgnh_set_rccl_comm(tgnh_handle h, void* nccl_comm) {
     CHECK_H(h);
     if (h->host_only) return fail(TGNH_ERR_STATE, "host-only handle");
     tgnh_status rc = deferred_guard(h, "tgnh_set_rccl_comm"); if (rc) return rc;
+    h->ke_carry = false;
     if (!rccl().ok) return fail(TGNH_ERR_HIP, rccl().error);
     if (h->rccl_comm) { rc = tgnh_rccl_shutdown(h); if (rc) return rc; }
     if (!nccl_comm) { h->allreduce = nullptr; h->allreduce_user = nullptr; return TGNH_OK; }
@@ -976,6 +1010,7 @@ extern "C" tgnh_status tgnh_rccl_init(tgnh_handle h, int world, int rank, const 
     if (h->host_only) return fail(TGNH_ERR_STATE, "host-only handle");
     if (world < 1 || rank < 0 || rank >= world || !id) return fail(TGNH_ERR_ARG, "bad world / rank / id");
     tgnh_status rc = deferred_guard(h, "tgnh_rccl_init"); if (rc) return rc;
+    h->ke_carry = false;
     if (!rccl().ok) return fail(TGNH_ERR_HIP, rccl().error);
     if (h->rccl_comm) { rc = tgnh_rccl_shutdown(h); if (rc) return rc; }
     HIP_OK(hipSetDevice(h->device));
@@ -1140,6 +1175,47 @@ static int wave_grid_for(tgnh_handle h, int ops) {
 static ChainArgs chain_args(tgnh_handle h);
 static tgnh_status commit_stage(tgnh_handle h, hipStream_t s);
 
+// words of the tagged-row area (TileArgs::rows) and what a launch of `grid` work-groups with NT thermostats writes there
+// (row_word in tgnh_kernels.hip: rows in blocks of 64, word-major inside a block, two words per thermostat)
+static size_t tagged_words_allocated() { return (size_t)2 * GRID_CAP * CHAIN_INLINE_SUM_NT; }
+static size_t tagged_words_touched(int grid, int NT) {
+    if (grid < 1) return 0;
+    const int r = grid - 1, j = 2 * NT - 1;
+    return ((size_t)(r >> 6) * (2 * CHAIN_INLINE_SUM_NT) + j) * 64 + (r & 63) + 1;
+}
+
+// The sizes a streaming launch is bound by, checked on the host before it goes out: one row of partial sums per work-group
+// in a table of GRID_CAP rows; tagged rows only with G <= 8; a wave-tile table of num_wtiles + 1 entries in which every tile
+// holds <= 64 slots (tgnh_create built them so: this is the launch-side half of that contract).
+static tgnh_status check_launch(tgnh_handle h, const TileArgs& a, int grid, int block, bool wave, bool tagged) {
+    if (grid < 1 || grid > GRID_CAP || grid > h->grid) return fail(TGNH_ERR_STATE, "internal: grid exceeds the partial-row table");
+    if (wave) {
+        if (!a.wave_tile || (int)h->wave_tile.size() != a.num_wtiles + 1 || a.num_wtiles < 1)
+            return fail(TGNH_ERR_STATE, "internal: wave-tile table does not match the launch");
+        if ((long long)grid * (block / 64) > (long long)a.num_wtiles + (block / 64) - 1)
+            return fail(TGNH_ERR_STATE, "internal: more work-groups than wave tiles");
+    } else if (grid > h->num_tiles) return fail(TGNH_ERR_STATE, "internal: more work-groups than tiles");
+    if (tagged) {
+        if (!a.rows || !a.sync || h->L.NT > CHAIN_INLINE_SUM_NT || tagged_words_touched(grid, h->L.NT) > tagged_words_allocated())
+            return fail(TGNH_ERR_STATE, "internal: tagged rows do not fit their area");
+    }
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_get_launch_bounds(tgnh_handle h, int32_t out[8]) {
+    CHECK_H(h);
+    if (!out) return fail(TGNH_ERR_ARG, "null out");
+    const int nw = h->num_wtiles;
+    int g = h->num_tiles;                                                    // tile_kernel / step_kernel: at most one work-group per tile
+    if (nw > 0) g = std::max(g, (nw + TBLOCK / 64 - 1) / (TBLOCK / 64));     // wke_kernel: per four wave tiles (wstep_kernel: per eight)
+    g = std::max(1, std::min(g, GRID_CAP));
+    const bool tagged = h->L.NT <= CHAIN_INLINE_SUM_NT && (h->d_rows != nullptr || h->host_only);
+    out[0] = h->num_tiles; out[1] = nw; out[2] = (int)h->wave_tile.size(); out[3] = g;
+    out[4] = h->grid; out[5] = tagged ? (int)tagged_words_allocated() : 0;
+    out[6] = tagged ? (int)tagged_words_touched(g, h->L.NT) : 0; out[7] = h->L.NT;
+    return TGNH_OK;
+}
+
 static tgnh_status run_big_com(tgnh_handle h, bool kick, hipStream_t s) {
     BigComArgs b{};
     b.table = h->d_big_table; b.n = h->num_big; b.velm = h->velm;
@@ -1155,15 +1231,21 @@ static tgnh_status run_big_com(tgnh_handle h, bool kick, hipStream_t s) {
 static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, const double* scale = nullptr) {
     TileArgs a = tile_args(h, scale);
     bool inline_chain = false;
+    bool pingpong = false;
     if ((ops & OP_SCALE) && h->chain_pending && !scale) {           // this rescale launch runs the chain itself
-        if (h->stage_pending) { tgnh_status rc = commit_stage(h, s); if (rc) return rc; }
+        // A carried chain (no KE pass before it: nothing has committed the staged block on the way) reads the thermostat where the
+        // last in-kernel chain left it and writes the other copy: the two blocks differ only in what a chain writes, and a
+        // chain writes all of that every time (eta, etaDot, etaDotDot, KE before / after, the scale factors, KESum)
+        pingpong = h->carry_pending && h->stage_pending;
+        if (h->stage_pending && !pingpong) { tgnh_status rc = commit_stage(h, s); if (rc) return rc; }
         a.chain_on = 1;
-        a.chain = chain_args(h);
+        a.chain = chain_args(h);                                    // (takes note of the staged block: cleared there)
         a.chain.chain_twice = h->chain_pending_twice ? 1 : 0;
+        a.chain.ke_carry = h->carry_pending ? 1 : 0;
         a.sum_rows = h->sum_pending ? (h->ke_parts + h->num_big <= h->inline_sum_rows ? 1 : 2) : 0;
         a.x_wait = h->xwait_pending ? 1 : 0;
-        a.st_in = h->d_state;
-        a.st_out = h->d_stage;
+        a.st_in = pingpong ? h->d_stage : h->d_state;
+        a.st_out = pingpong ? h->d_state : h->d_stage;
         inline_chain = true;
     }
     if ((ops & (OP_POSDELTA | OP_MOVE)) && !h->pos_delta) return fail(TGNH_ERR_STATE, "posDelta buffer not bound");
@@ -1191,12 +1273,15 @@ static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, cons
             tgnh_status rc = run_big_com(h, (ops & OP_KICK) != 0, s); if (rc) return rc;
         }
     }
+    { tgnh_status rc = check_launch(h, a, grid, TBLOCK, wave, a.tail_sum != 0); if (rc) return rc; }
     {
         Timed t(h, s, kid);
         if (wave) HIP_OK(launch_wke(h->d.precision, ops, h->gb, a, grid, s));
         else HIP_OK(launch_tile(h->d.precision, ops, h->gb, a, grid, lds, s));
     }
-    if (inline_chain) { h->chain_pending = false; h->sum_pending = false; h->xwait_pending = false; h->stage_pending = true; }   // d_stage now holds the advanced thermostat
+    if (inline_chain) {            // the advanced thermostat now lies in d_stage (carried from a staged block: back in d_state)
+        h->chain_pending = false; h->sum_pending = false; h->xwait_pending = false; h->carry_pending = false; h->stage_pending = !pingpong;
+    }
     if (h->alternate_sweeps) h->sweep_reverse ^= 1;      // the next streaming launch starts where this one ends
     return TGNH_OK;
 }
@@ -1290,8 +1375,9 @@ static tgnh_status materialize_chain(tgnh_handle h, hipStream_t s) {
     ChainArgs a = chain_args(h);
     a.do_sum = h->sum_pending ? 1 : 0; a.do_chain = 1; a.chain_twice = h->chain_pending_twice ? 1 : 0;
     a.x_wait = h->xwait_pending ? 1 : 0;
+    a.ke_carry = h->carry_pending ? 1 : 0;
     { Timed t(h, s, KID_CHAIN); HIP_OK(launch_chain(a, s)); }
-    h->chain_pending = false; h->sum_pending = false; h->xwait_pending = false;
+    h->chain_pending = false; h->sum_pending = false; h->xwait_pending = false; h->carry_pending = false;
     return TGNH_OK;
 }
 
@@ -1340,10 +1426,12 @@ static tgnh_status run_resident(tgnh_handle h, hipStream_t s, int kind) {
         }
         a.chain.nparts = h->wresident_grid;
         h->ke_parts = h->wresident_grid;
+        { tgnh_status rc = check_launch(h, a, h->wresident_grid, WBLOCK, true, true); if (rc) return rc; }
         Timed t(h, s, KID_STEP);
         HIP_OK(launch_wstep(h->d.precision, h->gb, h->L.C > 1, a, h->wresident_grid, s));
     } else {
         h->ke_parts = grid;
+        { tgnh_status rc = check_launch(h, a, grid, TBLOCK, false, true); if (rc) return rc; }
         Timed t(h, s, KID_STEP);
         HIP_OK(launch_step(h->d.precision, h->gb, kind, a, grid, lds, s));
     }
@@ -1356,6 +1444,26 @@ static tgnh_status run_resident(tgnh_handle h, hipStream_t s, int kind) {
 // make scale[] hold the first thermostat half step for the current velocities (Ref :231, Cu :336)
 static tgnh_status first_half(tgnh_handle h, hipStream_t s) {
     if (h->first_half_done) return TGNH_OK;               // DEFER_SCALE: already folded into scale[]
+    if (h->ke_carry) {
+        // TRUST_STATE_CHANGED, and nothing has written velocities since the last end half's rescale: every kinetic-energy bin
+        // of the stored velocities is s^2 times the bin that chain started from -- the ke_post it left (Cu :574 tracks exactly
+        // that product) -- so this half's KE pass (Cu :474-488) and its row sum are not run: the chain starts from ke_post
+        h->ke_carry = false;
+        if (h->num_big && h->d.mode == TGNH_MODE_TGNH && h->d.use_com_temp_group) {
+            // (molecules longer than a tile: the KE pass that is not run would have left their centre-of-mass velocities in
+            // the table the rescale launch reads -- the end half's rescale has changed them since)
+            tgnh_status rc = run_big_com(h, false, s); if (rc) return rc;
+        }
+        if (h->inline_chain) {                            // ... inside the rescale launch that follows: this half step is ONE launch
+            h->chain_pending = true; h->chain_pending_twice = false; h->sum_pending = false; h->carry_pending = true;
+            return TGNH_OK;
+        }
+        ChainArgs a = chain_args(h);
+        a.do_sum = 0; a.do_chain = 1; a.ke_carry = 1;
+        Timed t(h, s, KID_CHAIN);
+        HIP_OK(launch_chain(a, s));
+        return TGNH_OK;
+    }
     tgnh_status rc = run_tile(h, OP_KE, KID_KE, s); if (rc) return rc;
     return run_chain(h, s, false);
 }
@@ -1402,9 +1510,9 @@ extern "C" tgnh_status tgnh_step_begin(tgnh_handle h, void* stream) {
         if (resident_now(h)) return run_resident(h, s, 0);           // the last step's end half and this begin half: one launch
         rc = settle_end(h, s); if (rc) return rc;
     }
-    if (!(h->d.flags & TGNH_FLAG_DEFER_SCALE) && resident_now(h))
+    if (!(h->d.flags & TGNH_FLAG_DEFER_SCALE) && resident_now(h) && !h->ke_carry)
         return run_resident(h, s, 1);                                // reference pass structure: KE, chain, rescale+kick+drift in one launch
-    rc = first_half(h, s); if (rc) return rc;
+    rc = first_half(h, s); if (rc) return rc;                       // (kinetic energies carried over: no first pass, no meeting -- the tile launch with its in-kernel chain)
     // Cu :351-376 fused; with a half kick still pending from the last step_end (DEFER_SCALE) that kick comes first
     rc = run_tile(h, (h->kick_pending ? OP_PREKICK : 0) | OP_SCALE | OP_KICK | OP_DRIFT, KID_SKD, s); if (rc) return rc;
     h->scale_pending = false; h->kick_pending = false; h->first_half_done = false;
@@ -1414,10 +1522,12 @@ extern "C" tgnh_status tgnh_step_begin(tgnh_handle h, void* stream) {
 static tgnh_status second_half(tgnh_handle h, hipStream_t s, int kick_ops) {
     tgnh_status rc;
     const bool defer = (h->d.flags & TGNH_FLAG_DEFER_SCALE) != 0;
+    h->ke_carry = false;                                   // (an end half without a begin half before it: its own KE pass runs in any case)
     if (h->scale_pending || h->kick_pending || h->end_pending) { rc = flush_impl(h, s); if (rc) return rc; }   // two end halves in a row
     if (!defer && resident_now(h)) {
         // reference pass structure: kick, KE, chain, rescale (Cu :384-402) in one launch; velocities are final when it ends
         rc = run_resident(h, s, kick_ops ? 2 : 4); if (rc) return rc;
+        h->ke_carry = h->carry_ok && !h->allreduce && !h->xchg_on;
         h->time += h->d.step_size;
         h->step_count += 1;
         return poll_status_async(h, s);
@@ -1440,6 +1550,9 @@ static tgnh_status second_half(tgnh_handle h, hipStream_t s, int kick_ops) {
     } else {
         rc = run_chain(h, s, false); if (rc) return rc;                            // Cu :394-395
         rc = run_tile(h, OP_SCALE, KID_SCALE, s); if (rc) return rc;               // Cu :402
+        // the velocities now stored have the bins ke_post; they stay that until somebody writes velocities (unsharded only: a
+        // rank that recomputes while its peers carry over would enter a collective alone)
+        h->ke_carry = h->carry_ok && !h->allreduce && !h->xchg_on;
     }
     h->time += h->d.step_size;                                                     // Cu :405-406 ; Ref :413-414
     h->step_count += 1;
@@ -1472,7 +1585,7 @@ extern "C" tgnh_status tgnh_step_begin_kick(tgnh_handle h, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     rc = settle_kick(h, s); if (rc) return rc;
     start_of_step(h);
-    if (!(h->d.flags & TGNH_FLAG_DEFER_SCALE) && resident_now(h)) return run_resident(h, s, 3);
+    if (!(h->d.flags & TGNH_FLAG_DEFER_SCALE) && resident_now(h) && !h->ke_carry) return run_resident(h, s, 3);
     rc = first_half(h, s); if (rc) return rc;
     rc = run_tile(h, OP_SCALE | OP_KICK | OP_POSDELTA, KID_OTHER, s); if (rc) return rc;   // Cu :351-360
     h->scale_pending = false; h->first_half_done = false;
@@ -1480,11 +1593,13 @@ extern "C" tgnh_status tgnh_step_begin_kick(tgnh_handle h, void* stream) {
 }
 extern "C" tgnh_status tgnh_step_begin_move(tgnh_handle h, void* stream) {
     tgnh_status rc = entry(h, true); if (rc) return rc;
+    h->ke_carry = false;
     rc = settle_kick(h, (hipStream_t)stream); if (rc) return rc;
     return run_tile(h, OP_MOVE, KID_OTHER, (hipStream_t)stream);                   // Cu :366-376
 }
 extern "C" tgnh_status tgnh_step_end_kick(tgnh_handle h, void* stream) {
     tgnh_status rc = entry(h, true); if (rc) return rc;
+    h->ke_carry = false;
     rc = settle_kick(h, (hipStream_t)stream); if (rc) return rc;
     return run_tile(h, OP_KICK, KID_OTHER, (hipStream_t)stream);                   // Cu :384-388
 }
@@ -1546,13 +1661,16 @@ static uint32_t owed(tgnh_handle h) {
 extern "C" tgnh_status tgnh_get_pending_state(tgnh_handle h, uint32_t* bits) {
     CHECK_H(h);
     if (!bits) return fail(TGNH_ERR_ARG, "null out");
-    *bits = owed(h) | (h->sweep_reverse ? 256u : 0u);
+    *bits = owed(h) | (h->sweep_reverse ? 256u : 0u) | (h->ke_carry ? 512u : 0u);
     return TGNH_OK;
 }
 
 extern "C" tgnh_status tgnh_state_changed(tgnh_handle h) {
     CHECK_H(h);
-    return deferred_guard(h, "tgnh_state_changed");       // kinetic energies are recomputed at every step anyway
+    tgnh_status rc = deferred_guard(h, "tgnh_state_changed");
+    if (rc) return rc;
+    h->ke_carry = false;              // TRUST_STATE_CHANGED: the next thermostat half step sums the kinetic energies again (Cu :474-488)
+    return TGNH_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -1650,6 +1768,7 @@ extern "C" tgnh_status tgnh_set_thermostat_state(tgnh_handle h, int which, void*
     int off, len;
     if (!chain_section(h, which, &off, &len)) return fail(TGNH_ERR_ARG, "bad thermostat array id");
     tgnh_status rc = deferred_guard(h, "tgnh_set_thermostat_state"); if (rc) return rc;
+    h->ke_carry = false;
     if (h->host_only) { std::copy(in, in + len, h->h_state.begin() + off); return TGNH_OK; }
     HIP_OK(hipSetDevice(h->device));
     rc = materialize_chain(h, (hipStream_t)stream); if (rc) return rc;

@@ -165,6 +165,8 @@ struct ChainArgs {
     int do_chain;              // run the chain from ke_red
     int chain_twice;           // DEFER_SCALE: second half of step n and first half of step n+1 back to back
     int lanes;                 // chains of 5-16 links (TGNH): a link per lane (chain_lanes_run) instead of LDS-resident links
+    int ke_carry;              // the chain's kinetic energies are the last chain's ke_post (= s^2 KE: the bins of the velocities that
+                               // chain's rescale left, TGNH_FLAG_TRUST_STATE_CHANGED) -- no KE pass, no row sum ran for this half step
     double dt;
     int S;
     double dtc, inv_dtc;       // dt / S and its reciprocal, formed on the host (a division is a dozen fp64 instructions of the chain wavefront)
@@ -330,6 +332,8 @@ struct tgnh_context {
     bool inline_sum_all = false;      // more rows than that (and < 2 M slots): all four wavefronts of the rescale launch sum them (sum_rows = 2)
     bool sum_pending = false;         // with chain_pending: the partial rows are not summed yet either (the rescale launch does both)
     bool chain_pending = false, chain_pending_twice = false;   // summed KE waits for the next rescale launch to run the chain
+    bool carry_pending = false;       // ... and that KE is the last chain's ke_post (ChainArgs::ke_carry), not ke_red
+    bool carry_ok = false;            // TGNH_FLAG_TRUST_STATE_CHANGED is in effect for this handle (set, unsharded, no molecule spans two groups)
     bool inline_chain = false;        // numNHChains == 1: the chain runs inside the rescale launch
     uint32_t* d_status = nullptr;
     uint32_t* h_status_seen = nullptr;   // pinned: where read-backs of the status word land (periodic, and at every query)
@@ -359,6 +363,7 @@ struct tgnh_context {
     int wresident_per_cu = 0, wresident_grid = 0;   // the same for wstep_kernel (0: none, or no wave tiles)
     int resident_per_cu = 0;          // work-groups of step_kernel per compute unit that the census at create found resident together (0: none -- the handle steps the DEFER_SCALE way)
     bool first_half_done = false;     // DEFER_SCALE: chain for the coming step's first half already run
+    bool ke_carry = false;            // TRUST_STATE_CHANGED: ke_post of the last end half IS the kinetic energy of the stored velocities
     double time = 0;
     int64_t step_count = 0;
     tgnh_allreduce_fn allreduce = nullptr;

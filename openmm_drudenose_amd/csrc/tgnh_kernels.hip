@@ -740,7 +740,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                 TRACE(13);
                 const bool one_link = !MULTI || L.C == 1;            // (2-4 links: chainN_run reads its state itself)
                 Chain1Regs creg{};
-                if (itg < NT) { if (one_link) creg = chain1_load(a.chain, a.st_in, itg); else creg.ke = a.st_in[L.off_ke_red + itg]; }
+                if (itg < NT) { if (one_link) creg = chain1_load(a.chain, a.st_in, itg); else creg.ke = a.st_in[chain_ke_src(a.chain) + itg]; }
                 if (a.x_wait) {                                      // sharded: everybody's sums arrive by mailbox
                     const double tot = xchg_wait_sum(a.chain.x, NT, itg, reinterpret_cast<double*>(smem));   // the images are not in use yet
                     creg.ke = tot;
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     if (write && itg == 63) a.st_out[L.off_kesum] = 0.5 * ks;       // Cu :493-497
                 } else if (write && itg == 63) {                     // Cu :493-497
                     double s = 0.0;
-                    for (int i = 0; i < NT; i++) s += a.x_wait ? s_scale[i] : a.st_in[L.off_ke_red + i];
+                    for (int i = 0; i < NT; i++) s += a.x_wait ? s_scale[i] : a.st_in[chain_ke_src(a.chain) + i];
                     a.st_out[L.off_kesum] = 0.5 * s;
                 }
                 if (MULTI && !one_link) chainN_run(a.chain, a.st_in, a.st_out, write, s_scale, itg, creg.ke);
@@ -1725,7 +1725,7 @@ __device__ __forceinline__ void chain_prologue(const ChainArgs& a, double (*sred
         }
         __syncthreads();
     } else if (tid < NT) {
-        s_ke[tid] = st[L.off_ke_red + tid];      // summed (and all-reduced) by an earlier launch
+        s_ke[tid] = st[chain_ke_src(a) + tid];   // summed (and all-reduced) by an earlier launch, or carried over from the last chain
     }
     if (a.x_send) xchg_send(a.x, NT, tid, BLOCK, s_chain, tid < NT ? s_ke[tid] : 0.0);
     if (a.x_wait) {

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (MODE_DUALNH, MODE_TGNH, PREC_SINGLE, PREC_MIXED, PREC_DOUBLE,  # noqa: F401
-                   FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES)
+                   FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES, FLAG_TRUST_STATE_CHANGED)
 from .synth import KB
 
 _PREC = {"single": PREC_SINGLE, "mixed": PREC_MIXED, "double": PREC_DOUBLE}
@@ -615,9 +615,9 @@ class HipContext(_HandleQueries):
                 _check(self.lib.tgnh_run_harness(self.h, self._x0_arg(), self.k_drude, self.k_tether, int(steps), self._stream()))
             return g
         for _ in range(4):
-            owed_before = self.pending_state() & 0xff
+            owed_before = self.pending_state() & 0x2ff
             first = record()
-            if self.pending_state() & 0xff == owed_before:
+            if self.pending_state() & 0x2ff == owed_before:
                 break
             first.replay()                                   # a transition: taken for real (the recording has advanced the clock)
             torch.cuda.synchronize(self.dev)
@@ -626,7 +626,7 @@ class HipContext(_HandleQueries):
             raise TgnhError(_lib.ERR_STATE, "capture_steps: the handle does not reach a steady state of its step sequence")
         clock = self.time()
         graphs = [first, record()]
-        if self.pending_state() & 0xff != owed_before:
+        if self.pending_state() & 0x2ff != owed_before:
             raise TgnhError(_lib.ERR_STATE, "capture_steps: the step sequence is not periodic")
         # a capture advances the host-side clock without running anything: the first one stands for the first replay,
         # the second one is taken back

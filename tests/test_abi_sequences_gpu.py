@@ -1,13 +1,16 @@
 """Random call sequences against the C ABI's host state machine (DrudeTGNHIntegrator.cpp:166-194: anything may happen between
 two steps -- queries, setters, a changed step size -- and the integrator must go on as if nothing had).
 
-The library steers its launches with a handful of "still owed" flags (tgnh_get_pending_state) x 4 flag combinations x 3 kinds
+The library steers its launches with a handful of "still owed" flags (tgnh_get_pending_state) x 6 flag combinations x 4 kinds
 of exchange; the deterministic tests walk the transitions somebody thought of.  Here a seeded random walk over the entry
-points drives a handle of every combination, and a PLAIN handle (flags 0, no exchange: the reference's own pass structure)
-is fed the same physical sequence -- the same steps, the same accepted setters at the same step boundaries; queries do not
-change physics.  Every 25 calls positions must agree to 1e-12, velocities to 5e-10 and (where the variant does not run the chain
-ahead) the thermostats to 1e-8; a call the variant refuses must be refused with TGNH_ERR_STATE, and is then not made on
-the plain handle either -- a refusal is allowed, a wrong trajectory is not."""
+points drives a handle of every combination, and a PLAIN handle (flags 0, no exchange: the reference's own pass structure) of
+the SAME TILE KIND -- wave tiles or 512-slot tiles, so that the kinetic-energy sums of the two are added in the same order
+wherever the two run the same pass -- is fed the same physical sequence: the same steps, the same accepted setters at the same
+step boundaries; queries do not change physics.  Every 25 calls positions must agree to 1e-12, velocities to 1e-10 and (where
+the variant does not run the chain ahead) the thermostats to rtol 1e-9 / atol 1e-12; a call the variant refuses must be refused
+with TGNH_ERR_STATE, and is then not made on the plain handle either -- a refusal is allowed, a wrong trajectory is not.
+One more walk compares ACROSS the tile kinds (wave-tile handle, 512-slot-tile reference: different orders of every sum) at
+the gate that comparison needs, 5e-10 / 1e-8."""
 import ctypes as C
 
 import numpy as np
@@ -15,7 +18,8 @@ import pytest
 
 from helpers import rel_err
 from openmm_drudenose_amd import synth, HipContext, _lib
-from openmm_drudenose_amd.drudetgnhplugin import DrudeTGNHIntegrator, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES, TgnhError
+from openmm_drudenose_amd.drudetgnhplugin import (DrudeTGNHIntegrator, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES,
+                                                   FLAG_TRUST_STATE_CHANGED, TgnhError)
 
 pytestmark = pytest.mark.gpu
 
@@ -43,11 +47,13 @@ def build(flags, exchange, chains, wave=False):
 
 
 class Walk:
-    def __init__(self, flags, exchange, chains, seed):
+    def __init__(self, flags, exchange, chains, seed, wave=None, cross=False):
         self.rng = np.random.default_rng(seed)
-        self.s, self.it, self.ctx = build(flags, exchange, chains, wave=seed % 2 == 1)      # (wave-tile and 512-slot-tile kernels, mixed over the grid)
-        _, self.rit, self.ref = build(0, None, chains)
+        wave = seed % 2 == 1 if wave is None else wave                                       # (wave-tile and 512-slot-tile kernels, mixed over the grid)
+        self.s, self.it, self.ctx = build(flags, exchange, chains, wave=wave)
+        _, self.rit, self.ref = build(0, None, chains, wave=wave != cross)                   # like with like, but for the one cross-kind walk
         self.flags = flags
+        self.gate_v, self.gate_t = ((5e-10, dict(rtol=1e-8, atol=1e-9)) if cross else (1e-10, dict(rtol=1e-9, atol=1e-12)))
         self.replay = None
         self.log = []
 
@@ -112,6 +118,30 @@ class Walk:
         if self.refused_or(lambda c: c.setVelocities(v), lambda c: c.setVelocities(c.getVelocities() * 0.999)):
             self.both(lambda c: c.compute_forces())
 
+    def op_remove_cm(self):
+        """the harness' CMMotionRemover: velocities change behind the integrator, the library's own call-out knows it"""
+        def cm(c):
+            if self.flags & FLAG_DEFER_SCALE:                # deferred: velocities lag between steps and the next half step has run
+                c._state_changed()                           # already -- the contract is stateChanged first, which such a handle refuses
+                c.getVelocities()
+            assert c.lib.tgnh_harness_remove_cm_motion(c.h, c._stream()) == 0
+        self.refused_or(cm, lambda c: c.lib.tgnh_harness_remove_cm_motion(c.h, c._stream()))
+
+    def op_rebind(self):
+        """tgnh_bind_buffers: the same arrays again (what the OpenMM glue does at every step), or the velocities in another array"""
+        def rebind(c, move):
+            if move:
+                c.torch.cuda.synchronize(c.dev)
+                c.velm = c.velm.clone()
+            rc = c.lib.tgnh_bind_buffers(c.h, c.posq.data_ptr(), c.posq_corr.data_ptr() if c.posq_corr is not None else None,
+                                         c.velm.data_ptr(), c.force.data_ptr(), c.pos_delta.data_ptr())
+            if rc != 0:
+                raise TgnhError(rc, c.lib.tgnh_last_error().decode())
+        move = bool(self.rng.integers(0, 2))
+        if move:
+            self.ctx.getVelocities()                         # (a moved array holds the reference's end-of-step velocities: settle what is pending first)
+        self.refused_or(lambda c: rebind(c, move), lambda c: rebind(c, move))
+
     def op_set_thermostat(self):
         which = int(self.rng.integers(0, 2))
         try:
@@ -142,17 +172,17 @@ class Walk:
             assert c.check() == 0 and c.time()[1] == self.ref.time()[1]
 
     OPS = [("step", 6), ("step_pieces", 3), ("split_step", 2), ("graph", 1), ("set_step_size", 1), ("set_drude_steps", 1),
-           ("set_velocities", 1), ("set_thermostat", 1), ("flush", 2), ("queries", 5)]
+           ("set_velocities", 1), ("set_thermostat", 1), ("remove_cm", 1), ("rebind", 1), ("flush", 2), ("queries", 5)]
 
     def compare(self, where):
         pos, vel = self.ctx.getPositions(), self.ctx.getVelocities()
         ep, ev = rel_err(pos, self.ref.getPositions()), rel_err(vel, self.ref.getVelocities())
-        assert ep <= 1e-12 and ev <= 5e-10, (where, ep, ev, self.log[-12:])      # (different orders of the sums over ~800 steps: 1e-10 seen; a wrong launch shows as 1e-3)
+        assert ep <= 1e-12 and ev <= self.gate_v, (where, ep, ev, self.log[-12:])      # (a wrong launch shows as 1e-3)
         assert self.ctx.time() == pytest.approx(self.ref.time(), rel=1e-12) and self.ctx.check() == 0
         if not self.flags & FLAG_DEFER_SCALE:                # (deferred: the chain has run the next step's first half already)
             for which in (0, 1):
                 a, b = self.ctx.thermostat_state(which), self.ref.thermostat_state(which)
-                assert np.allclose(a, b, rtol=1e-8, atol=1e-9), (where, which, self.log[-12:])
+                assert np.allclose(a, b, **self.gate_t), (where, which, self.log[-12:])
 
     def run(self):
         names = [n for n, w in self.OPS for _ in range(w)]
@@ -165,8 +195,27 @@ class Walk:
         self.ctx.close(); self.ref.close()
 
 
+TRUST = FLAG_TRUST_STATE_CHANGED
+
+
 @pytest.mark.parametrize("exchange", [None, "hook", "mailbox", "rccl"])
-@pytest.mark.parametrize("flags", [0, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP])
+@pytest.mark.parametrize("flags", [0, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP, TRUST, TRUST | FLAG_RESIDENT_STEP])
 def test_random_call_sequences(flags, exchange):
+    """(TRUST with an exchange attached is ignored by the library: those walks check exactly that)"""
     chains = 1 if (flags + (0 if exchange is None else 1)) % 2 == 0 else 3          # one- and three-link chains, mixed over the grid
     Walk(flags, exchange, chains, seed=1000 + 16 * flags + len(exchange or "")).run()
+
+
+@pytest.mark.parametrize("chains", [1, 3])
+def test_kinetic_energies_carried_over_survive_random_call_sequences(chains):
+    """TGNH_FLAG_TRUST_STATE_CHANGED without an exchange, both tile kinds: every call that may write velocities between two steps
+    (setVelocities, the split entry points, the harness' CMMotionRemover, velocities bound to another array, a thermostat set)
+    must make the next half step sum its kinetic energies again -- a carried sum that survived one of them shows as 1e-3."""
+    for wave in (False, True):
+        w = Walk(TRUST, None, chains, seed=77 + chains, wave=wave)
+        w.run()
+
+
+def test_random_call_sequence_across_tile_kinds():
+    """a wave-tile handle against a 512-slot-tile reference: every sum in another order, the loose gate"""
+    Walk(FLAG_DEFER_SCALE, None, 3, seed=4242, wave=True, cross=True).run()

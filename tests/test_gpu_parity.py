@@ -12,7 +12,7 @@ import pytest
 
 from openmm_drudenose_amd import synth, _lib
 from openmm_drudenose_amd.drudetgnhplugin import (DrudeTGNHIntegrator, HipContext, TgnhError,
-                                                   FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES)
+                                                   FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES, FLAG_TRUST_STATE_CHANGED)
 from helpers import make_oracle, oracle_run, rel_err, to_internal
 
 pytestmark = pytest.mark.gpu
@@ -32,6 +32,13 @@ def bind_groups(it, group, ngroups):
         it.addTempGroup()
     for g in group:
         it.addParticleTempGroup(int(g))
+
+
+def bind_groups_array(it, group, ngroups):
+    """the same for millions of particles: the array goes in whole (a Python list that long is slow to build and to walk)"""
+    for _ in range(ngroups):
+        it.addTempGroup()
+    it._particleTempGroup = np.ascontiguousarray(group, np.int32)
 
 
 SYSTEMS = {
@@ -228,6 +235,112 @@ def test_100_step_parity(sysname, mode, chains, drude_chains, com, hardwall, pre
     for which in (0, 1):
         a, b = ctx.thermostat_state(which), o.chain(which)
         assert np.allclose(a, b, rtol=1e-6, atol=1e-9 * max(1.0, np.abs(b).max()))
+    ctx.close()
+
+
+TRUST = FLAG_TRUST_STATE_CHANGED
+TRUST_CASES = [
+    # sysname, mode, chains, drude_chains, flags
+    ("mixed", "TGNH", 1, True, TRUST),                        # the chain inside the rescale launch, reading the staged block where it lies
+    ("mixed", "TGNH", 3, True, TRUST),                        # 2-4 links inside the rescale launch
+    ("mixed", "TGNH", 10, True, TRUST),                       # chain_kernel (a link per lane) started from the carried sums
+    ("water1000", "TGNH", 1, True, TRUST | FLAG_RESIDENT_STEP),   # the end half as one step_kernel launch, the begin half the tile launch
+    ("il40", "dualNH", 1, False, TRUST),                      # the Reference platform's coupled one-link chain
+    ("mixed", "dualNH", 3, True, TRUST),
+    ("polymer", "TGNH", 1, True, TRUST),                      # a molecule longer than a tile: its COM table is refreshed without the KE pass
+    ("groups12", "TGNH", 2, True, TRUST),                     # more than 8 groups: LDS bins, chain_kernel
+]
+
+
+@pytest.mark.parametrize("precision", ["mixed", "double"])
+@pytest.mark.parametrize("sysname,mode,chains,drude_chains,flags", TRUST_CASES)
+def test_100_step_parity_trust_state_changed(sysname, mode, chains, drude_chains, flags, precision):
+    """TGNH_FLAG_TRUST_STATE_CHANGED: the reference's pass structure (velocities never lag) whose begin half starts its chain from
+    the kinetic energies the last end half's chain left (s^2 KE, Cu :574) instead of summing them again (Cu :474-488).  Against the
+    oracle, which does sum them: (a) 100 undisturbed steps -- one KE pass in all, the first step's; (b) the same with every half step
+    queried (queries settle what is pending: the other launch sequence), per-half-step kinetic energies and scale factors
+    included; (c) velocities set in mid-run (stateChanged, DrudeTGNHIntegrator.cpp:166-170): the next half sums again."""
+    s, g, ng, it, ctx = make(sysname, mode, precision, flags=flags, chains=chains, drude_chains=drude_chains, hardwall=0.02, tiles="lds")
+    o = make_oracle(s, g, ng, mode, it)
+    pos_o, vel_o, kes, scs = oracle_run(o, s, 100, record=True, x0=ctx.sites())
+    kes, scs = to_internal(kes, mode), to_internal(scs, mode)
+    ctx.timing(True)
+    ctx.step(100)
+    ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
+    ctx.timing(False)
+    ke_passes = ctx.timing_read(_lib.KID_KE)[1]
+    print(f"{sysname} {mode} {precision} chains {chains}: undisturbed pos {ep:.2e} vel {ev:.2e}, {ke_passes} KE passes in 100 steps")
+    assert ep <= TOL and ev <= TOL
+    assert ke_passes == 1 and ctx.pending_state() & 512
+    for which in (0, 1):
+        a, b = ctx.thermostat_state(which), o.chain(which)
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-9 * max(1.0, np.abs(b).max()))
+    ctx.close()
+    # (b) every half step queried
+    s, g, ng, it, ctx = make(sysname, mode, precision, flags=flags, chains=chains, drude_chains=drude_chains, hardwall=0.02, tiles="lds")
+    worst_ke = worst_sc = 0.0
+    m = np.ones(kes.shape[1], bool)
+    if mode == "dualNH":
+        m[1] = False
+    for i in range(100):
+        ctx.step_begin()
+        ke, sc = ctx.last_kinetic_energies(), ctx.last_scale_factors()
+        worst_ke = max(worst_ke, np.abs(ke - kes[2 * i]).max() / np.abs(kes[2 * i]).max())
+        worst_sc = max(worst_sc, np.abs(sc[m] - scs[2 * i][m]).max())
+        ctx.compute_forces()
+        ctx.step_end()
+        ke, sc = ctx.last_kinetic_energies(), ctx.last_scale_factors()
+        worst_ke = max(worst_ke, np.abs(ke - kes[2 * i + 1]).max() / np.abs(kes[2 * i + 1]).max())
+        worst_sc = max(worst_sc, np.abs(sc[m] - scs[2 * i + 1][m]).max())
+    ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
+    print(f"    queried: pos {ep:.2e} vel {ev:.2e} KE {worst_ke:.2e} scale {worst_sc:.2e}")
+    assert ep <= TOL and ev <= TOL and worst_ke <= TOL_KE and worst_sc <= TOL_KE
+    ctx.close()
+    # (c) stateChanged in mid-run
+    s, g, ng, it, ctx = make(sysname, mode, precision, flags=flags, chains=chains, drude_chains=drude_chains, hardwall=0.02, tiles="lds")
+    o = make_oracle(s, g, ng, mode, it)
+    x0 = ctx.sites()
+    po, vo = s.positions.copy(), s.velocities.copy()
+    f = o.harness_force(po, x0, synth.K_DRUDE, synth.K_TETHER)
+    o.run_harness(po, vo, f, x0, synth.K_DRUDE, synth.K_TETHER, 10)
+    vo *= 0.9
+    o.run_harness(po, vo, f, x0, synth.K_DRUDE, synth.K_TETHER, 10)
+    ctx.timing(True)
+    ctx.step(10)
+    assert ctx.pending_state() & 512
+    ctx.setVelocities(ctx.getVelocities() * 0.9)
+    assert not ctx.pending_state() & 512
+    ctx.step(10)
+    ep, ev = rel_err(ctx.getPositions(), po), rel_err(ctx.getVelocities(), vo)
+    ctx.timing(False)
+    print(f"    velocities set after 10 steps: pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= TOL and ev <= TOL and ctx.timing_read(_lib.KID_KE)[1] == 2
+    ctx.close()
+
+
+def test_trust_state_changed_is_ignored_where_it_cannot_hold():
+    """A molecule that spans two temperature groups (s^2 KE is then not the rescaled velocities' bin), DEFER_SCALE, a sharded
+    handle: the flag changes nothing -- every begin half sums its kinetic energies, the trajectory is the plain one."""
+    s, g, ng = synth.water_box(300)
+    g = g.copy(); g[2::5] = 1                                   # every H1 in a group of its own
+    runs = []
+    for flags in (0, TRUST):
+        it = integ(chains=1, hardwall=0.02)
+        bind_groups(it, g, 2)
+        ctx = HipContext(s, it, mode="TGNH", precision="double", flags=flags)
+        ctx.timing(True)
+        ctx.step(20)
+        runs.append((ctx.getPositions(), ctx.getVelocities()))
+        ctx.timing(False)
+        assert ctx.timing_read(_lib.KID_KE)[1] == 20 and not ctx.pending_state() & 512
+        ctx.close()
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+    s, g, ng, it, ctx = make("mixed", "TGNH", "double", flags=TRUST, chains=1)
+    ctx.set_allreduce(lambda t: None)                            # a collective hook: sharded as far as the handle knows
+    ctx.timing(True)
+    ctx.step(5)
+    ctx.timing(False)
+    assert ctx.timing_read(_lib.KID_KE)[1] == 5 and not ctx.pending_state() & 512
     ctx.close()
 
 
@@ -1532,21 +1645,65 @@ def test_random_constraint_clusters_against_the_oracle(seed, mode):
     ctx.close()
 
 
-def test_full_size_steps_against_the_oracle():
-    """The metric configuration itself (1 M Drude pairs = 5 M slots, mixed precision, deferred rescale, hard wall, the
-    bench's integrator settings) against the oracle directly: the oracle manages ~5 steps/s at this size, so a few
-    steps are affordable -- enough to pass through every launch of the step, the in-kernel chain and the row sum
-    over all 1.2 k x 8 partial rows."""
-    s, g, ng = synth.water_box(1_000_000)
+_FULL = {}
+
+
+def full_size_case(mode):
+    """The metric system (1 M Drude pairs = 5 M slots, the bench's integrator settings) and three oracle steps of it, once per
+    mode: the oracle manages 5-10 steps/s at this size.  Tether sites as every float-position context stores them."""
+    if "system" not in _FULL:
+        _FULL["system"] = synth.water_box(1_000_000)
+    s, g, ng = _FULL["system"]
+    if mode not in _FULL:
+        it = integ(chains=1, hardwall=0.02)
+        gm, ngm = (g, ng) if mode == "TGNH" else (np.zeros_like(g), 1)
+        o = make_oracle(s, gm, ngm, mode, it)
+        x0 = s.positions.astype(np.float32).astype(np.float64)
+        _FULL[mode] = oracle_run(o, s, 3, x0=x0) + (x0,)
+    return (s, g, ng) + _FULL[mode]
+
+
+RESIDENT_DEFER = FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP
+
+
+@pytest.mark.parametrize("mode,flags,precision", [
+    ("TGNH", RESIDENT_DEFER, "mixed"),       # bench.py's headline leg: wstep_kernel
+    ("dualNH", RESIDENT_DEFER, "mixed"),     # ... its dualNH/mixed/resident leg
+    ("TGNH", RESIDENT_DEFER, "single"),      # ... single precision through wstep_kernel (reported; the gate is the single-precision one)
+    ("TGNH", FLAG_DEFER_SCALE, "mixed"),     # tile_kernel + wke_kernel, three launches per step
+    ("dualNH", FLAG_DEFER_SCALE, "mixed"),
+    ("TGNH", 0, "mixed"),                    # the reference's pass structure (what the OpenMM glue runs)
+    ("TGNH", FLAG_RESIDENT_STEP, "mixed"),   # ... with each thermostat half one step_kernel launch
+])
+def test_full_size_steps_against_the_oracle(mode, flags, precision):
+    """The metric configuration itself against the oracle directly, through every launch structure bench.py times: a few steps
+    are affordable -- enough to pass through every launch of the step, the in-kernel chain, the row collection over all the
+    work-groups of the resident grid (every wavefront of wstep_kernel walks ~20 tiles forward and back here, and work-group 0
+    collects the largest number of rows: the regime the 2 M-slot cases do not reach)."""
+    s, g, ng, pos_o, vel_o, x0 = full_size_case(mode)
     it = integ(chains=1, hardwall=0.02)
-    bind_groups(it, g, ng)
-    ctx = HipContext(s, it, mode="TGNH", precision="mixed", flags=FLAG_DEFER_SCALE)
-    o = make_oracle(s, g, ng, "TGNH", it)
-    pos_o, vel_o = oracle_run(o, s, 3, x0=ctx.sites())
+    if mode == "TGNH":
+        bind_groups_array(it, g, ng)
+    ctx = HipContext(s, it, mode=mode, precision=precision, flags=flags)
+    assert np.array_equal(ctx.sites(), x0)
+    ctx.timing(True)
     ctx.step(3)
     ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
-    print(f"5 M slots, 3 steps: pos {ep:.2e} vel {ev:.2e}")
-    assert ep <= TOL and ev <= TOL          # (thermostat variables are not compared: deferred, the chain is half a step ahead)
+    ctx.timing(False)
+    nstep = ctx.timing_read(_lib.KID_STEP)[1]
+    print(f"5 M slots, 3 steps, {mode} {precision} flags {flags}: pos {ep:.2e} vel {ev:.2e} ({nstep} one-launch steps, "
+          f"{ctx.resident_work_groups()} work-groups per CU resident)")
+    if flags == RESIDENT_DEFER:
+        assert nstep >= 2                   # it really was wstep_kernel: steps 2 and 3 (the first step has no end half to fold in)
+    elif flags == FLAG_RESIDENT_STEP:
+        assert nstep >= 6                   # both halves of every step
+    else:
+        assert nstep == 0
+    if precision == "single":               # float4 state against the fp64 oracle: test_single_precision_deviation's figures
+        assert ep <= 1e-6 and ev <= 1e-3
+    else:
+        assert ep <= TOL and ev <= TOL      # (thermostat variables are not compared: deferred, the chain is half a step ahead)
+    assert ctx.check() == 0
     ctx.close()
 
 

@@ -95,6 +95,105 @@ def test_wave_tiles_and_their_words(name, com):
         assert np.all(pos == 0) and np.all(size == 1) and np.all(wt[:-1, 1] == 1)
 
 
+def _wave_tile_system(name):
+    """the systems of test_every_access_of_the_wave_tile_kernels_stays_inside_its_buffers"""
+    if name == "testwater":                                  # the reference's testWater box: 216 x (O, D, H1, H2, M), constraints + M site
+        import water_test_system as wts
+        s = wts.build()
+        return s, np.zeros(s.num_particles, np.int32), 1
+    if name.startswith("ragged"):
+        from helpers import random_topology
+        mass, pd, pp, resid, group, ngroups, cons, sizes, first, rng = random_topology(int(name[6:]))
+        s = synth.DrudeSystem(mass=mass, pair_drude=np.array(pd, np.int32), pair_parent=np.array(pp, np.int32), resid=resid,
+                              constraints=np.array(cons, np.int32).reshape(-1, 2))
+        return s, group, ngroups
+    return BUILDERS[name]()
+
+
+@pytest.mark.parametrize("mode,com", [("TGNH", True), ("TGNH", False), ("dualNH", True)])
+@pytest.mark.parametrize("name", ["testwater", "water", "nacl", "il", "mixed", "pnm"] + [f"ragged{k}" for k in range(8)])
+def test_every_access_of_the_wave_tile_kernels_stays_inside_its_buffers(name, mode, com):
+    """What wke_kernel / wstep_kernel touch, re-derived on the CPU from the tables a handle hands its launches
+    (wave_load, load_vf, work / prepare / finish in tgnh_kernels.hip; launch sizes in tgnh_host.cpp):
+
+      global   slot ws + lane for lane < n of every wave tile: inside [0, N); the table has num_wtiles + 1 entries, the last
+               one N; velocities, index words and forces are read there and nowhere else;
+      LDS      a lane reads its molecule's lanes first .. first + (molecule slots - 1) with first = lane - position, and its
+               Drude partner's lane: all inside [0, n) of the wavefront's own 64-lane image; the walk's trip count (the tile's
+               largest molecule) covers every molecule of the tile; a padding lane reads itself;
+      rows     one row of partial sums per work-group in a table of GRID_CAP rows, or tagged cells (row_word's layout) in an
+               area sized for GRID_CAP rows of <= 10 thermostats: the largest grid any launch of the handle takes fits both.
+
+    On the reference's own testWater box (the box of the one device fault this repository has on record), the
+    ragged topologies of helpers.random_topology, and the synthetic boxes; TGNH with and without the COM group, dualNH."""
+    s, g, ng = _wave_tile_system(name)
+    if mode == "dualNH":
+        if s.num_pairs == 0:
+            pytest.skip("dualNH needs a Drude pair")
+        it = integ(com=com)
+    else:
+        it = integ(group=g, ngroups=ng, com=com)
+    t = HostTopology(s, it, mode=mode)
+    n = s.num_particles
+    wt = t.topology(9).reshape(-1, 2)
+    bounds = np.zeros(8, np.int32)
+    assert t.lib.tgnh_get_launch_bounds(t.h, bounds.ctypes.data_as(_lib.c_i32p)) == 0
+    tiles, wtiles, entries, grid, rows, tagged, touched, NT = (int(x) for x in bounds)
+    uses_com = mode == "TGNH" and com
+    longest = np.bincount(s.resid).max()
+    # ---- launch-side sizes
+    assert entries == len(wt) and (wtiles == 0) == (len(wt) == 0) and (wtiles == 0 or entries == wtiles + 1)
+    assert 1 <= grid <= rows and rows == 2048
+    assert grid >= min(tiles, 2048) and (wtiles == 0 or grid >= min((wtiles + 3) // 4, 2048))
+    if NT <= 10:
+        assert tagged == 2 * 2048 * 10 and 0 < touched <= tagged
+        # row_word(r, j) = ((r >> 6) * 20 + j) * 64 + (r & 63): the last word of the last row of that grid
+        r, j = grid - 1, 2 * NT - 1
+        assert touched == ((r >> 6) * 20 + j) * 64 + (r & 63) + 1
+    else:
+        assert tagged == 0 and touched == 0                 # more than 8 groups: no tagged rows, the tile kernels' partial rows only
+    # cuts that would go through a pair or (COM group on) a molecule; no legal cut within 64 slots somewhere = no wave tiles
+    cut_ok = np.ones(n + 1, bool)
+    for a, b in zip(s.pair_drude, s.pair_parent):
+        cut_ok[min(a, b) + 1:max(a, b) + 1] = False
+    if uses_com:
+        cut_ok[1:n] &= np.diff(s.resid) != 0
+    cut_ok[n] = True
+    pos, possible = 0, not (uses_com and longest > 64)
+    while possible and pos < n:
+        ends = np.flatnonzero(cut_ok[pos + 1:min(pos + 64, n) + 1])
+        possible = len(ends) > 0
+        pos = pos + 1 + int(ends[-1]) if possible else pos
+    assert (wtiles > 0) == possible, (name, mode, com)
+    if not possible:
+        return
+    # ---- the table
+    start = wt[:, 0].astype(np.int64)
+    assert start[0] == 0 and start[-1] == n and np.all(np.diff(start) >= 1) and np.all(np.diff(start) <= 64)
+    w = t.topology(10).view(np.uint32)
+    assert len(w) == n
+    for k in range(wtiles):
+        ws, cnt, maxn = int(start[k]), int(start[k + 1] - start[k]), int(wt[k, 1])
+        lane = np.arange(64)
+        word = np.where(lane < cnt, np.r_[w[ws:ws + cnt], np.zeros(64 - cnt, np.uint32)], np.uint32(64 << 10))   # wave_load's padding word
+        assert ws + cnt <= n                                                  # every global index of the tile
+        j, n1 = ((word >> 17) & 63).astype(np.int64), ((word >> 23) & 63).astype(np.int64)
+        first = lane - j
+        live = lane < cnt
+        if uses_com:
+            assert np.all(first[live] >= 0) and np.all((first + n1)[live] < cnt), (name, k)     # the molecule lies inside the tile
+            assert np.all(n1[live] + 1 <= maxn), (name, k)                   # the walk (k < maxn, k <= n1) reaches every slot of it
+        assert np.all(j[~live] == 0) and np.all(n1[~live] == 0)               # padding lanes: a molecule of their own
+        pl = lane + ((word >> 10) & 127).astype(np.int64) - 64
+        role = word & 3
+        assert np.all((pl >= 0) & (pl < 64)) and np.all(pl[live & (role != 0)] < cnt), (name, k)
+        assert np.all(pl[role == 0] == lane[role == 0])
+        # partners point at each other, Drude <-> parent
+        pr = role[pl]
+        assert np.all(pr[role == 1] == 2) and np.all(pr[role == 2] == 1) and np.all(pl[pl[role != 0]] == lane[role != 0])
+    t.close()
+
+
 @pytest.mark.parametrize("name,com", [("pnm", True), ("nacl", True), ("il", True), ("mixed", True), ("water", True), ("mixed", False),
                                       ("water", False), ("polymer", True), ("polymer", False)])
 def test_tiles_of_identical_molecules_need_no_per_slot_words(name, com):
