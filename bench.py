@@ -48,11 +48,13 @@ def parse():
     p.add_argument("--molecules", type=int, default=1_000_000, help="SWM4 molecules = Drude pairs (metric: 1,000,000)")
     p.add_argument("--precision", default="mixed", choices=["single", "mixed", "double"])
     p.add_argument("--mode", default="TGNH", choices=["TGNH", "dualNH"])
-    p.add_argument("--variant", default="auto", choices=["auto", "plain", "plain-resident", "defer", "resident"],
+    p.add_argument("--variant", default="auto", choices=["auto", "plain", "plain-trust", "plain-resident", "defer", "resident"],
                    help="defer = end-of-step rescale and second half kick folded into the next step's first pass; resident = "
                         "defer with the whole step in ONE launch whose work-groups meet on the device (step_kernel; with the "
-                        "RCCL hook it steps the defer way); plain = the reference's pass structure (what the OpenMM glue "
-                        "runs); plain-resident = that structure with each thermostat half one step_kernel launch; "
+                        "RCCL hook it steps the defer way); plain = the reference's pass structure; plain-trust = that structure with "
+                        "TGNH_FLAG_TRUST_STATE_CHANGED (the begin half starts its chain from the kinetic energies the last end half "
+                        "left: no KE pass; what the OpenMM glue runs for a System without CMMotionRemover / AndersenThermostat); "
+                        "plain-resident = the plain structure with each thermostat half one step_kernel launch; "
                         "auto = resident (single precision from 3 M slots per GPU: defer) (DESIGN.md)")
     p.add_argument("--chains", type=int, default=1)
     p.add_argument("--drude-steps", type=int, default=20, help="drudeStepsPerRealStep (reference default 20)")
@@ -79,11 +81,11 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
     import torch
     import torch.distributed as dist
     from openmm_drudenose_amd import DrudeTGNHIntegrator, HipContext
-    from openmm_drudenose_amd.drudetgnhplugin import FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP
+    from openmm_drudenose_amd.drudetgnhplugin import FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_TRUST_STATE_CHANGED
     from openmm_drudenose_amd.system import shard_bounds
     it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, args.drude_steps, args.chains, True, True)
     it.setMaxDrudeDistance(args.hardwall)
-    flags = {"plain": 0, "plain-resident": FLAG_RESIDENT_STEP, "defer": FLAG_DEFER_SCALE,
+    flags = {"plain": 0, "plain-trust": FLAG_TRUST_STATE_CHANGED, "plain-resident": FLAG_RESIDENT_STEP, "defer": FLAG_DEFER_SCALE,
              "resident": FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP}[variant]
     local, lgroup = system, group
     if world > 1:
@@ -492,7 +494,7 @@ def step_model_bytes(num_slots, precision, variant):
     V = 16 if precision == "single" else 32
     X = 16 if precision == "single" else 32
     F = 24
-    per = {"plain": 7 * V + 2 * F + 2 * X, "plain-resident": 6 * V + 3 * F + 2 * X, "defer": 3 * V + 2 * F + 2 * X,
+    per = {"plain": 7 * V + 2 * F + 2 * X, "plain-trust": 6 * V + 2 * F + 2 * X, "plain-resident": 6 * V + 3 * F + 2 * X, "defer": 3 * V + 2 * F + 2 * X,
            "resident": 3 * V + 2 * F + 2 * X}[variant]
     return num_slots * per
 
@@ -606,6 +608,7 @@ def main():
     if ctx.exchange == "mailbox" and not all_ranks_agree((ctx.status_flags() & 4) == 0):
         raise SystemExit("bench.py: the mailbox exchange timed out inside the timed run")
     graph_used = ctx.graph_used
+    step_kernel_name = ctx.resident_kernel() or "step_kernel"
     exchange_used = ctx.exchange
     rccl_site = ctx.rccl_site
     headline_ranks = per_rank_exchange_report(ctx, exchange_used, world) if use_dist else None
@@ -639,7 +642,7 @@ def main():
     if mailbox_info:
         extra["mailbox"] = dict(extra.get("mailbox", {}), **mailbox_info)
     if world == 1 and not args.no_extra:
-        for prec, var in ((args.precision, "plain"), (args.precision, "plain-resident"), (args.precision, "defer"), (args.precision, "resident"),
+        for prec, var in ((args.precision, "plain"), (args.precision, "plain-trust"), (args.precision, "plain-resident"), (args.precision, "defer"), (args.precision, "resident"),
                           ("single", "defer" if system.num_particles / world >= 3_000_000 else args.variant)):
             if (prec, var) == (args.precision, args.variant):
                 continue
@@ -686,7 +689,7 @@ def main():
                 "sum_kernels_us_per_step": leg["sum_kernels_us_per_step"], "suspect": leg["suspect"],
                 "csrc_sha": csrc_sha(),
             },
-            "roofline": {"bound": "hbm", "kernel": "step_kernel" if dkid == _lib.KID_STEP else "tile_kernel<scale+kick+drift>",
+            "roofline": {"bound": "hbm", "kernel": step_kernel_name if dkid == _lib.KID_STEP else "tile_kernel<scale+kick+drift>",
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,

@@ -72,8 +72,10 @@ enum { TGNH_FLAG_RESIDENT_STEP = 4 };  /* whole thermostat halves in ONE launch 
                                         * never lag -- usable wherever the plain structure is.  With DEFER_SCALE:
                                         * tgnh_step_end launches nothing and the next tgnh_step_begin runs that end half and
                                         * its own begin half in one launch.  Either way the handle needs the device to itself
-                                        * while stepping (see tgnh_set_resident_share); one-link chains, <= 8 temperature
-                                        * groups, no collective hook -- otherwise it quietly steps with the tile launches.
+                                        * while stepping (see tgnh_set_resident_share); <= 8 temperature groups, no
+                                        * collective hook, and chains of 1-4 links with DEFER_SCALE on a topology with wave tiles
+                                        * (wstep_kernel), one-link chains otherwise (step_kernel) -- else it quietly steps with
+                                        * the tile launches (tgnh_get_resident_kernel says which).
                                         * With a mailbox exchange attached and DEFER_SCALE, state queries between steps are
                                         * collective over the ranks. */
 
@@ -193,6 +195,9 @@ tgnh_status tgnh_set_resident_share(tgnh_handle h, int share);
 /* Work-groups of the resident step kernel per compute unit that tgnh_create found resident together (a census launch checks
  * the occupancy query); 0 = the handle steps the DEFER_SCALE way (flag not set, or nothing passed the census). */
 tgnh_status tgnh_get_resident_work_groups(tgnh_handle h, int* per_compute_unit);
+/* Which kernel this handle's next tgnh_step_begin runs as its one launch: 0 none (the streaming launches), 1 step_kernel (512-slot
+ * tiles, one-link chains), 2 wstep_kernel (a whole deferred step over wave tiles, chains of 1-4 links). */
+tgnh_status tgnh_get_resident_kernel(tgnh_handle h, int* which);
 
 /* Mailbox exchange: the same all-reduce of the NT kinetic-energy sums, done by the integrator's own kernels with
  * plain stores into every peer's mailbox over xGMI (no collective launch on the step's critical path).  Optional;
@@ -236,7 +241,12 @@ tgnh_status tgnh_step_end_thermo(tgnh_handle h, void* stream);
  * reference's end-of-step state; call before anything else reads velm. */
 tgnh_status tgnh_flush(tgnh_handle h, void* stream);
 /* A caller that captured `nsteps` steps into a hipGraph and replays it tells the handle here: the host-side
- * clock and step count advance only when the step functions are called, not when a graph is replayed. */
+ * clock and step count advance only when the step functions are called, not when a graph is replayed.
+ * Determinism: the sweep direction of a step's launches -- which orders the additions of its kinetic-energy sums -- is fixed from
+ * the step counter when the step is ENQUEUED (step k starts in direction k & 1, see "What is reproducible bit for bit" above), so a recording bakes
+ * its directions in.  A graph of an EVEN number of steps replays the eager loop's launches exactly; a graph of an odd number
+ * does so on every other replay only -- record two graphs back to back and replay them in turn (HipContext.capture_steps does)
+ * if the trajectory is to be the eager one bit for bit.  Either way the result is correct to rounding. */
 tgnh_status tgnh_note_replayed_steps(tgnh_handle h, int nsteps);
 /* What the handle still owes the trajectory, as a bit set (inspection only; a caller that records steps into a hipGraph
  * checks that the set is the same before and after the recorded steps -- a graph replays launches, not decisions):
@@ -263,7 +273,8 @@ tgnh_status tgnh_get_num_thermostats(tgnh_handle h, int* count);               /
 tgnh_status tgnh_get_last_kinetic_energies(tgnh_handle h, void* stream, double* ke);   /* no 1/2; before the chain */
 tgnh_status tgnh_get_last_scale_factors(tgnh_handle h, void* stream, double* scale);
 /* bit0: a Drude beyond 2x the hard wall; bit1: the harness SHAKE did not converge; bit2: a mailbox exchange timed out;
- * bit3: the work-groups of a resident step did not all meet.  *flags is always filled in.  bit2, bit3 -- and bit0 in DUALNH mode, where the Reference platform throws
+ * bit3: the work-groups of a resident step did not all meet; bit4: a kinetic-energy pass that sums its own rows (tail sum) did not
+ * receive every row -- the sums were left as NaN.  *flags is always filled in.  bit2, bit3, bit4 -- and bit0 in DUALNH mode, where the Reference platform throws
  * (ReferenceDrudeTGNHKernels.cpp:311-312) -- are FAILURES and sticky: once the host has seen one (here, at any other
  * tgnh_get_*, at tgnh_exchange_detach, or through the read-back the library enqueues behind every 64th step) every later
  * tgnh_step_*, tgnh_flush and tgnh_get_* returns TGNH_ERR_STATE / TGNH_ERR_HARDWALL with the message in tgnh_last_error(). */

@@ -57,6 +57,7 @@ SIGNATURES = {
     "tgnh_get_pending_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "tgnh_set_resident_share": (C.c_int, [C.c_void_p, C.c_int]),
     "tgnh_get_resident_work_groups": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "tgnh_get_resident_kernel": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "tgnh_exchange_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "tgnh_exchange_attach": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tgnh_exchange_attach_pointers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

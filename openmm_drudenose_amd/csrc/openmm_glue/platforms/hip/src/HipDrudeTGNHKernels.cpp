@@ -1,6 +1,7 @@
 // OpenMM-HIP glue (not compiled here, see HipDrudeTGNHKernels.h).  Everything with arithmetic in it lives
 // behind the C ABI; this file only translates OpenMM objects into tgnh_desc and device pointers.
 #include "HipDrudeTGNHKernels.h"
+#include "openmm/AndersenThermostat.h"
 #include "openmm/CMMotionRemover.h"
 #include "openmm/OpenMMException.h"
 #include "openmm/internal/ContextImpl.h"
@@ -50,10 +51,15 @@ void HipIntegrateDrudeTGNHStepKernel::initialize(const System& system, const Dru
         double distance;
         system.getConstraintParameters(i, ci[i], cj[i], distance);
     }
-    bool hasCMM = false;
-    for (int i = 0; i < system.getNumForces(); i++)
+    bool hasCMM = false, editsVelocities = false;
+    for (int i = 0; i < system.getNumForces(); i++) {
         if (dynamic_cast<const CMMotionRemover*>(&system.getForce(i)) != nullptr)
             hasCMM = true;
+        // forces whose updateContextState writes velocities behind the integrator (DrudeTGNHIntegrator.cpp:186), without stateChanged
+        if (dynamic_cast<const CMMotionRemover*>(&system.getForce(i)) != nullptr || dynamic_cast<const AndersenThermostat*>(&system.getForce(i)) != nullptr)
+            editsVelocities = true;
+    }
+    (void) editsVelocities;                                // (read under DRUDETGNH_TRUST_STATE_CHANGED only)
 
     tgnh_desc d = {};
     d.struct_size = sizeof(tgnh_desc);
@@ -64,6 +70,18 @@ void HipIntegrateDrudeTGNHStepKernel::initialize(const System& system, const Dru
     // ... with each thermostat half as one launch (velocities still never lag).  Needs this context to have the device to
     // itself while it steps: off by default (CMake option DRUDETGNH_RESIDENT_STEP), because several OpenMM contexts may share a GPU
     d.flags = TGNH_FLAG_RESIDENT_STEP;
+#endif
+#ifdef DRUDETGNH_TRUST_STATE_CHANGED
+    // The begin half of a step starts its chain from the kinetic energies the last end half's chain left (s^2 KE, Cu :574)
+    // instead of summing them again (Cu :474-488): one pass over the velocities less per step.  Exact as long as nothing writes
+    // velocities between two steps without the integrator hearing of it: Context::setVelocities and friends reach
+    // DrudeTGNHIntegrator::stateChanged (DrudeTGNHIntegrator.cpp:166-170), which execute() below forwards through
+    // integrator.isKineticEnergySumValid() -- the ONE-LINE accessor this option needs in DrudeTGNHIntegrator.h (INTEGRATION.md
+    // section 3) -- but CMMotionRemover and AndersenThermostat edit velocities in updateContextState silently, so a System that
+    // holds either keeps the reference's passes.  (A plugin Force that does the same must not be combined with this option.)
+    trustStateChanged = !editsVelocities;
+    if (trustStateChanged)
+        d.flags |= TGNH_FLAG_TRUST_STATE_CHANGED;
 #endif
     d.device = cu.getDeviceIndex();
     d.num_particles = numParticles;
@@ -107,6 +125,10 @@ void HipIntegrateDrudeTGNHStepKernel::execute(ContextImpl& context, const DrudeT
                             cu.getUseMixedPrecision() ? (void*) cu.getPosqCorrection().getDevicePointer() : nullptr,
                             (void*) cu.getVelm().getDevicePointer(), (const void*) cu.getForce().getDevicePointer(),
                             (void*) integration.getPosDelta().getDevicePointer()));
+#ifdef DRUDETGNH_TRUST_STATE_CHANGED
+    if (trustStateChanged && !integrator.isKineticEnergySumValid())     // stateChanged since the last step (DrudeTGNHIntegrator.cpp:166-170, :192)
+        check(tgnh_state_changed(handle));
+#endif
     if (cu.getAtomsWereReordered())                         // CudaDrudeTGNHKernels.cpp:344-347
         context.calcForcesAndEnergy(true, false);
     if (numConstraints == 0) {

@@ -23,6 +23,7 @@ private:
     HipContext& cu;
     tgnh_handle handle;
     int numConstraints;
+    bool trustStateChanged = false;
 };
 
 }  // namespace OpenMM

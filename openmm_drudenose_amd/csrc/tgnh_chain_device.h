@@ -93,36 +93,22 @@ __device__ __forceinline__ double fma3(const double a, const double b, const dou
     return d;
 }
 
-// exp(y) for the fast paths below: Taylor polynomials in Estrin form -- the serial chain there is bound by the
-// latency of dependent fp64 operations (~17 cycles each, measured), so depth counts: degree 7 at depth 3 for
-// |y| < 2^-6 (truncation y^8/8! < 2^-63), degree 12 at depth 4 for |y| < 2^-2 (y^13/13! < 2^-58).
-__device__ __forceinline__ double chain_exp7(const double y) {
-    const double y2 = y * y;
-    const double p0 = 1.0 + y;
-    const double p1 = fma(y, 1.0 / 6.0, 0.5);
-    const double p2 = fma(y, 1.0 / 120.0, 1.0 / 24.0);
-    const double p3 = fma(y, 1.0 / 5040.0, 1.0 / 720.0);
-    const double y4 = y2 * y2;
-    const double q0 = fma(p1, y2, p0);
-    const double q1 = fma(p3, y2, p2);
-    return fma(q1, y4, q0);
-}
-__device__ __forceinline__ double chain_exp12(const double y) {
-    const double y2 = y * y;
-    const double p0 = 1.0 + y;
-    const double p1 = fma(y, 1.0 / 6.0, 0.5);
-    const double p2 = fma(y, 1.0 / 120.0, 1.0 / 24.0);
-    const double p3 = fma(y, 1.0 / 5040.0, 1.0 / 720.0);
-    const double p4 = fma(y, 1.0 / 362880.0, 1.0 / 40320.0);
-    const double p5 = fma(y, 1.0 / 39916800.0, 1.0 / 3628800.0);
-    const double y4 = y2 * y2;
-    const double q0 = fma(p1, y2, p0);
-    const double q1 = fma(p3, y2, p2);
-    const double q2 = fma(p5, y2, p4);
-    const double y8 = y4 * y4;
-    const double r0 = fma(q1, y4, q0);
-    const double r1 = fma(y4, 1.0 / 479001600.0, q2);
-    return fma(r1, y8, r0);
+// exp(y) for |y| < 2^-4 in nine fused multiply-adds (Horner, degree 9: truncation y^10 / 10! < 2^-61): the instruction count of the depth-3 Estrin form of
+// degree 7 that stood here until round 4 (|y| < 2^-6), with four times its range.  A lone wavefront issues one fp64 instruction per ~8 cycles, 9.5 when it depends on the one before
+// (tools/micro/issue_probe.hip): the depth Estrin's form saves is worth 13 cycles an exponential, the eight instructions of the
+// wide form that a box between 2^-6 and 2^-4 no longer needs are worth 64 -- and the synthetic boxes of bench.py sit there
+// (arguments 0.02-0.03 at 32 k slots with three or ten links).
+__device__ __forceinline__ double chain_exp9(const double y) {
+    double p = 1.0 / 362880.0;
+    p = fma(p, y, 1.0 / 40320.0);
+    p = fma(p, y, 1.0 / 5040.0);
+    p = fma(p, y, 1.0 / 720.0);
+    p = fma(p, y, 1.0 / 120.0);
+    p = fma(p, y, 1.0 / 24.0);
+    p = fma(p, y, 1.0 / 6.0);
+    p = fma(p, y, 0.5);
+    p = fma(p, y, 1.0);
+    return fma(p, y, 1.0);
 }
 
 struct ChainConst {
@@ -131,7 +117,7 @@ struct ChainConst {
 };
 
 // The S sub-steps of a register-resident chain of CC >= 2 links with the exponentials that repeat taken once (see
-// chain_real_core) and no range test inside the loop: WIDE = false evaluates them with the depth-3 polynomial (|x| < 2^-6),
+// chain_real_core) and no range test inside the loop: WIDE = false evaluates them with the degree-9 polynomial (|x| < 2^-4),
 // WIDE = true with chain_exp_wide (|x| < 1).  Returns the largest |x| met; the caller repeats the call with the next wider
 // form if that left the range.  `live`: the etaMass > 0 guard of link 0 (Cu :561, :579; the Drude thermostat has none).
 template <int CC, bool WIDE>
@@ -143,12 +129,12 @@ __device__ __forceinline__ double chain_fast_loop(double* eta, double* etaDot, d
     for (int iter = 0; iter < k.S; iter++) {
 #pragma unroll
         for (int i = CC - 1; i >= 0; i--) {                          // Cu :566-571 / :607-618
-            if (i < CC - 1) { const double x = -k.dtc8 * etaDot[i + 1]; xmax = fmax(xmax, fabs(x)); ef[i] = WIDE ? chain_exp_wide(x) : chain_exp7(x); }
+            if (i < CC - 1) { const double x = -k.dtc8 * etaDot[i + 1]; xmax = fmax(xmax, fabs(x)); ef[i] = WIDE ? chain_exp_wide(x) : chain_exp9(x); }
             etaDot[i] *= ef[i];
             etaDot[i] += etaDotDot[i] * k.dtc4;
             etaDot[i] *= ef[i];
         }
-        { const double x = -k.dtc2 * etaDot[0]; xmax = fmax(xmax, fabs(x)); const double e = WIDE ? chain_exp_wide(x) : chain_exp7(x); scale *= e; ke *= e * e; }   // Cu :573-574 / :620-621
+        { const double x = -k.dtc2 * etaDot[0]; xmax = fmax(xmax, fabs(x)); const double e = WIDE ? chain_exp_wide(x) : chain_exp9(x); scale *= e; ke *= e * e; }   // Cu :573-574 / :620-621
 #pragma unroll
         for (int i = 0; i < CC; i++) eta[i] += k.dtc2 * etaDot[i];   // Cu :575-577 / :623
         if (live) etaDotDot[0] = (ke - nkbt) * invQ0;                // Cu :579-581 / :629
@@ -181,14 +167,14 @@ __device__ __forceinline__ bool chain_fast(double* eta, double* etaDot, double* 
     double x0 = fabs(k.dtc2 * etaDot[0]);
 #pragma unroll
     for (int i = 1; i < CC; i++) x0 = fmax(x0, fabs(k.dtc8 * etaDot[i]));
-    bool wide = __any(x0 >= 0.0078125);
+    bool wide = __any(x0 >= 0.03125);
     double xmax = 0.0;
     if (!wide) {
         xmax = chain_fast_loop<CC, false>(eta, etaDot, etaDotDot, etaMass, invM, k, nkbt, kbT, live, invQ0, ef_top, ke, scale);
 #ifdef TGNH_TRACE
-        if (blockIdx.x == 0) { g_chain_dbg[which] = fmax(g_chain_dbg[which], xmax); if (xmax >= 0.015625) g_chain_dbg[2 + which] += 1.0; }
+        if (blockIdx.x == 0) { g_chain_dbg[which] = fmax(g_chain_dbg[which], xmax); if (xmax >= 0.0625) g_chain_dbg[2 + which] += 1.0; }
 #endif
-        if (__builtin_expect(!__any(xmax >= 0.015625), 1)) return true;
+        if (__builtin_expect(!__any(xmax >= 0.0625), 1)) return true;
         wide = true;
     } else {
         xmax = 1.0;                                                  // (nothing run yet: fall into the wide form)

@@ -40,11 +40,15 @@ __global__ __launch_bounds__(BLOCK) void shake_kernel(const ClusterArgs a) {
     const float4* __restrict__ pcorr = reinterpret_cast<const float4*>(a.posq_corr);
     mixed4* __restrict__ velm = reinterpret_cast<mixed4*>(a.velm);
     mixed4* __restrict__ pdelta = reinterpret_cast<mixed4*>(a.pos_delta);
-    const mixed tol = (mixed)a.tol;
+    // The iteration runs in double in every precision: in single, a cluster's positions (~3 nm, ulp 2.4e-7) put the squared
+    // bond lengths within a few roundings of the 2 tol d^2 = 2e-7 nm^2 gate, and a float iteration can circle it for good
+    // (status bit 1 in one of 48 trajectories of the reference's water test, round 4) -- a property of this call-out, not of the path
+    typedef double work;
+    const work tol = (work)a.tol;
     for (int c = blockIdx.x * BLOCK + threadIdx.x; c < a.n; c += gridDim.x * BLOCK) {
         const int4 at4 = a.atoms[c];
         const int at[4] = {at4.x, at4.y, at4.z, at4.w};
-        mixed x[4][3], q[4][3], w[4];         // positions, the corrected quantity (delta or velocity), inverse masses
+        work x[4][3], q[4][3], w[4];          // positions, the corrected quantity (delta or velocity), inverse masses
         mixed4 keep[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -54,16 +58,16 @@ __global__ __launch_bounds__(BLOCK) void shake_kernel(const ClusterArgs a) {
             if (at[k] >= 0) {
                 const real4 p = posq[at[k]];
                 x[k][0] = p.x; x[k][1] = p.y; x[k][2] = p.z;
-                if (PREC == TGNH_PREC_MIXED) { const float4 cc = pcorr[at[k]]; x[k][0] += (mixed)cc.x; x[k][1] += (mixed)cc.y; x[k][2] += (mixed)cc.z; }
+                if (PREC == TGNH_PREC_MIXED) { const float4 cc = pcorr[at[k]]; x[k][0] += (work)cc.x; x[k][1] += (work)cc.y; x[k][2] += (work)cc.z; }
                 const mixed4 v = velm[at[k]];
                 w[k] = v.w;
                 if (VELOCITY) { keep[k] = v; q[k][0] = v.x; q[k][1] = v.y; q[k][2] = v.z; }
                 else { keep[k] = pdelta[at[k]]; q[k][0] = keep[k].x; q[k][1] = keep[k].y; q[k][2] = keep[k].z; }
             }
         }
-        mixed d2[6];
+        work d2[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) { const mixed d = (mixed)a.dist[(size_t)c * 6 + k]; d2[k] = d * d; }
+        for (int k = 0; k < 6; k++) { const work d = (work)a.dist[(size_t)c * 6 + k]; d2[k] = d * d; }
         bool converged = false;
         int iter = 0;
         while (!converged && iter++ < SHAKE_MAX_ITER) {
@@ -72,22 +76,22 @@ __global__ __launch_bounds__(BLOCK) void shake_kernel(const ClusterArgs a) {
             for (int k = 0; k < 6; k++) {
                 if (d2[k] > 0) {
                     const int i = PA[k], j = PB[k];
-                    const mixed rx = x[i][0] - x[j][0], ry = x[i][1] - x[j][1], rz = x[i][2] - x[j][2];
+                    const work rx = x[i][0] - x[j][0], ry = x[i][1] - x[j][1], rz = x[i][2] - x[j][2];
                     if (VELOCITY) {
-                        const mixed vx = q[i][0] - q[j][0], vy = q[i][1] - q[j][1], vz = q[i][2] - q[j][2];
-                        const mixed r2 = rx * rx + ry * ry + rz * rz, rv = rx * vx + ry * vy + rz * vz;
-                        const mixed g = rv / (r2 * (w[i] + w[j]));
+                        const work vx = q[i][0] - q[j][0], vy = q[i][1] - q[j][1], vz = q[i][2] - q[j][2];
+                        const work r2 = rx * rx + ry * ry + rz * rz, rv = rx * vx + ry * vy + rz * vz;
+                        const work g = rv / (r2 * (w[i] + w[j]));
                         if ((g < 0 ? -g : g) * (w[i] + w[j]) > tol) {
                             converged = false;
                             q[i][0] -= g * w[i] * rx; q[i][1] -= g * w[i] * ry; q[i][2] -= g * w[i] * rz;
                             q[j][0] += g * w[j] * rx; q[j][1] += g * w[j] * ry; q[j][2] += g * w[j] * rz;
                         }
                     } else {
-                        const mixed sx = rx + (q[i][0] - q[j][0]), sy = ry + (q[i][1] - q[j][1]), sz = rz + (q[i][2] - q[j][2]);
-                        const mixed diff = d2[k] - (sx * sx + sy * sy + sz * sz);
+                        const work sx = rx + (q[i][0] - q[j][0]), sy = ry + (q[i][1] - q[j][1]), sz = rz + (q[i][2] - q[j][2]);
+                        const work diff = d2[k] - (sx * sx + sy * sy + sz * sz);
                         if ((diff < 0 ? -diff : diff) > 2 * tol * d2[k]) {
                             converged = false;
-                            const mixed g = diff / (2 * (rx * sx + ry * sy + rz * sz) * (w[i] + w[j]));
+                            const work g = diff / (2 * (rx * sx + ry * sy + rz * sz) * (w[i] + w[j]));
                             q[i][0] += g * w[i] * rx; q[i][1] += g * w[i] * ry; q[i][2] += g * w[i] * rz;
                             q[j][0] -= g * w[j] * rx; q[j][1] -= g * w[j] * ry; q[j][2] -= g * w[j] * rz;
                         }
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(BLOCK) void shake_kernel(const ClusterArgs a) {
         for (int k = 0; k < 4; k++) {
             if (at[k] >= 0) {
                 mixed4 o = keep[k];
-                o.x = q[k][0]; o.y = q[k][1]; o.z = q[k][2];
+                o.x = (mixed)q[k][0]; o.y = (mixed)q[k][1]; o.z = (mixed)q[k][2];
                 if (VELOCITY) velm[at[k]] = o; else pdelta[at[k]] = o;
             }
         }

@@ -14,7 +14,21 @@
 #include <map>
 
 #include <dlfcn.h>
+#include <mutex>
+// RCCL is bound with dlopen at run time (rccl() below); of its header only five types and three enumerators are used.  A ROCm
+// install without the RCCL headers still builds this library (and the OpenMM glue): the declarations below are RCCL's ABI
+// (rccl.h: ncclUniqueId is 128 bytes, ncclSuccess = 0, ncclSum = 0, ncclFloat64 = ncclDouble = 8).
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclDouble = 8 } ncclDataType_t;
+}
+#endif
 
 #include "tgnh_internal.h"
 #ifndef TGNH_MEETING_MEM
@@ -952,13 +966,18 @@ struct Rccl {
     std::string error;
     bool ok = false;
 };
-Rccl& rccl() {
+void rccl_bind(Rccl& r);
+Rccl& rccl() {                                   // (handles of different threads may reach this at once: bound exactly once)
     static Rccl r;
-    if (r.lib || !r.error.empty()) return r;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_bind(r); });
+    return r;
+}
+void rccl_bind(Rccl& r) {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);     // the copy the process already has
     for (const char* n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (!r.lib) { r.error = std::string("RCCL not found (librccl.so.1): ") + dlerror(); return r; }
+    if (!r.lib) { r.error = std::string("RCCL not found (librccl.so.1): ") + dlerror(); return; }
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
@@ -966,7 +985,6 @@ Rccl& rccl() {
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;
     if (!r.ok) r.error = "RCCL: a required symbol is missing from librccl";
-    return r;
 }
 #define RCCL_OK(expr)                                                                                        \
     do {                                                                                                     \
@@ -999,7 +1017,10 @@ extern "C" tgnh_status tgnh_set_rccl_comm(tgnh_handle h, void* nccl_comm) {
     h->ke_carry = false;
     if (!rccl().ok) return fail(TGNH_ERR_HIP, rccl().error);
     if (h->rccl_comm) { rc = tgnh_rccl_shutdown(h); if (rc) return rc; }
-    if (!nccl_comm) { h->allreduce = nullptr; h->allreduce_user = nullptr; return TGNH_OK; }
+    if (!nccl_comm) {                                   // (a hook the caller installed with tgnh_set_allreduce is not this call's to clear)
+        if (h->allreduce == rccl_allreduce) { h->allreduce = nullptr; h->allreduce_user = nullptr; }
+        return TGNH_OK;
+    }
     h->rccl_comm = nccl_comm; h->rccl_owned = false;
     h->allreduce = rccl_allreduce; h->allreduce_user = h;
     return TGNH_OK;
@@ -1085,6 +1106,11 @@ static void note_status(tgnh_handle h, uint32_t flags) {
         h->failed = "resident step (noticed at step " + std::to_string((long long)h->step_count) + "): the launch's work-groups did "
                     "not all become resident within the time limit (TGNH_FLAG_RESIDENT_STEP needs the device to itself)";
         if (flags & 4u) h->failed += "; the waiting work-groups timed out in turn (status bits 2 and 3)";
+    } else if (flags & 16u) {
+        h->failed_code = TGNH_ERR_STATE;
+        h->failed = "kinetic-energy pass (noticed at step " + std::to_string((long long)h->step_count) + "): work-group 0 did not "
+                    "receive every work-group's row of sums within the time limit (the sums were left as NaN: nothing integrated "
+                    "on with a partial sum); the device is shared with something that keeps this launch's work-groups from running";
     } else if (flags & 4u) {
         h->failed_code = TGNH_ERR_STATE;
         h->failed = "mailbox exchange timed out (noticed at step " + std::to_string((long long)h->step_count) +
@@ -1293,9 +1319,9 @@ static ChainArgs chain_args(tgnh_handle h) {
     a.dt = h->d.step_size; a.S = h->d.drude_steps_per_real_step;
     a.dtc = a.dt / a.S; a.inv_dtc = 1.0 / a.dtc;                               // Cu :440-443
     a.realkbT = h->realkbT; a.drudekbT = h->drudekbT;
-    // chains of 5-16 links: a link per lane (chain_lanes_run) -- ten links at 32 k slots 63 us per step against 172 with LDS-resident
-    // links, at the metric size 99 against 183 (profiles/r03_chain_cost.md)
-    a.lanes = 1;
+    // chains of 5-16 links: chain_long_kernel<C>, the links in registers (round 3 ran them a link per lane, chain_lanes_run: kept
+    // behind a switch for the comparison in profiles/r04_chain_cost.md)
+    a.lanes = 0;
 #ifdef TGNH_TUNING
     if (const char* e = getenv("TGNH_CHAIN_LANES")) a.lanes = e[0] != '0';
 #endif
@@ -1392,6 +1418,14 @@ static bool resident_kind(tgnh_handle h, int kind) {
 }
 static bool resident_now(tgnh_handle h) {
     return resident_kind(h, (h->d.flags & TGNH_FLAG_DEFER_SCALE) ? 0 : 1);
+}
+
+extern "C" tgnh_status tgnh_get_resident_kernel(tgnh_handle h, int* which) {
+    CHECK_H(h);
+    if (!which) return fail(TGNH_ERR_ARG, "null out");
+    const int kind = (h->d.flags & TGNH_FLAG_DEFER_SCALE) ? 0 : 1;
+    *which = !resident_kind(h, kind) ? 0 : (kind == 0 && h->wresident_per_cu > 0) ? 2 : 1;
+    return TGNH_OK;
 }
 
 // One launch of step_kernel.  kind 0: a whole deferred step (the last step's end half + this step's begin half, both chain

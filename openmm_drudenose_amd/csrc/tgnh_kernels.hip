@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileAr
 #pragma unroll
         for (int b = 0; b < GB + 2; b++) acc[b] = 0.0;
         const bool ok = collect_rows<GB, false, TBLOCK>(a, tid, (int)gridDim.x, NT, (unsigned long long)(gen0 + 1u), acc);
-        if (!ok) atomicOr(a.status, 8u);
+        if (!ok) atomicOr(a.status, 16u);                                // a row never came (bounded polling): status bit 4, the host's failure
 #pragma unroll
         for (int b = 0; b < GB + 2; b++) {
             if (b < NT) {
@@ -1024,12 +1024,15 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void wke_kernel(const TileAr
                 if (lane == 0) s_tail[wv][b] = t;
             }
         }
-        __syncthreads();
+        // (the barrier of the hand-over doubles as the vote: incomplete sums are not left where the all-reduce and the chain
+        // would take them for kinetic energies -- NaN instead, so that nothing integrates on with a partial sum during the
+        // up to 64 steps until the host reads the status word; step_meet withholds its send in the same situation)
+        const bool all_ok = __syncthreads_and(ok ? 1 : 0) != 0;
         if (tid < NT) {
             double t = 0.0;
 #pragma unroll
             for (int k = 0; k < TBLOCK / 64; k++) t += s_tail[k][tid];
-            a.ke_red[tid] = t;
+            a.ke_red[tid] = all_ok ? t : __longlong_as_double(0x7ff8000000000000ll);
         }
         if (tid == 0) a.sync[1] = gen0 + 1u;                             // the next launch's rows carry the next tag
     }
@@ -1334,9 +1337,10 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void step_kernel(const TileA
 // wstep_kernel: step_kernel's whole deferred time step (STEP_DEFER) over WAVE tiles -- wke_kernel's structure for both passes.
 //
 // A wavefront owns <= 64 consecutive slots and a private LDS image; nothing in a pass waits for another wavefront.  What that
-// buys at shard sizes: the kernel needs half of step_kernel's registers (one slot per lane, no second copy of a 512-slot
-// tile's arrays), so 2048 work-groups = 524 k slots are resident at once instead of 393 k -- at 625 k slots five wavefronts of
-// six hold ONE tile each for the whole step -- and for a held tile the second pass starts from registers: its kicked
+// buys at shard sizes: a pass without barriers, and for a held tile a second pass that starts from registers.  The one-link
+// instantiation takes 110 (single) / 121 (mixed, double) VGPRs = 4 wavefronts per SIMD = two 512-thread work-groups per compute
+// unit: 512 work-groups = 262 144 slots are resident at once (tests/test_kernel_resources.py asserts the occupancy) -- at 625 k
+// slots a wavefront walks 2.4 tiles forward and back, at 5 M slots 19 -- and for the tile it holds across the meeting: its kicked
 // velocities, forces, index word, mass and centre-of-mass velocity are pass 1's, its partner's velocity is still in the
 // wavefront's image, its positions were fetched before the meeting.  Same meeting (step_meet), same arithmetic per slot as
 // tile_body / wke_kernel, same fixed order of every sum.  Topologies without wave tiles (a molecule longer than a wavefront,
@@ -1597,8 +1601,8 @@ __global__ __launch_bounds__(WBLOCK) void wstep_kernel(const TileArgs a) {
     const bool have = w0 < nw;                             // (a wavefront beyond the last tile only takes part in the meeting)
     int w = w0;
     // One register image: no tile is loaded ahead of the one being worked on.  What hides a tile's load latency is the other
-    // wavefronts of the SIMD -- six of them at this register count, against four with a second image (measured: the second
-    // image bought nothing at 4 per SIMD, and at 625 k slots six per SIMD means no wavefront walks more than two tiles).
+    // wavefronts of the SIMD -- four of them at this register count (a second image was measured at the same occupancy and
+    // bought nothing; it would cost the fourth wavefront today).
     // Tile bounds are scalar loads one tile ahead of their use.
     Bounds b0{}, b1{};
     WStepIn<PREC> cur;
@@ -1807,6 +1811,34 @@ __global__ __launch_bounds__(BLOCK) void chain_kernel(const ChainArgs a) {
         }
     }
     CHAIN_TRACE(2);
+}
+// Chains of 5-16 links (TGNH; ten is the reference test's value, TestReferenceDrudeTGNHIntegrator.cpp:166): a kernel per chain
+// length with the links of a thermostat in the REGISTERS of its lane, every loop unrolled -- run_tgnh<CC>, the form of the chains
+// of 2-4 links (no range test inside the loop, the exponentials that repeat within a sub-step taken once, the wide form when an
+// equilibrating box leaves the short polynomial's range).  A thermostat's half step is 2 C S link updates, each waiting for the one
+// before (the sweeps of Cu :566-571 / :586-592 bounce from end to end), run by one wavefront that issues one fp64 instruction per
+// ~8 cycles: what it costs is instructions per update.  A link per lane (chain_lanes_run, round 3) pays per update two DPP moves
+// for the neighbour's value, a range-tested exponential in EVERY lane and four conditional moves to commit in one: ~340
+// instructions per sub-step of ten links against ~150 here.  Kernels of their own so that chain_kernel's code stays what it was
+// (a launch starts with a cold instruction cache); a thermostat per lane, the Drude thermostat on the second wavefront.
+template <int CC>
+__global__ __launch_bounds__(BLOCK) void chain_long_kernel(const ChainArgs a) {
+    __shared__ double sred[BLOCK / 64][MAX_GROUPS + 2];
+    __shared__ double s_chain[2 * XCHG_MAX_WORLD * XCHG_NT_PAD > 64 ? 2 * XCHG_MAX_WORLD * XCHG_NT_PAD : 64];
+    __shared__ double s_ke[MAX_GROUPS + 2];
+    const ChainLayout& L = a.L;
+    const int NT = L.NT, tid = threadIdx.x;
+    chain_prologue(a, sred, s_chain, s_ke);
+    if (!a.do_sum) __syncthreads();
+    int itg = -1;
+    if (tid < NT - 1) itg = tid;
+    else if (tid == 64) itg = NT - 1;
+    if (itg >= 0) run_tgnh<CC>(a, a.st, a.st, true, nullptr, itg, nullptr, s_ke[itg]);
+    if (tid == 0) {                                                  // Cu :493-497
+        double s = 0.0;
+        for (int i = 0; i < NT; i++) s += s_ke[i];
+        a.st[L.off_kesum] = 0.5 * s;
+    }
 }
 #pragma clang fp contract(fast)
 
@@ -2154,6 +2186,14 @@ int tile_blocks_per_cu(int precision, int ops, int gb, size_t lds, bool multi) {
 
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
     if (!a.do_chain) TGNH_LAUNCH(rowsum_kernel, dim3(1), dim3(BLOCK), 0, s, a);
+    else if (a.L.mode == TGNH_MODE_TGNH && a.L.C > 4 && a.L.C <= 16 && !a.lanes) {
+        switch (a.L.C) {
+#define TGNH_LONG(c) case c: TGNH_LAUNCH(chain_long_kernel<c>, dim3(1), dim3(BLOCK), 0, s, a); break;
+            TGNH_LONG(5) TGNH_LONG(6) TGNH_LONG(7) TGNH_LONG(8) TGNH_LONG(9) TGNH_LONG(10) TGNH_LONG(11) TGNH_LONG(12)
+            TGNH_LONG(13) TGNH_LONG(14) TGNH_LONG(15) TGNH_LONG(16)
+#undef TGNH_LONG
+        }
+    }
     else TGNH_LAUNCH(chain_kernel, dim3(1), dim3(BLOCK), 0, s, a);
 #ifdef TGNH_TUNING
     // timing experiment only (the thermostat advances twice): the same launch again, its code now in the caches

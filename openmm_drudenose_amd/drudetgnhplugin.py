@@ -441,6 +441,12 @@ class HipContext(_HandleQueries):
         _check(self.lib.tgnh_get_resident_work_groups(self.h, C.byref(n)))
         return n.value
 
+    def resident_kernel(self):
+        """The kernel the next step_begin runs as its one launch: None, 'step_kernel' or 'wstep_kernel'."""
+        n = C.c_int()
+        _check(self.lib.tgnh_get_resident_kernel(self.h, C.byref(n)))
+        return (None, "step_kernel", "wstep_kernel")[n.value]
+
     def exchange_detach(self):
         _check(self.lib.tgnh_exchange_detach(self.h))
 

@@ -54,6 +54,13 @@ class Walk:
         _, self.rit, self.ref = build(0, None, chains, wave=wave != cross)                   # like with like, but for the one cross-kind walk
         self.flags = flags
         self.gate_v, self.gate_t = ((5e-10, dict(rtol=1e-8, atol=1e-9)) if cross else (1e-10, dict(rtol=1e-9, atol=1e-12)))
+        if flags & FLAG_TRUST_STATE_CHANGED and exchange is None and not cross:
+            # a carried bin is KE prod exp(-dtc etaDot) (Cu :574), the plain handle's is summed from the velocities again: equal to
+            # rounding, not bit for bit -- two different sums, as across the tile kinds, and the same gate: the higher links of a
+            # three-link chain amplify a rounding of etaDot_0 by Q_0 / Q_1 ~ the number of degrees of freedom (Cu :588; measured
+            # 1.3e-9 relative in the third link's etaDot after ~700 steps, 3.9e-12 absolute in eta); a sum that survived a write of
+            # the velocities shows as 1e-3
+            self.gate_t = dict(rtol=1e-8, atol=1e-9)
         self.replay = None
         self.log = []
 
@@ -182,7 +189,8 @@ class Walk:
         if not self.flags & FLAG_DEFER_SCALE:                # (deferred: the chain has run the next step's first half already)
             for which in (0, 1):
                 a, b = self.ctx.thermostat_state(which), self.ref.thermostat_state(which)
-                assert np.allclose(a, b, **self.gate_t), (where, which, self.log[-12:])
+                worst = float(np.max(np.abs(a - b) / (self.gate_t["atol"] + self.gate_t["rtol"] * np.abs(b))))
+                assert np.allclose(a, b, **self.gate_t), (where, which, worst, float(np.abs(a - b).max()), self.log[-12:])
 
     def run(self):
         names = [n for n, w in self.OPS for _ in range(w)]

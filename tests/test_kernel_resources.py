@@ -15,13 +15,15 @@ def test_hot_kernels_keep_their_occupancy():
     assert out.returncode == 0, out.stderr[-2000:]
     rows = {}
     for line in out.stdout.splitlines():
-        m = re.match(r"(\S+<[^>]*>)\s+VGPR\s+(\d+)\s+AGPR\s+\d+\s+SGPR\s+\S+\s+scratch\s+(\d+)\s+occ\s+(\d+)\s+LDS\s+\d+\s+vspill\s+(\d+)\s+stackops\s+(\d+)", line)
+        m = re.match(r"(\S+<[^>]*>)\s+VGPR\s+(\d+)\s+AGPR\s+\d+\s+SGPR\s+\S+\s+scratch\s+(\d+)\s+occ\s+(\d+)\s+LDS\s+(\d+)\s+vspill\s+(\d+)\s+stackops\s+(\d+)", line)
         if m:
-            rows[m.group(1).replace(" ", "")] = (int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)), int(m.group(6)))
+            rows[m.group(1).replace(" ", "")] = (int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(6)), int(m.group(7)), int(m.group(5)))
     assert len(rows) > 40, out.stdout[-2000:]
     # nothing may spill to memory: no vector-register spill, not one instruction that touches the stack (a few instantiations
     # report a 36-byte scratch size with neither: a slot reserved for spilled scalar registers that all went to VGPR lanes)
-    spills = {k: v for k, v in rows.items() if v[3] != 0 or v[4] != 0 or v[1] > 64}
+    # (chain_long_kernel<14..16>, one wavefront with the chain's links in registers, moves values between its vector and accumulation
+    # registers -- reported as VGPR spills, but to AGPRs: its scratch and stack counts must still be zero)
+    spills = {k: v for k, v in rows.items() if (v[3] != 0 and not k.startswith("chain_long_kernel")) or v[4] != 0 or v[1] > 64}
     assert not spills, spills
     for prec in (0, 1, 2):
         for gb in (1, 4, 8):
@@ -35,6 +37,16 @@ def test_hot_kernels_keep_their_occupancy():
                 assert rows[f"wke_kernel<{prec},{ops},{gb}>"][0] <= 102, rows[f"wke_kernel<{prec},{ops},{gb}>"]
             assert rows[f"wstep_kernel<{prec},{gb},false>"][0] <= 128, rows[f"wstep_kernel<{prec},{gb},false>"]
             assert rows[f"wstep_kernel<{prec},{gb},true>"][0] <= 256, rows[f"wstep_kernel<{prec},{gb},true>"]
+            # ... and the occupancies the comments in tgnh_kernels.hip, DESIGN.md and profiles/ rely on, as the compiler reports
+            # them (wavefronts per SIMD): wstep_kernel 4 = two 512-thread work-groups per compute unit = 512 work-groups = 262 144
+            # slots resident at once on 256 CUs, whose LDS (images + pattern constants) must fit twice into a CU's 160 KiB;
+            # the KE passes at >= 5
+            w = rows[f"wstep_kernel<{prec},{gb},false>"]
+            assert w[2] == 4 and 2 * w[5] <= 160 * 1024, w
+            assert rows[f"wstep_kernel<{prec},{gb},true>"][2] == 2
+            for ops in (8, 10, 138):
+                k = rows[f"wke_kernel<{prec},{ops},{gb}>"]
+                assert k[2] >= 5 and k[2] * k[5] <= 160 * 1024, k      # (4 wavefronts per work-group: occupancy = work-groups per CU)
         for ops in (1, 7, 71, 65, 19):          # the rescale launches: one-link chains at 3 work-groups per CU, 2-4 links at 2
             assert rows[f"tile_kernel<{prec},{ops},1,false>"][0] <= 168, (prec, ops)
             assert rows[f"tile_kernel<{prec},{ops},1,true>"][0] <= 256, (prec, ops)
