@@ -48,13 +48,13 @@ def parse():
     p.add_argument("--molecules", type=int, default=1_000_000, help="SWM4 molecules = Drude pairs (metric: 1,000,000)")
     p.add_argument("--precision", default="mixed", choices=["single", "mixed", "double"])
     p.add_argument("--mode", default="TGNH", choices=["TGNH", "dualNH"])
-    p.add_argument("--variant", default="auto", choices=["auto", "plain", "plain-trust", "plain-resident", "defer", "resident"],
+    p.add_argument("--variant", default="auto", choices=["auto", "plain", "plain-trust", "plain-resident", "plain-resident-trust", "defer", "resident"],
                    help="defer = end-of-step rescale and second half kick folded into the next step's first pass; resident = "
                         "defer with the whole step in ONE launch whose work-groups meet on the device (step_kernel; with the "
                         "RCCL hook it steps the defer way); plain = the reference's pass structure; plain-trust = that structure with "
                         "TGNH_FLAG_TRUST_STATE_CHANGED (the begin half starts its chain from the kinetic energies the last end half "
                         "left: no KE pass; what the OpenMM glue runs for a System without CMMotionRemover / AndersenThermostat); "
-                        "plain-resident = the plain structure with each thermostat half one step_kernel launch; "
+                        "plain-resident = the plain structure with each thermostat half one step_kernel launch; plain-resident-trust = both; "
                         "auto = resident (single precision from 3 M slots per GPU: defer) (DESIGN.md)")
     p.add_argument("--chains", type=int, default=1)
     p.add_argument("--drude-steps", type=int, default=20, help="drudeStepsPerRealStep (reference default 20)")
@@ -72,9 +72,19 @@ def parse():
                    help="internal: this process is a child rank that measures the non-headline exchange of a sharded run "
                         "(--exchange names it) and prints its record; started by the ranks of the main run, see side_leg_in_children")
     p.add_argument("--side-leg-timeout", type=float, default=180.0, help="seconds the main run gives its side-leg children")
+    p.add_argument("--probe-rccl-site", action="store_true",
+                   help="internal: this process is a child rank that tries the library's own RCCL site (tgnh_rccl_init: a communicator "
+                        "of its own, ncclAllReduce enqueued by the library) on a small sharded box and prints whether it worked; started "
+                        "by the ranks of a sharded run before they commit to it, see probe_rccl_site_in_children")
+    p.add_argument("--probe-timeout", type=float, default=90.0, help="seconds the main run gives the RCCL-site probe")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the extra single-precision / variant legs")
     return p.parse_args()
+
+
+# Whether the ranks of a sharded run may use the library's own RCCL site (tgnh_rccl_init): None = not probed (one rank: a one-rank
+# communicator is what the GPU suite tests), True / False = what probe_rccl_site_in_children found on this node.
+RCCL_SITE_OK = None
 
 
 def build_context(args, system, group, ngroups, rank, world, precision, variant):
@@ -85,7 +95,8 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
     from openmm_drudenose_amd.system import shard_bounds
     it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, args.drude_steps, args.chains, True, True)
     it.setMaxDrudeDistance(args.hardwall)
-    flags = {"plain": 0, "plain-trust": FLAG_TRUST_STATE_CHANGED, "plain-resident": FLAG_RESIDENT_STEP, "defer": FLAG_DEFER_SCALE,
+    flags = {"plain": 0, "plain-trust": FLAG_TRUST_STATE_CHANGED, "plain-resident": FLAG_RESIDENT_STEP,
+             "plain-resident-trust": FLAG_RESIDENT_STEP | FLAG_TRUST_STATE_CHANGED, "defer": FLAG_DEFER_SCALE,
              "resident": FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP}[variant]
     local, lgroup = system, group
     if world > 1:
@@ -114,7 +125,7 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
         # through the process group); the torch.distributed hook set above stays only if that cannot be had -- a rehearsal
         # with several ranks on one device (RCCL refuses a device twice) or a gloo group.
         native = "TGNH_BENCH_DEVICE" not in os.environ and os.environ.get("TGNH_BENCH_BACKEND", "nccl") == "nccl" \
-            and os.environ.get("TGNH_BENCH_RCCL", "library") == "library"
+            and os.environ.get("TGNH_BENCH_RCCL", "library") == "library" and (RCCL_SITE_OK is True or (world == 1 and RCCL_SITE_OK is None))
         ctx.rccl_site = "library (ncclAllReduce enqueued by libdrudetgnh_hip)" if native and ctx.rccl_init_over(dist, rank, world) \
             else "torch.distributed.all_reduce through the tgnh_set_allreduce hook"
     if world > 1 and "TGNH_BENCH_DEVICE" in os.environ:
@@ -219,7 +230,7 @@ def per_rank_exchange_report(ctx, exchange, world):
 def dominant_kid(variant):
     """the launch that carries most of a step: step_kernel (resident) or the fused rescale + half kick + drift pass"""
     from openmm_drudenose_amd import _lib
-    return _lib.KID_STEP if variant in ("resident", "plain-resident") else _lib.KID_SKD
+    return _lib.KID_STEP if variant in ("resident", "plain-resident") else _lib.KID_SKD      # (plain-resident-trust: the begin half is the tile launch)
 
 
 def timed_run(ctx, steps, warmup, world, graph_steps=0, dom_kid=0):
@@ -434,18 +445,7 @@ def side_leg_in_children(args, other, rank, world, argv):
     # (under torchrun the ranks' rendezvous is the agent's store; the children make their own on the new port)
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]))
-    drop = ("--side-leg", "--exchange", "--no-extra")
-    keep, skip = [], False
-    for a in argv:                                     # the main run's own arguments, minus what the child sets itself
-        if skip:
-            skip = False
-            continue
-        if a in drop:
-            skip = a == "--exchange"
-            continue
-        if a.startswith("--exchange="):
-            continue
-        keep.append(a)
+    keep = child_argv(argv, ("--side-leg", "--no-extra", "--probe-rccl-site"), ("--exchange",))
     cmd = [sys.executable, os.path.abspath(__file__)] + keep + ["--exchange", other, "--side-leg", "--no-cpu-baseline"]
     info = {"measured_by": "child ranks with a process group of their own"}
     try:
@@ -466,6 +466,81 @@ def side_leg_in_children(args, other, rank, world, argv):
         info["failed"] = "; ".join(bad)
         info["steps_per_s"] = None
     return info
+
+
+def child_argv(argv, drop_flags, drop_valued):
+    """the main run's own arguments minus what a child sets itself"""
+    keep, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a in drop_flags:
+            continue
+        if a in drop_valued:
+            skip = True
+            continue
+        if any(a.startswith(v + "=") for v in drop_valued):
+            continue
+        keep.append(a)
+    return keep
+
+
+def probe_rccl_site_in_children(args, rank, world, argv):
+    """Before the ranks of a sharded run commit to the library's own RCCL site, child processes try it: ncclCommInitRank is
+    collective, so a rank on which it fails or blocks would leave its peers inside it for good, with the headline record lost.
+    One child per rank, a process group of their own, a small sharded box stepped eagerly and from a hipGraph through
+    tgnh_rccl_init; the parents only wait (bounded).  Every rank returns the same verdict: True = the site works across
+    these devices, False = the headline uses torch.distributed's all_reduce through the hook (the same RCCL, torch's site)."""
+    import subprocess
+    import torch.distributed as dist
+    port = [free_port() if rank == 0 else None]
+    dist.broadcast_object_list(port, src=0)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]))
+    cmd = [sys.executable, os.path.abspath(__file__)] + child_argv(argv, ("--side-leg", "--no-extra", "--probe-rccl-site"), ("--exchange",)) \
+        + ["--probe-rccl-site", "--no-cpu-baseline", "--no-extra"]
+    ok, why = False, None
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, timeout=args.probe_timeout)
+        lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if p.returncode == 0 and (rank != 0 or (lines and json.loads(lines[-1]).get("rccl_site_ok") is True)):
+            ok = True
+        else:
+            why = f"child rank {rank} ended with exit code {p.returncode}" + ("" if rank != 0 or lines else ", no verdict")
+    except subprocess.TimeoutExpired:
+        why = f"child rank {rank} did not finish within {args.probe_timeout:.0f} s and was stopped"
+    votes = [None] * world
+    dist.all_gather_object(votes, (ok, why))
+    bad = [w for o, w in votes if not o]
+    if bad and rank == 0:
+        print("[bench] the library's RCCL site did not pass its probe (" + "; ".join(str(b) for b in bad) + "): torch.distributed's all_reduce through the hook", file=sys.stderr)
+    return not bad
+
+
+def rccl_site_probe(args, system_unused, rank, world):
+    """the child's side of probe_rccl_site_in_children"""
+    import torch
+    import torch.distributed as dist
+    from openmm_drudenose_amd import synth
+    global RCCL_SITE_OK
+    RCCL_SITE_OK = True                                # (this IS the probe: take the site)
+    system, group, ngroups = synth.water_box(2500 * world)
+    ctx = build_context(args, system, group, ngroups, rank, world, args.precision, "defer")
+    good = ctx.rccl_site is not None and ctx.rccl_site.startswith("library")
+    if good:
+        ctx.step(20)
+        replay = ctx.capture_steps(5)
+        for _ in range(4):
+            replay()
+        torch.cuda.synchronize()
+        eta = torch.from_numpy(np.concatenate([ctx.thermostat_state(0), ctx.thermostat_state(1)])).to(CDEV)
+        every = [torch.empty_like(eta) for _ in range(world)]
+        dist.all_gather(every, eta)
+        good = bool(torch.isfinite(eta).all()) and all(torch.equal(every[0], e) for e in every) and ctx.check() == 0
+    good = all_ranks_agree(good)
+    close_sharded(ctx)
+    return good
 
 
 def dry_launch(args, world, rank):
@@ -494,7 +569,8 @@ def step_model_bytes(num_slots, precision, variant):
     V = 16 if precision == "single" else 32
     X = 16 if precision == "single" else 32
     F = 24
-    per = {"plain": 7 * V + 2 * F + 2 * X, "plain-trust": 6 * V + 2 * F + 2 * X, "plain-resident": 6 * V + 3 * F + 2 * X, "defer": 3 * V + 2 * F + 2 * X,
+    per = {"plain": 7 * V + 2 * F + 2 * X, "plain-trust": 6 * V + 2 * F + 2 * X, "plain-resident": 6 * V + 3 * F + 2 * X,
+           "plain-resident-trust": 5 * V + 3 * F + 2 * X, "defer": 3 * V + 2 * F + 2 * X,
            "resident": 3 * V + 2 * F + 2 * X}[variant]
     return num_slots * per
 
@@ -540,6 +616,15 @@ def main():
         ranks_met = int(t.item())
         if ranks_met != args.gpus or dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but {ranks_met} ranks met in the process group")
+
+    global RCCL_SITE_OK
+    if args.probe_rccl_site:                           # a child rank of probe_rccl_site_in_children: try, report, done
+        good = rccl_site_probe(args, None, rank, world)
+        if rank == 0:
+            os.write(real_stdout, (json.dumps({"rccl_site_ok": bool(good)}) + "\n").encode())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
     from openmm_drudenose_amd import synth, _lib
     system, group, ngroups = synth.water_box(args.molecules)
@@ -587,6 +672,11 @@ def main():
                 info["attached"] = False
         return info
 
+    # (TGNH_BENCH_PROBE=1: the probe also on one rank, for tests/test_bench_sharded_gpu.py -- a one-GPU box cannot hold two RCCL ranks)
+    if use_dist and (world > 1 or os.environ.get("TGNH_BENCH_PROBE") == "1") and BACKEND == "nccl" and "TGNH_BENCH_DEVICE" not in os.environ \
+            and os.environ.get("TGNH_BENCH_RCCL", "library") == "library":
+        # (a side-leg child measuring the RCCL exchange probes like the main run would; one measuring the mailboxes never takes the site)
+        RCCL_SITE_OK = probe_rccl_site_in_children(args, rank, world, sys.argv[1:]) if args.exchange == "rccl" else False
     if args.side_leg:                                  # a child rank of side_leg_in_children: measure, report, done
         info = side_leg(args.exchange)
         if rank == 0:
@@ -642,7 +732,7 @@ def main():
     if mailbox_info:
         extra["mailbox"] = dict(extra.get("mailbox", {}), **mailbox_info)
     if world == 1 and not args.no_extra:
-        for prec, var in ((args.precision, "plain"), (args.precision, "plain-trust"), (args.precision, "plain-resident"), (args.precision, "defer"), (args.precision, "resident"),
+        for prec, var in ((args.precision, "plain"), (args.precision, "plain-trust"), (args.precision, "plain-resident"), (args.precision, "plain-resident-trust"), (args.precision, "defer"), (args.precision, "resident"),
                           ("single", "defer" if system.num_particles / world >= 3_000_000 else args.variant)):
             if (prec, var) == (args.precision, args.variant):
                 continue
@@ -677,11 +767,12 @@ def main():
                             f"{args.mode} mode, {args.precision} precision, numNHChains={args.chains}, hard wall "
                             f"{args.hardwall} nm, harness force call-out inside the timed region",
                 "precision": args.precision, "variant": args.variant,
-                "variant_ran": args.variant if dkid == dominant_kid(args.variant) else {"resident": "defer", "plain-resident": "plain"}.get(args.variant, args.variant),
+                "variant_ran": args.variant if dkid == dominant_kid(args.variant) else {"resident": "defer", "plain-resident": "plain", "plain-resident-trust": "plain-trust"}.get(args.variant, args.variant),
                 "hipgraph": graph_used,
                 "parallelism": f"particle-sharded x{world} (whole molecules), one KE all-reduce per step",
                 "exchange": exchange_used, "rccl_ranks": ranks_met if use_dist else None,
                 "rccl_site": rccl_site if exchange_used == "rccl" else None,
+                "rccl_site_probe": RCCL_SITE_OK,          # what child ranks found when they tried the library's site first (None: not probed)
                 "per_rank": headline_ranks,
                 "slots_per_gpu": local_slots,
                 "model_bytes_per_step": b_step,

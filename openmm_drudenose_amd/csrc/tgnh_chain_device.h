@@ -647,8 +647,14 @@ __device__ __forceinline__ void chain1_finish(const ChainArgs& a, const Chain1Re
             // Which polynomial: the short one while every |y| stays below 2^-6 -- a thermostat near equilibrium --, chain_exp_wide
             // (|y| < 1) otherwise.  Chosen for the whole wavefront from the exponents at entry (with a factor two of room) and
             // checked after the loop: leaving the chosen range costs a second pass, it is never wrong.
-            bool wide = __any(((unsigned)__double2hiint(y_0) & 0x7fffffffu) >= 0x3f800000u);          // some |y_0| >= 2^-7
-            if (!wide) {
+            // (round 4: a middle form, degree 9 for |y| < 2^-4 in 9 fmas.  A box that starts away from equilibrium -- every fresh
+            // context of bench.py, for its first ~40 steps -- sits between 2^-7 and 2^-5 and paid the wide form's 17 instructions
+            // per sub-step: 197 against 190 us per launch at the metric size exactly in the window the driver's 20-step run times,
+            // tools/micro/first_steps.py.)
+            const unsigned ay0 = (unsigned)__double2hiint(y_0) & 0x7fffffffu;
+            int form = __any(ay0 >= 0x3fa00000u) ? 2 : __any(ay0 >= 0x3f800000u) ? 1 : 0;              // some |y_0| >= 2^-5 / >= 2^-7
+            bool wide = form == 2;
+            if (form == 0) {
                 const double k720 = 1.0 / 720.0, k120 = 1.0 / 120.0, k24 = 1.0 / 24.0, k6 = 1.0 / 6.0;
                 for (int iter = 0; iter < a.S; iter++) {
                     ymax = max(ymax, (unsigned)__double2hiint(y) & 0x7fffffffu);     // two 32-bit operations (fmax on doubles: three fp64 ones)
@@ -663,7 +669,19 @@ __device__ __forceinline__ void chain1_finish(const ChainArgs& a, const Chain1Re
                     edd = fma3(ke, invQ0, c0);                           // Cu :579-581, :629
                     y = fma3(edd, ky, y);                                // Cu :583-585 / :630-632 and the next :568-570
                 }
-                if (__builtin_expect(__any(ymax >= 0x3f900000u), 0)) {   // some |y| >= 2^-6: again, with the long polynomial
+                if (__builtin_expect(__any(ymax >= 0x3f900000u), 0)) {   // some |y| >= 2^-6: again, with the next polynomial
+                    ke = ke_0; y = y_0; sy = 0.0; ymax = 0u; form = 1;
+                }
+            }
+            if (form == 1) {
+                for (int iter = 0; iter < a.S; iter++) {
+                    ymax = max(ymax, (unsigned)__double2hiint(y) & 0x7fffffffu);
+                    ke *= chain_exp9(y);
+                    sy += y;
+                    edd = fma3(ke, invQ0, c0);
+                    y = fma3(edd, ky, y);
+                }
+                if (__builtin_expect(__any(ymax >= 0x3fb00000u), 0)) {   // some |y| >= 2^-4: again, with the long polynomial
                     ke = ke_0; y = y_0; sy = 0.0; ymax = 0u; wide = true;
                 }
             }

@@ -1832,8 +1832,8 @@ extern "C" tgnh_status tgnh_get_topology_len(tgnh_handle h, int which, int* len)
     if (which == 8) { *len = (int)h->meta.size(); return TGNH_OK; }
     if (which == 9) { *len = 2 * (int)h->wave_tile.size(); return TGNH_OK; }      // wave tiles: (first slot, largest molecule) pairs, one more than tiles; 0 = none
     if (which == 10) { *len = (int)h->wmeta.size(); return TGNH_OK; }
-    if (which == 11) { *len = (int)h->tile_pat.size(); return TGNH_OK; }        // per 512-slot tile: period | pattern << 8 (0: per-slot words)
-    if (which == 12) { *len = (int)h->wtile_pat.size(); return TGNH_OK; }       // ... per wave tile
+    if (which == 11) { *len = (int)h->tile_pat.size(); return TGNH_OK; }        // per 512-slot tile: period | molecules per period << 8 | pattern << 16 (0: per-slot words)
+    if (which == 12) { *len = (int)h->wtile_pat.size(); return TGNH_OK; }       // per wave tile: period | pattern << 8
     if (which == 13) { *len = (int)h->pattern.size(); return TGNH_OK; }         // the patterns, 64 words each
     if (which == 14) { *len = (int)h->wpattern.size(); return TGNH_OK; }
     const std::vector<int>* v = topo_vec(h, which);

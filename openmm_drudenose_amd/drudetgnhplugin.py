@@ -381,18 +381,23 @@ class HipContext(_HandleQueries):
     def rccl_init_over(self, dist, rank, world):
         """The library's communicator set up through a torch.distributed process group (which only carries the 128-byte id):
         all ranks return True (the library enqueues ncclAllReduce itself from now on) or all return False (nothing changed)."""
-        torch = self.torch
         ok, err = 1, None
         ids = [None]
+        # ncclCommInitRank is collective: a rank that cannot even bind RCCL must say so BEFORE anybody enters it, or its peers
+        # wait inside it for good.  Every rank therefore makes an id of its own first (binds the library, not collective) and
+        # the ranks vote; only rank 0's id is used.
         try:
+            mine = self.rccl_unique_id()
             if rank == 0:
-                ids[0] = self.rccl_unique_id()
+                ids[0] = mine
         except Exception as e:                      # noqa: BLE001
-            ids[0], err = None, e
-        dist.broadcast_object_list(ids, src=0)
-        if ids[0] is None:
-            self.rccl_error = err or RuntimeError("rank 0 could not create an RCCL id")
+            ok, err = 0, e
+        votes = [None] * world
+        dist.all_gather_object(votes, ok)
+        if not all(votes):
+            self.rccl_error = err or RuntimeError("RCCL could not be bound on rank(s) " + str([r for r, v in enumerate(votes) if not v]))
             return False
+        dist.broadcast_object_list(ids, src=0)
         try:
             self.rccl_init(world, rank, ids[0])
         except Exception as e:                      # noqa: BLE001

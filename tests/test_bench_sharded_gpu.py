@@ -47,3 +47,28 @@ def test_a_side_leg_that_dies_does_not_take_the_headline_with_it():
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["exchange"] == "rccl"
     mb = j["extra"]["mailbox"]
     assert mb["steps_per_s"] is None and "stopped" in mb["failed"]
+
+
+def _bench_nccl(argv, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(TGNH_FORCE_DIST="1", TGNH_BENCH_PROBE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29533")
+    e.update(env)
+    return subprocess.run([sys.executable, BENCH] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=600)
+
+
+@pytest.mark.gpu
+def test_the_rccl_site_is_probed_by_children_before_the_ranks_commit_to_it():
+    """ncclCommInitRank is collective: a rank on which the library's own RCCL site fails or blocks would leave its peers inside it.
+    A sharded bench.py therefore lets CHILD ranks try the site first (a small box, eagerly and from a hipGraph, thermostats compared
+    over the ranks) and takes it only when they all came back in time.  One rank here (a one-GPU box cannot hold two RCCL ranks:
+    TGNH_BENCH_PROBE=1 runs the same plumbing): the probe passes and the headline uses the library's site; with no time given to the
+    children it fails and the headline still comes out, through torch.distributed's all_reduce."""
+    p = _bench_nccl(["--molecules", "20000", "--steps", "50", "--warmup", "5", "--no-extra", "--no-cpu-baseline"])
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    j = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert j["config"]["rccl_site_probe"] is True and j["config"]["rccl_site"].startswith("library") and j["value"] > 0
+    p = _bench_nccl(["--molecules", "20000", "--steps", "50", "--warmup", "5", "--no-extra", "--no-cpu-baseline", "--probe-timeout", "0.001"],
+                    MASTER_PORT="29534")
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    j = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert j["config"]["rccl_site_probe"] is False and j["config"]["rccl_site"].startswith("torch.distributed") and j["value"] > 0

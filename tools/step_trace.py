@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase timeline of step_kernel (tuning build with -DTGNH_TRACE -DTGNH_TUNING):
    python tools/build_variant.py build_variants/lib_trace.so -DTGNH_TRACE -DTGNH_TUNING
-   TGNH_LIB=build_variants/lib_trace.so python tools/step_trace.py [molecules ...]
+   TGNH_LIB=build_variants/lib_trace.so python tools/step_trace.py [--precision single|mixed|double] [molecules ...]
 Slots: 0 entry, 1 pass 1 done, 2 row handed in, 7 (work-group 0) rows collected, 8 sums received, 9 chain done,
 15 exit (pass 2 done).  Times in us from the first work-group's entry."""
 import ctypes as C, os, sys
@@ -12,11 +12,15 @@ from openmm_drudenose_amd.drudetgnhplugin import DrudeTGNHIntegrator, HipContext
 
 NAMES = {0: "entry", 1: "pass 1 done", 2: "row handed in", 6: "poll starts*", 10: "rows all seen*", 7: "rows collected*", 13: "sums sent*", 14: "chain loop 1 in", 11: "chain loop 2 out", 12: "chain out", 8: "sums received", 9: "chain done",
          3: "p1 t0 data in", 4: "p1 t0 prepared", 5: "p2 t0 pre-store", 15: "exit"}
-for mol in [int(x) for x in sys.argv[1:]] or [125000]:
+argv = sys.argv[1:]
+precision = "mixed"
+if argv and argv[0] == "--precision":
+    precision, argv = argv[1], argv[2:]
+for mol in [int(x) for x in argv] or [125000]:
     s, g, ng = synth.water_box(mol)
     it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, 1, True, True)
     it.setMaxDrudeDistance(0.02)
-    ctx = HipContext(s, it, mode="TGNH", precision="mixed", flags=FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP)
+    ctx = HipContext(s, it, mode="TGNH", precision=precision, flags=FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP)
     lib = _lib.load()
     it.step(50)
     import torch
@@ -31,7 +35,7 @@ for mol in [int(x) for x in sys.argv[1:]] or [125000]:
         live = tr[:, 0] > 0
         tr = tr[live]
         base = tr[:, 0].min()
-        print(f"--- {mol} molecules, step_kernel: {live.sum()} work-groups, span {(tr[:, 15].max() - base) / 100:.2f} us")
+        print(f"--- {mol} molecules, {precision}, {ctx.resident_kernel()}: {live.sum()} work-groups, span {(tr[:, 15].max() - base) / 100:.2f} us")
         for sl in (0, 3, 4, 1, 2, 6, 10, 7, 13, 8, 14, 11, 12, 9, 5, 15):
             col = tr[:, sl]
             m = col >= base
