@@ -1677,6 +1677,8 @@ RESIDENT_DEFER = FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP
     ("dualNH", FLAG_DEFER_SCALE, "mixed"),
     ("TGNH", 0, "mixed"),                    # the reference's pass structure (what the OpenMM glue runs)
     ("TGNH", FLAG_RESIDENT_STEP, "mixed"),   # ... with each thermostat half one step_kernel launch
+    ("TGNH", FLAG_TRUST_STATE_CHANGED, "mixed"),                        # ... without the begin half's KE pass (bench.py's plain-trust leg)
+    ("TGNH", FLAG_TRUST_STATE_CHANGED | FLAG_RESIDENT_STEP, "mixed"),   # ... and the end half as one launch (plain-resident-trust)
 ])
 def test_full_size_steps_against_the_oracle(mode, flags, precision):
     """The metric configuration itself against the oracle directly, through every launch structure bench.py times: a few steps
@@ -1700,6 +1702,11 @@ def test_full_size_steps_against_the_oracle(mode, flags, precision):
         assert nstep >= 2                   # it really was wstep_kernel: steps 2 and 3 (the first step has no end half to fold in)
     elif flags == FLAG_RESIDENT_STEP:
         assert nstep >= 6                   # both halves of every step
+    elif flags == FLAG_TRUST_STATE_CHANGED | FLAG_RESIDENT_STEP:
+        assert nstep == 4                   # the first step's begin half and every end half; steps 2 and 3 begin from the carried sums
+        assert ctx.timing_read(_lib.KID_KE)[1] == 0
+    elif flags == FLAG_TRUST_STATE_CHANGED:
+        assert nstep == 0 and ctx.timing_read(_lib.KID_KE)[1] == 1      # one KE pass in all: the first step's
     else:
         assert nstep == 0
     if precision == "single":               # float4 state against the fp64 oracle: test_single_precision_deviation's figures

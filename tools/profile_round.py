@@ -106,8 +106,8 @@ def main():
     shutil.copy(stats, os.path.join(prof, f"{a.tag}_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats)))
     prec = line["config"]["precision"]
-    if line["roofline"]["kernel"] == "step_kernel":
-        dom = f"wstep_kernel<{prec},deferred step>" if variant == "resident" else f"step_kernel<{prec},plain begin half>"
+    if line["roofline"]["kernel"] in ("step_kernel", "wstep_kernel"):        # (bench.py names the kernel that ran: tgnh_get_resident_kernel)
+        dom = f"{line['roofline']['kernel']}<{prec},deferred step>" if variant == "resident" else f"step_kernel<{prec},plain begin half>"
     else:
         dom = f"tile<{prec},{'prekick+' if variant == 'defer' else ''}rescale+kick+drift>"
     with open(os.path.join(prof, f"{a.tag}_summary.md"), "w") as f:
