@@ -320,6 +320,16 @@ tgnh_status tgnh_harness_force(tgnh_handle h, const void* x0, double k_drude, do
  * and one byte per slot in place of the meta word.  Afterwards tgnh_harness_force / tgnh_run_harness* accept x0 = NULL
  * and read the packed form (the same forces bit for bit). */
 tgnh_status tgnh_harness_pack_sites(tgnh_handle h, const void* x0);
+/* A hint for the next tgnh_harness_pack_sites: the box repeats one molecule of `mol_slots` slots (<= 64) on a simple cubic lattice --
+ * this handle's molecule j is molecule m = first_molecule + j of the box (a shard starts in the middle of it), at
+ * (m / side^2, (m / side) mod side, m mod side) x spacing, slot k of it at that point + geom[k] (doubles [mol_slots][3]),
+ * rounded once to the position type -- as the synthetic water boxes are built.  pack_sites CHECKS every tethered site against that
+ * formula, bit for bit, and every slot's role / partner / tether flag against molecule 0's; if all hold, the force kernel forms
+ * sites and flags from the slot index and reads nothing but positions (56 B per slot in mixed precision: what it must read and
+ * write anyway; 65 B with packed sites); if not, the hint is dropped and the sites are packed as before.  mol_slots = 0 clears it. */
+tgnh_status tgnh_harness_lattice_hint(tgnh_handle h, int mol_slots, int side, double spacing, const double* geom, int first_molecule);
+/* 0 explicit x0 / nothing packed yet, 1 packed sites, 2 lattice sites (what the last tgnh_harness_pack_sites ended in). */
+tgnh_status tgnh_harness_sites_kind(tgnh_handle h, int* kind);
 /* nsteps x { step_begin, harness force into the bound force buffer, step_end }
  * enqueued back to back with no host synchronisation. */
 tgnh_status tgnh_run_harness(tgnh_handle h, const void* x0, double k_drude, double k_tether,

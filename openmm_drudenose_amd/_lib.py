@@ -89,6 +89,8 @@ SIGNATURES = {
     "tgnh_half_kick": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tgnh_harness_force": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "tgnh_harness_pack_sites": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tgnh_harness_lattice_hint": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, c_f64p, C.c_int]),
+    "tgnh_harness_sites_kind": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "tgnh_run_harness": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "tgnh_harness_set_clusters": (C.c_int, [C.c_void_p, C.c_int, c_i32p, c_f64p]),
     "tgnh_harness_shake_positions": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),

@@ -530,6 +530,7 @@ static void free_device(tgnh_context* c) {
     if (c->d_sflag) (void)hipFree(c->d_sflag);
     if (c->d_sbase) (void)hipFree(c->d_sbase);
     if (c->d_sites) (void)hipFree(c->d_sites);
+    if (c->d_lat_tab) (void)hipFree(c->d_lat_tab);
     if (c->d_big_table) (void)hipFree(c->d_big_table);
     if (c->d_big_com) (void)hipFree(c->d_big_com);
     if (c->d_partials) (void)hipFree(c->d_partials);
@@ -1885,10 +1886,13 @@ extern "C" tgnh_status tgnh_harness_force(tgnh_handle h, const void* x0, double 
                                           void* force_out, void* stream) {
     tgnh_status rc = entry(h, true); if (rc) return rc;
     if (!force_out) return fail(TGNH_ERR_ARG, "null force_out");
-    if (!x0 && !h->d_sflag) return fail(TGNH_ERR_ARG, "null x0 and no packed sites (tgnh_harness_pack_sites)");
+    if (!x0 && !h->d_sflag && !h->lat_on) return fail(TGNH_ERR_ARG, "null x0 and no packed sites (tgnh_harness_pack_sites)");
     ForceArgs a{};
     a.posq = h->posq; a.posq_corr = h->posq_corr; a.x0 = x0; a.meta = h->d_meta;
-    if (!x0) { a.sflag = h->d_sflag; a.sbase = h->d_sbase; a.sites = h->d_sites; }
+    if (!x0 && h->lat_on) {
+        a.lat_k = h->lat_k; a.lat_side = h->lat_side; a.lat_mol0 = h->lat_mol0; a.lat_spacing = h->lat_spacing; a.lat_tab = h->d_lat_tab;
+        a.lat_inv_k = 1.0 / h->lat_k; a.lat_inv_side = 1.0 / h->lat_side; a.lat_inv_side2 = 1.0 / ((double)h->lat_side * h->lat_side);
+    } else if (!x0) { a.sflag = h->d_sflag; a.sbase = h->d_sbase; a.sites = h->d_sites; }
     a.force = reinterpret_cast<long long*>(force_out);
     a.n = h->d.num_particles; a.padded = h->d.padded_num_particles;
     a.k_drude = k_drude; a.k_tether = k_tether;
@@ -1928,12 +1932,56 @@ extern "C" tgnh_status tgnh_harness_pack_sites(tgnh_handle h, const void* x0) {
     if (h->d_sbase) (void)hipFree(h->d_sbase);
     if (h->d_sites) (void)hipFree(h->d_sites);
     h->d_sflag = nullptr; h->d_sbase = nullptr; h->d_sites = nullptr;
+    h->lat_on = false;
+    if (h->lat_k > 0) {
+        // The hint (tgnh_harness_lattice_hint) is taken only if it reproduces what was just packed: every slot's byte is molecule
+        // 0's, every tethered site is fl(fl64(lattice index x spacing) + geom) in the position type -- the arithmetic of the kernel
+        const int k = h->lat_k, side = h->lat_side;
+        bool ok = N > 0 && N % k == 0 && (long long)side * side * side >= (long long)h->lat_mol0 + N / k;
+        for (int i = 0; i < N && ok; i++) {
+            const int pos = i % k, mol = h->lat_mol0 + i / k;
+            ok = flag[i] == flag[pos] && (flag[i] >> 3) != 0;         // (a partner more than 15 slots away reads the meta word: not here)
+            if (ok && (flag[i] & 4u)) {
+                const int idx[3] = {mol / (side * side), (mol / side) % side, mol % side};
+                const unsigned char* rec = raw.data() + (size_t)i * 4 * rs;
+                for (int ax = 0; ax < 3 && ok; ax++) {
+                    volatile double c = (double)idx[ax] * h->lat_spacing;          // (two roundings, as numpy's: no contraction)
+                    const double v = c + h->lat_geom[(size_t)pos * 3 + ax];
+                    ok = rs == sizeof(double) ? reinterpret_cast<const double*>(rec)[ax] == v : reinterpret_cast<const float*>(rec)[ax] == (float)v;
+                }
+            }
+        }
+        if (ok) {
+            std::vector<unsigned char> tab(LAT_TAB_BYTES, 0);
+            std::memcpy(tab.data(), flag.data(), (size_t)k);
+            std::memcpy(tab.data() + 64, h->lat_geom.data(), sizeof(double) * 3 * (size_t)k);
+            if (!h->d_lat_tab) HIP_OK(hipMalloc(&h->d_lat_tab, LAT_TAB_BYTES));
+            HIP_OK(hipMemcpy(h->d_lat_tab, tab.data(), LAT_TAB_BYTES, hipMemcpyHostToDevice));
+            h->lat_on = true;
+            return TGNH_OK;                                            // nothing per slot is kept
+        }
+    }
     HIP_OK(hipMalloc(&h->d_sflag, flag.size()));
     HIP_OK(hipMalloc(&h->d_sbase, base.size() * sizeof(uint32_t)));
     HIP_OK(hipMalloc(&h->d_sites, std::max(sites.size(), (size_t)16) + 16));    // (+16: a 12-byte record may be fetched as four dwords)
     HIP_OK(hipMemcpy(h->d_sflag, flag.data(), flag.size(), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(h->d_sbase, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     if (!sites.empty()) HIP_OK(hipMemcpy(h->d_sites, sites.data(), sites.size(), hipMemcpyHostToDevice));
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_harness_lattice_hint(tgnh_handle h, int mol_slots, int side, double spacing, const double* geom, int first_molecule) {
+    CHECK_H(h);
+    if (mol_slots == 0) { h->lat_k = 0; h->lat_geom.clear(); return TGNH_OK; }
+    if (mol_slots < 1 || mol_slots > 64 || side < 1 || side > 1290 || !(spacing > 0) || !geom || first_molecule < 0) return fail(TGNH_ERR_ARG, "bad lattice hint");
+    h->lat_k = mol_slots; h->lat_side = side; h->lat_spacing = spacing; h->lat_mol0 = first_molecule;
+    h->lat_geom.assign(geom, geom + 3 * (size_t)mol_slots);
+    return TGNH_OK;
+}
+extern "C" tgnh_status tgnh_harness_sites_kind(tgnh_handle h, int* kind) {
+    CHECK_H(h);
+    if (!kind) return fail(TGNH_ERR_ARG, "null out");
+    *kind = h->lat_on ? 2 : (h->d_sflag ? 1 : 0);
     return TGNH_OK;
 }
 

@@ -256,7 +256,13 @@ struct ForceArgs {
     const uint8_t* sflag;
     const uint32_t* sbase;
     const void* sites;
+    // lattice sites (tgnh_harness_lattice_hint, verified by tgnh_harness_pack_sites): one molecule of lat_k slots repeated on a
+    // simple cubic lattice; flag byte and site offset per slot of the molecule in lat_tab: bytes [64] then doubles [64][3]
+    int lat_k, lat_side, lat_mol0;
+    double lat_spacing, lat_inv_k, lat_inv_side, lat_inv_side2;
+    const unsigned char* lat_tab;
 };
+constexpr size_t LAT_TAB_BYTES = 64 + 64 * 3 * sizeof(double);
 
 // A launcher reports THIS launch's error: whatever an earlier call left behind (e.g. a stream capture the caller
 // abandoned) is read off first.
@@ -374,6 +380,11 @@ struct tgnh_context {
     uint8_t* d_sflag = nullptr;               // harness: packed tether sites (ForceArgs::sflag / sbase / sites), tgnh_harness_pack_sites
     uint32_t* d_sbase = nullptr;
     void* d_sites = nullptr;
+    int lat_k = 0, lat_side = 0, lat_mol0 = 0;              // ... or lattice sites: the hint (lat_k = 0: none), and whether pack_sites found it to hold
+    double lat_spacing = 0;
+    std::vector<double> lat_geom;
+    bool lat_on = false;
+    unsigned char* d_lat_tab = nullptr;
     // mailbox exchange (tgnh_exchange_*): replaces the hook when attached
     tgnh::XchgArgs x{};
     bool xchg_on = false, xwait_pending = false;

@@ -2266,10 +2266,92 @@ __global__ __launch_bounds__(BLOCK) void force_packed_kernel(const ForceArgs a) 
     }
 }
 
+// ... and from LATTICE sites (ForceArgs::lat_*: one molecule repeated on a simple cubic lattice, checked slot by slot by
+// tgnh_harness_pack_sites): flag byte and site are functions of the slot index -- molecule m = i div k, slot i - m k of it, lattice
+// point (m div side^2, (m div side) mod side, m mod side) -- so the kernel reads positions and writes forces, nothing else: the
+// 56 B per slot (mixed) the call-out cannot do without.  The site is fl(fl64(index x spacing) + geom), two roundings and a
+// conversion, the bits numpy gave the packed sites (__dmul_rn / __dadd_rn: never contracted; the force arithmetic itself is the
+// packed kernel's, under the same contraction rules: the same forces bit for bit); x div d as floor((x + 1/2) / d): never within
+// rounding of an integer.
+template <int PREC>
+__global__ __launch_bounds__(BLOCK) void force_lattice_kernel(const ForceArgs a) {
+    typedef typename Prec<PREC>::real real;
+    typedef typename Prec<PREC>::real4 real4;
+    typedef typename Prec<PREC>::mixed mixed;
+    __shared__ double s_geom[64 * 3];
+    __shared__ unsigned char s_flag[64];
+    const real4* __restrict__ posq = reinterpret_cast<const real4*>(a.posq);
+    const float4* __restrict__ pcorr = reinterpret_cast<const float4*>(a.posq_corr);
+    if (threadIdx.x < 64) s_flag[threadIdx.x] = a.lat_tab[threadIdx.x];
+    if (threadIdx.x < 192) s_geom[threadIdx.x] = reinterpret_cast<const double*>(a.lat_tab + 64)[threadIdx.x];
+    __syncthreads();
+    const mixed kd = (mixed)a.k_drude, kt = (mixed)a.k_tether;
+    const int lane = threadIdx.x & 63;
+    const int nround = (a.n + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
+    for (int rr = 0; rr < nround; rr++) {
+        const int r = a.reverse ? nround - 1 - rr : rr;
+        const int blk = a.reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+        const int i = (r * gridDim.x + blk) * BLOCK + threadIdx.x;
+        const bool in = i < a.n;
+        real4 p = {}; float4 c = {};
+        if (in) {
+            p = posq[i];
+            if (PREC == TGNH_PREC_MIXED) c = pcorr[i];
+        }
+        const int mloc = (int)(((double)i + 0.5) * a.lat_inv_k), pos = in ? i - mloc * a.lat_k : 0;
+        const int mol = a.lat_mol0 + mloc;                               // this handle's molecules start at lat_mol0 of the box (shards)
+        const uint32_t b = in ? s_flag[pos] : 0u;
+        const bool tethered = (b & 4u) != 0;
+        real s0 = 0, s1 = 0, s2 = 0;
+        if (tethered) {
+            const int ix = (int)(((double)mol + 0.5) * a.lat_inv_side2), rem = mol - ix * a.lat_side * a.lat_side;
+            const int iy = (int)(((double)rem + 0.5) * a.lat_inv_side), iz = rem - iy * a.lat_side;
+            s0 = (real)__dadd_rn(__dmul_rn((double)ix, a.lat_spacing), s_geom[3 * pos]);
+            s1 = (real)__dadd_rn(__dmul_rn((double)iy, a.lat_spacing), s_geom[3 * pos + 1]);
+            s2 = (real)__dadd_rn(__dmul_rn((double)iz, a.lat_spacing), s_geom[3 * pos + 2]);
+        }
+        mixed x = p.x, y = p.y, z = p.z;
+        if (PREC == TGNH_PREC_MIXED) { x += (mixed)c.x; y += (mixed)c.y; z += (mixed)c.z; }
+        const uint32_t role = b & 3u;
+        const int off = (int)(b >> 3) - 16;
+        const int pl = lane + off;
+        const int src = (pl >= 0 && pl < 64) ? pl : lane;
+        mixed ox = __shfl(x, src, 64), oy = __shfl(y, src, 64), oz = __shfl(z, src, 64);
+        mixed fx = 0, fy = 0, fz = 0;
+        if (in) {
+            if (tethered) { fx = -kt * (x - (mixed)s0); fy = -kt * (y - (mixed)s1); fz = -kt * (z - (mixed)s2); }
+            if (role != ROLE_NORMAL) {
+                if (src != pl) {
+                    const int j = i + off;
+                    const real4 q = posq[j];
+                    ox = q.x; oy = q.y; oz = q.z;
+                    if (PREC == TGNH_PREC_MIXED) { const float4 cq = pcorr[j]; ox += (mixed)cq.x; oy += (mixed)cq.y; oz += (mixed)cq.z; }
+                }
+                const bool is_d = role == ROLE_DRUDE;
+                const mixed sgn = is_d ? (mixed)-1 : (mixed)1;
+                const mixed sx = is_d ? x - ox : ox - x, sy = is_d ? y - oy : oy - y, sz = is_d ? z - oz : oz - z;
+                fx += sgn * kd * sx; fy += sgn * kd * sy; fz += sgn * kd * sz;
+            }
+            a.force[i] = (long long)(fx * (mixed)4294967296.0);
+            a.force[i + a.padded] = (long long)(fy * (mixed)4294967296.0);
+            a.force[i + 2 * a.padded] = (long long)(fz * (mixed)4294967296.0);
+        }
+    }
+}
+
 hipError_t launch_force(int precision, const ForceArgs& a, hipStream_t s) {
     int grid = (a.n + BLOCK - 1) / BLOCK;
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
+    if (a.lat_tab) {
+        switch (precision) {
+            case TGNH_PREC_SINGLE: TGNH_LAUNCH((force_lattice_kernel<TGNH_PREC_SINGLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+            case TGNH_PREC_MIXED: TGNH_LAUNCH((force_lattice_kernel<TGNH_PREC_MIXED>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+            case TGNH_PREC_DOUBLE: TGNH_LAUNCH((force_lattice_kernel<TGNH_PREC_DOUBLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (a.sflag) {
         switch (precision) {
             case TGNH_PREC_SINGLE: TGNH_LAUNCH((force_packed_kernel<TGNH_PREC_SINGLE>), dim3(grid), dim3(BLOCK), 0, s, a); break;

@@ -257,7 +257,7 @@ class HipContext(_HandleQueries):
     """
 
     def __init__(self, system, integrator, mode="TGNH", precision="mixed", device=0, flags=0, kB=KB,
-                 k_drude=None, k_tether=None, allreduce=None, global_dof_sum=None):
+                 k_drude=None, k_tether=None, allreduce=None, global_dof_sum=None, lattice_sites=True):
         import torch
         self.torch = torch
         self.lib = _lib.load()
@@ -296,6 +296,7 @@ class HipContext(_HandleQueries):
         self.x0 = torch.zeros((n, 4), dtype=rdt, device=self.dev)        # harness tether sites, w = tether flag
         self.sites_packed = False
         self.unpacked_sites = False                                      # (tests: the harness force from x0 itself, the round-1 kernel)
+        self.use_lattice_sites = bool(lattice_sites)                     # (tests: False keeps the packed sites where the lattice form would hold)
         inv = np.where(system.mass == 0.0, 0.0, 1.0 / np.where(system.mass == 0.0, 1.0, system.mass))
         self.velm[:, 3] = torch.from_numpy(inv).to(self.dev, mdt)
         _check(self.lib.tgnh_bind_buffers(self.h, self.posq.data_ptr(),
@@ -513,8 +514,22 @@ class HipContext(_HandleQueries):
         flag[self.system.pair_drude] = False
         self.x0[:, 3] = self.torch.from_numpy(flag.astype(np.float64)).to(self.dev, self.rdt)
         self.torch.cuda.synchronize(self.dev)
+        lat = getattr(self.system, "lattice", None)
+        if lat is not None and self.use_lattice_sites:
+            # (a hint only: the library checks every slot against it and packs the sites as before where it does not hold)
+            k, side, spacing, geom, first = lat
+            geom = np.ascontiguousarray(geom, np.float64)
+            _check(self.lib.tgnh_harness_lattice_hint(self.h, int(k), int(side), float(spacing), geom.ctypes.data_as(_lib.c_f64p), int(first)))
+        else:
+            _check(self.lib.tgnh_harness_lattice_hint(self.h, 0, 0, 0.0, None, 0))
         _check(self.lib.tgnh_harness_pack_sites(self.h, self.x0.data_ptr()))
         self.sites_packed = True
+
+    def sites_kind(self):
+        """how the harness force finds its tether sites: 'x0' (explicit array), 'packed', 'lattice'"""
+        n = C.c_int()
+        _check(self.lib.tgnh_harness_sites_kind(self.h, C.byref(n)))
+        return ("x0", "packed", "lattice")[n.value]
 
     def _x0_arg(self):
         """None (NULL: the library reads its packed copy) once set_sites has packed them, else the float4 / double4 array"""

@@ -72,6 +72,7 @@ def water_box(n_mol, order="test", temperature=300.0, drude_temperature=1.0, see
     mass, pd, pp, resid, pos = _molecules(n_mol, table, spacing)
     out = _finish(mass, pd, pp, resid, pos, np.zeros(mass.shape[0], np.int32), 1, rng, temperature, drude_temperature,
                   f"swm4-{n_mol}" + ("-rigid" if rigid else ""))
+    out[0].lattice = (5, int(np.ceil(n_mol ** (1.0 / 3.0) - 1e-9)), float(spacing), np.asarray(table["geom"], np.float64), 0)   # (_lattice, _molecules)
     if rigid:
         o, h1, h2, m = (0, 2, 3, 4) if order == "test" else (0, 1, 2, 3)
         base = np.arange(n_mol) * 5

@@ -22,6 +22,10 @@ class DrudeSystem:
     cluster_dist: np.ndarray = None        # [K,6] distances for pairs (0,1)(0,2)(0,3)(1,2)(1,3)(2,3), 0 = none
     site_atoms: np.ndarray = None          # [S,4] (site, p1, p2, p3)
     site_weights: np.ndarray = None        # [S,3]
+    # harness only: the box repeats ONE molecule on a simple cubic lattice (synth.water_box) -- (slots per molecule, side, spacing nm,
+    # geometry [slots][3], index of this system's first molecule in the box); a hint for the harness force's tether sites, checked
+    # slot by slot by the library before it is used
+    lattice: tuple = None
 
     def __post_init__(self):
         self.mass = np.ascontiguousarray(self.mass, np.float64)
@@ -72,7 +76,11 @@ class DrudeSystem:
         if len(self.constraints):
             cm = (self.constraints[:, 0] >= lo) & (self.constraints[:, 0] < hi)
         r = self.resid[lo:hi]
+        lat = None
+        if self.lattice is not None and lo % self.lattice[0] == 0:
+            lat = self.lattice[:4] + (self.lattice[4] + lo // self.lattice[0],)
         return DrudeSystem(
+            lattice=lat,
             mass=self.mass[lo:hi], pair_drude=inv[self.pair_drude[pm]], pair_parent=inv[self.pair_parent[pm]],
             resid=r - r.min() if r.size else r, constraints=inv[self.constraints[cm]] if cm.any() else np.zeros((0, 2), np.int32),
             has_cm_motion_remover=self.has_cm_motion_remover,

@@ -1303,6 +1303,48 @@ def test_packed_sites_give_the_same_forces(sysname, precision):
     ctx.close()
 
 
+@pytest.mark.parametrize("precision", ["single", "mixed", "double"])
+@pytest.mark.parametrize("n_mol", [27, 1000, 1500])
+def test_lattice_sites_give_the_same_forces(n_mol, precision):
+    """A box that repeats one molecule on a lattice (synth.water_box says so: DrudeSystem.lattice) needs no per-slot site data at
+    all: tgnh_harness_pack_sites checks the hint slot by slot and the force kernel then forms flag byte and site from the slot
+    index (force_lattice_kernel: positions in, forces out, nothing else).  Bit for bit the forces of the packed form -- a cube of
+    molecules and a box that does not fill its cube (1 500 of 12^3), a shard that starts in the middle of the box -- and a box
+    whose sites do not obey the formula falls back to the packed form by itself."""
+    s, g, ng = synth.water_box(n_mol)
+    rng = np.random.default_rng(9)
+    moved = s.positions + rng.normal(0, 0.01, s.positions.shape)
+    forces = {}
+    for lat in (True, False):
+        it = integ(chains=1)
+        ctx = HipContext(s, it, mode="TGNH", precision=precision, lattice_sites=lat)
+        assert ctx.sites_kind() == ("lattice" if lat else "packed")
+        ctx.setPositions(moved)
+        ctx.compute_forces()
+        forces[lat] = ctx.force.clone()
+        if lat:                                              # other sites (not the lattice's): the hint no longer holds
+            ctx.set_sites(moved)
+            assert ctx.sites_kind() == "packed"
+        ctx.close()
+    assert forces[True].abs().max() > 0 and ctx.torch.equal(forces[True], forces[False])
+    if n_mol >= 1000:                                        # a shard: molecules 300 .. 800 of the box
+        sh = s.slice_molecules(1500, 4000)
+        assert sh.lattice is not None and sh.lattice[4] == 300
+        out = {}
+        for lat in (True, False):
+            ctx = HipContext(sh, integ(chains=1), mode="TGNH", precision=precision, lattice_sites=lat)
+            assert ctx.sites_kind() == ("lattice" if lat else "packed")
+            ctx.setPositions(moved[1500:4000])
+            ctx.compute_forces()
+            out[lat] = ctx.force.clone()
+            ctx.close()
+        assert ctx.torch.equal(out[True], out[False])
+        n = sh.num_particles
+        pad = forces[True].numel() // 3
+        whole = forces[True].view(3, pad)[:, 1500:4000]
+        assert ctx.torch.equal(out[True].view(3, -1)[:, :n], whole)      # ... the same forces as inside the whole box
+
+
 @pytest.mark.parametrize("flags", [0, FLAG_RESIDENT_STEP])
 @pytest.mark.parametrize("mode", ["dualNH", "TGNH"])
 def test_kinetic_energy_query(mode, flags):
@@ -1714,6 +1756,49 @@ def test_full_size_steps_against_the_oracle(mode, flags, precision):
     else:
         assert ep <= TOL and ev <= TOL      # (thermostat variables are not compared: deferred, the chain is half a step ahead)
     assert ctx.check() == 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("flags", [0, FLAG_DEFER_SCALE, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP, FLAG_TRUST_STATE_CHANGED])
+@pytest.mark.parametrize("mode", ["TGNH", "dualNH"])
+def test_system_without_any_drude_pair(mode, flags):
+    """A DrudeForce without particles (the API only asks for exactly one DrudeForce, DrudeTGNHIntegrator.cpp:110-124): 3 P = 0 Drude
+    degrees of freedom, so the Drude thermostat's mass is 0 and its chain is 0/0 in the reference's own arithmetic (Cu :227-235, :605;
+    Ref :168-171, :491-492) -- a NaN scale factor that multiplies nothing, since no pair exists.  The oracle shows exactly that; the
+    HIP path must too: finite positions and velocities equal to the oracle's, the real thermostats' factors equal, NaN where the
+    oracle has NaN, no status bit.  (Massless sites and molecules of one to three atoms in the box.)"""
+    rng = np.random.default_rng(5)
+    n = 900
+    mass = np.full(n, 39.9)
+    mass[::7] = 0.0
+    resid = np.repeat(np.arange(n // 3), 3)[:n]
+    pos = rng.uniform(0, 4, (n, 3))
+    vel = rng.normal(0, 0.3, (n, 3))
+    vel[mass == 0] = 0
+    s = synth.DrudeSystem(mass=mass, pair_drude=np.zeros(0, np.int32), pair_parent=np.zeros(0, np.int32), resid=resid, positions=pos, velocities=vel)
+    g = np.zeros(n, np.int32)
+    it = integ(chains=2, hardwall=0.02)
+    if mode == "TGNH":
+        bind_groups(it, g, 1)
+    else:
+        # the Reference platform reads pairParticles[0] at initialize (Ref :181): undefined behaviour without a pair; the library says so
+        with pytest.raises(TgnhError) as e:
+            HipContext(s, it, mode=mode, precision="double", flags=flags)
+        assert e.value.status == _lib.ERR_UNSUPPORTED and "Drude pair" in str(e.value)
+        return
+    ctx = HipContext(s, it, mode=mode, precision="double", flags=flags)
+    o = make_oracle(s, g, 1, mode, it)
+    pos_o, vel_o, kes, scs = oracle_run(o, s, 40, record=True, x0=ctx.sites())
+    ctx.step(40)
+    ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
+    sc, sco = ctx.last_scale_factors(), to_internal(scs, mode)[-1]
+    print(f"no Drude pair, {mode}, flags {flags}: pos {ep:.2e} vel {ev:.2e}; scale factors {sc} (oracle {sco})")
+    assert np.isfinite(ctx.getPositions()).all() and np.isfinite(ctx.getVelocities()).all()
+    assert ep <= TOL and ev <= TOL and ctx.check() == 0
+    if not flags & FLAG_DEFER_SCALE:          # (deferred: the factors in hand belong to the next step's first half as well)
+        assert np.isnan(sc[-1]) and np.isnan(sco[-1])
+        real = ~np.isnan(sco)
+        assert np.allclose(sc[real], sco[real], rtol=0, atol=TOL_KE)
     ctx.close()
 
 
