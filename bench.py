@@ -564,12 +564,13 @@ def dry_launch(args, world, rank):
 
 
 def step_model_bytes(num_slots, precision, variant):
-    """SURVEY 8d state-array model of one step for the pass structure actually run: plain = the reference's passes
-    (7V + 2F + 2X); defer = rescale+kick+drift (2V + F + 2X) and kick+KE without a velocity write (V + F)."""
+    """SURVEY 8d state-array model of one step for the pass structure actually run: plain = the reference's passes (SURVEY's
+    7V + 2F + 2X as 6V + 3F + 2X since round 4: the end half's kick+KE pass stores nothing and its rescale launch forms the kicked
+    velocities again); defer = rescale+kick+drift (2V + F + 2X) and kick+KE without a velocity write (V + F)."""
     V = 16 if precision == "single" else 32
     X = 16 if precision == "single" else 32
     F = 24
-    per = {"plain": 7 * V + 2 * F + 2 * X, "plain-trust": 6 * V + 2 * F + 2 * X, "plain-resident": 6 * V + 3 * F + 2 * X,
+    per = {"plain": 6 * V + 3 * F + 2 * X, "plain-trust": 5 * V + 3 * F + 2 * X, "plain-resident": 6 * V + 3 * F + 2 * X,
            "plain-resident-trust": 5 * V + 3 * F + 2 * X, "defer": 3 * V + 2 * F + 2 * X,
            "resident": 3 * V + 2 * F + 2 * X}[variant]
     return num_slots * per

@@ -1576,15 +1576,22 @@ static tgnh_status second_half(tgnh_handle h, hipStream_t s, int kick_ops) {
         return poll_status_async(h, s);
     }
     // DEFER_SCALE, fused path: the kicked velocities only feed the sums (Cu :384-388 + :474-488); the next step's first
-    // launch -- or tgnh_flush -- forms them again from the same force buffer and goes on from there
-    const int nostore = (defer && kick_ops) ? OP_NOSTORE : 0;
+    // launch -- or tgnh_flush -- forms them again from the same force buffer and goes on from there.
+    // The reference's own structure, fused path (round 4): the same unstored kick+KE pass, and the rescale launch of THIS call forms
+    // the kicked velocities again before it rescales them (OP_PREKICK: the same expression on the same force buffer, the same
+    // bits) -- V r, F r | V r/w, F r = 144 B per slot where kick+KE with a store and a plain rescale move 152, and the read-only
+    // pass runs at 62 us where the storing one takes 87-92 (5 M slots).  velm holds the reference's end-of-step velocities when
+    // tgnh_step_end returns, as before.  (The split path's halves work on stored velocities around the constraint call-outs.)
+    const bool fold = !defer && kick_ops != 0;
+    const int nostore = kick_ops ? OP_NOSTORE : 0;
+    h->end_folded = fold;
     rc = run_tile(h, kick_ops | OP_KE | nostore, kick_ops ? KID_KICK_KE : KID_KE, s); if (rc) return rc;
     if (defer) {
         rc = run_chain(h, s, true); if (rc) return rc;
         h->scale_pending = true; h->first_half_done = true; h->kick_pending = nostore != 0;
     } else {
         rc = run_chain(h, s, false); if (rc) return rc;                            // Cu :394-395
-        rc = run_tile(h, OP_SCALE, KID_SCALE, s); if (rc) return rc;               // Cu :402
+        rc = run_tile(h, (fold ? OP_PREKICK : 0) | OP_SCALE, KID_SCALE, s); if (rc) return rc;   // Cu :402 (and :384-388 again, see above)
         // the velocities now stored have the bins ke_post; they stay that until somebody writes velocities (unsharded only: a
         // rank that recomputes while its peers carry over would enter a collective alone)
         h->ke_carry = h->carry_ok && !h->allreduce && !h->xchg_on;
@@ -2045,8 +2052,8 @@ extern "C" tgnh_status tgnh_algorithmic_bytes(tgnh_handle h, int kernel, double*
     double b = 0;
     switch (kernel) {
         case KID_SKD: b = N * (2 * V + F + 2 * X); break;       // scale+kick+drift: V r/w, F r, X r/w
-        case KID_KICK_KE: b = N * ((h->d.flags & TGNH_FLAG_DEFER_SCALE ? 1 : 2) * V + F); break;   // kick+KE: V r(/w), F r; DEFER_SCALE leaves the kicked velocities unstored
-        case KID_SCALE: b = N * (2 * V); break;                 // rescale (+KE): V r/w
+        case KID_KICK_KE: b = N * (V + F); break;               // kick+KE: V r, F r -- the kicked velocities feed the sums only (every fused structure since round 4)
+        case KID_SCALE: b = N * (2 * V + (h->end_folded ? F : 0)); break;    // rescale: V r/w (+ F r where it forms the kicked velocities again)
         case KID_KE: b = N * V; break;                          // KE: V r
         case KID_FORCE: b = N * (X + F); break;                 // harness: X r, F w (x0 excluded)
         case KID_STEP:       // step_kernel: its two passes.  Deferred: (V r, F r) + (V r/w, F r, X r/w); the reference's pass

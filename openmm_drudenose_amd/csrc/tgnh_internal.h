@@ -369,6 +369,7 @@ struct tgnh_context {
     int wresident_per_cu = 0, wresident_grid = 0;   // the same for wstep_kernel (0: none, or no wave tiles)
     int resident_per_cu = 0;          // work-groups of step_kernel per compute unit that the census at create found resident together (0: none -- the handle steps the DEFER_SCALE way)
     bool first_half_done = false;     // DEFER_SCALE: chain for the coming step's first half already run
+    bool end_folded = false;          // the last fused end half left the kick to its rescale launch (OP_PREKICK: algorithmic bytes of KID_SCALE)
     bool ke_carry = false;            // TRUST_STATE_CHANGED: ke_post of the last end half IS the kinetic energy of the stored velocities
     double time = 0;
     int64_t step_count = 0;
