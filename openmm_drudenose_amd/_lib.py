@@ -117,6 +117,15 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m openmm_drudenose_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the integrator path.")
+    # ONE HIP runtime per process.  PyTorch ships its own libamdhip64 / libhsa-runtime64; this library links the system's
+    # (/opt/rocm).  Loaded after torch, its libamdhip64.so.7 resolves to the copy the process already holds and everybody talks
+    # to the same runtime; loaded BEFORE torch, the process ends up with two, and the second to touch the device finds none
+    # ("hipGetDeviceCount: no ROCm-capable device is detected" -- build() followed by smoke() in one interpreter, round 4).  The
+    # Python side of this package hands the library torch's device memory anyway, so torch goes first whenever it is there.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         if os.environ.get("TGNH_LIB") and not hasattr(lib, name):
