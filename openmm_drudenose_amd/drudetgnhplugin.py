@@ -616,7 +616,8 @@ class HipContext(_HandleQueries):
             self.ke_sum_valid = True
 
     def capture_steps(self, steps):
-        """Captures `steps` time steps (harness force call-out included, and the KE all-reduce when sharded) into
+        """Captures `steps` time steps (harness force call-out included -- and the harness' constraint / virtual-site call-outs for a
+        system with constraints --, and the KE all-reduce when sharded) into
         a hipGraph on a side stream and returns a callable that replays it.  The step sequence must not change afterwards
         (no setters).  A handle that is not in the steady state of its step sequence is brought there first, by up to
         three times `steps` real steps (see below): read the step count afterwards if it matters."""
@@ -638,7 +639,11 @@ class HipContext(_HandleQueries):
         def record():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                _check(self.lib.tgnh_run_harness(self.h, self._x0_arg(), self.k_drude, self.k_tether, int(steps), self._stream()))
+                if self.constrained:                         # the step loop step() runs for such a system: the split entry points around the harness' constraint call-outs
+                    _check(self.lib.tgnh_run_harness_constrained(self.h, self._x0_arg(), self.k_drude, self.k_tether,
+                                                                 self.integrator.getConstraintTolerance(), int(steps), self._stream()))
+                else:
+                    _check(self.lib.tgnh_run_harness(self.h, self._x0_arg(), self.k_drude, self.k_tether, int(steps), self._stream()))
             return g
         for _ in range(4):
             owed_before = self.pending_state() & 0x2ff

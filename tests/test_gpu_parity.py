@@ -765,6 +765,36 @@ def test_graph_replay_matches_eager(flags, chains, mode):
     ref[4].close(); alt[4].close()
 
 
+@pytest.mark.parametrize("flags", [0, FLAG_RESIDENT_STEP, FLAG_TRUST_STATE_CHANGED])
+def test_graph_replay_of_the_constrained_step_matches_eager(flags):
+    """capture_steps on a system WITH constraints records the loop step() runs for it -- the split entry points around the harness
+    SHAKE / velocity stage / virtual sites (Cu :336-406) -- not the unconstrained one (until round 4 it recorded tgnh_run_harness
+    whatever the system held: a replay integrated rigid water without its constraints).  Rigid SWM4 water: bitwise equal to eager
+    steps, and the bonds are at their lengths."""
+    out = []
+    for graphed in (False, True):
+        s, g, ng = synth.water_box(216, rigid=True)
+        it = integ(chains=1, hardwall=0.02, dt=0.0005)
+        bind_groups(it, g, ng)
+        ctx = HipContext(s, it, mode="TGNH", precision="double", flags=flags)
+        assert ctx.constrained
+        ctx.step(3)
+        if graphed:
+            replay = ctx.capture_steps(5)
+            for _ in range(4):
+                replay()
+        else:
+            ctx.step(20)
+        assert ctx.time()[1] == 23 and ctx.check() == 0
+        out.append((ctx.getPositions(), ctx.getVelocities(), ctx.thermostat_state(1)))
+        ctx.close()
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    pos = out[1][0].reshape(-1, 5, 3)                         # O, D, H1, H2, M
+    assert np.allclose(np.linalg.norm(pos[:, 2] - pos[:, 0], axis=1), 0.09572, rtol=2e-5)
+    assert np.allclose(np.linalg.norm(pos[:, 3] - pos[:, 2], axis=1), 0.15139, rtol=2e-5)
+
+
 def test_split_constraint_path_matches_fused():
     """begin_kick / begin_move / end_kick / end_thermo (the posDelta path around OpenMM's constraint
     call-outs, Cu :356-369, :384-402) with no constraints applied equals the fused step."""

@@ -32,7 +32,6 @@ for name, build, hw in CFG:
         n, eager, graph = 500, 0.0, 0.0
         for _ in range(3):                       # best of three: a row now and then catches a host stall (C2 single: 13.9 k once, 71 k alone)
             t0 = time.perf_counter(); ctx.step(n); torch.cuda.synchronize(); eager = max(eager, n / (time.perf_counter() - t0))
-            if constrained: continue             # (capture_steps records the unconstrained step loop only)
             rep = ctx.capture_steps(10); rep(); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(n // 10): rep()
