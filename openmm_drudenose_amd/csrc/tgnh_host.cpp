@@ -184,6 +184,18 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
         if (start > 0 && start < N && c->resid[start] == c->resid[start - 1]) n += 1;
         return n;
     };
+    // Where the molecular COM is not needed (dualNH; TGNH without the COM group) a tile may end inside a molecule -- but a box of
+    // one small molecule then has tiles that start at every phase of it, i.e. as many index-word patterns as the molecule has
+    // slots, and a kernel whose lane forms its word again for every tile (dualNH/mixed/resident 200 us per launch where TGNH's
+    // 60-slot tiles of whole waters take 186).  So a cut that may go anywhere still prefers a molecule's end when one lies within
+    // the last tenth of the tile.
+    const bool have_resid = (int)c->resid.size() == N;
+    auto mol_cut = [&](int st, int end, int span, auto&& legal) {
+        if (com || !have_resid || end >= N) return end;
+        for (int e = end; e > st && e >= end - span / 10; e--)
+            if (c->resid[e] != c->resid[e - 1] && legal(e)) return e;
+        return end;
+    };
     int cap = TILE_SLOTS;
 #ifdef TGNH_TUNING
     if (const char* e = getenv("TGNH_TILE_CAP")) { int v = atoi(e); if (v >= 64 && v <= TILE_SLOTS) cap = v; }
@@ -199,6 +211,7 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
         while (end > start && !ok(end)) end--;
         if (end == start)
             return fail(TGNH_ERR_UNSUPPORTED, "a Drude pair spans more than one 512-slot tile");
+        end = mol_cut(start, end, cap, ok);
         if (align > 1 && end < N) {           // prefer a cut on an `align`-slot boundary close by
             for (int e = end; e > start && e > end - 64; e--)
                 if (e % align == 0 && ok(e)) { end = e; break; }
@@ -250,6 +263,7 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
             int end = std::min(st + WAVE_SLOTS, N);
             while (end > st && end < N && forbid[end] > 0) end--;
             if (end == st) { fits = false; break; }
+            end = mol_cut(st, end, WAVE_SLOTS, [&](int e) { return forbid[e] == 0; });
             int maxn = 1;
             if (com) for (int i = st; i < end; i++) maxn = std::max(maxn, c->res_count[c->resid[i]]);
             wt.push_back(make_int2(st, maxn));
