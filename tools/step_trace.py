@@ -43,5 +43,11 @@ for mol in [int(x) for x in argv] or [125000]:
                 continue
             us = (col[m] - base) / 100.0
             print(f"  {NAMES[sl]:16s} n={m.sum():5d}  min {us.min():6.2f}  p50 {np.median(us):6.2f}  p90 {np.percentile(us, 90):6.2f}  max {us.max():6.2f}")
+        if os.environ.get("TGNH_TRACE_BY_XCD"):              # where the spread comes from: work-group b runs on XCD b mod 8, on compute unit (b div 8) mod 32 of it
+            idx = np.flatnonzero(live)
+            for sl in (1, 15):
+                us = (tr[:, sl] - base) / 100.0
+                print(f"  {NAMES[sl]:12s} by XCD (p50): " + " ".join(f"{np.median(us[idx % 8 == x]):6.2f}" for x in range(8)) +
+                      "   | by slot on the CU (first / second work-group): " + " ".join(f"{np.median(us[(idx // 256) == k]):6.2f}" for k in range(2)))
         ctx.compute_forces(); ctx.step_end()
     ctx.close()
