@@ -389,9 +389,18 @@ def cpu_baseline(args, system, group, ngroups):
         o.run_harness(pos, vel, f, x0, synth.K_DRUDE, synth.K_TETHER, 2)
         per = (time.perf_counter() - t0) / 2
         n = int(max(3, min(200, budget / max(per, 1e-6))))
-        t0 = time.perf_counter()
-        o.run_harness(pos, vel, f, x0, synth.K_DRUDE, synth.K_TETHER, n)
-        return n, n / (time.perf_counter() - t0)
+        # three chunks, the fastest one's rate: one core of a shared host (256 hardware threads, other tenants) reads 25 % low now
+        # and then for seconds at a time (10.8 and 7.7 steps/s in two runs a minute apart on one box, round 4)
+        best, done = 0.0, 0
+        for k in range(3):
+            m = n // 3 + (1 if k < n % 3 else 0)
+            if m == 0:
+                continue
+            t0 = time.perf_counter()
+            o.run_harness(pos, vel, f, x0, synth.K_DRUDE, synth.K_TETHER, m)
+            best = max(best, m / (time.perf_counter() - t0))
+            done += m
+        return done, best
 
     nd, vd = one("dualNH", args.cpu_seconds / 2)
     nt, vt = one("TGNH", args.cpu_seconds / 2)
@@ -399,7 +408,7 @@ def cpu_baseline(args, system, group, ngroups):
             "dualnh": round(vd, 4), "tgnh": round(vt, 4),
             "sample": f"{nd} steps (dualNH = platforms/reference's algorithm, `value`) and {nt} steps (TGNH = platforms/cuda's "
                       f"algorithm) of the same {system.num_pairs}-pair system ({system.num_particles} slots), "
-                      f"oracle/tgnh_oracle.c, fp64, gcc -O2, 1 thread, harness force included",
+                      f"oracle/tgnh_oracle.c, fp64, gcc -O2, 1 thread, harness force included; each in three chunks, the fastest chunk's rate",
             "host_cpus": os.cpu_count()}
 
 
