@@ -1,4 +1,6 @@
 #!/bin/bash
+# (How round 4's pattern-mass-constants experiment was run; the kernels it compares exist with profiles/r04_pconst_experiment.patch
+# applied -- the experiment was taken out of the library again, profiles/r04_scaling_ceiling.md.)
 # Pattern mass constants (PCONST_*, tgnh_internal.h) against the per-slot reciprocals (a -DTGNH_NO_PCONST build,
 # tools/build_variant.py build_variants/nopconst.so -DTGNH_NO_PCONST), interleaved on one box: the 8-GPU shard (625 k slots,
 # hipGraph) and the metric size (eager, bench.py's default shape).   usage: tools/micro/pconst_ab.sh <outdir>

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (How round 4's pattern-mass-constants experiment was run; the kernels it compares exist with profiles/r04_pconst_experiment.patch
+# applied -- the experiment was taken out of the library again, profiles/r04_scaling_ceiling.md.)
 # SQ counters of wstep_kernel at the 8-GPU shard size with the pattern mass constants (the library as built) and with per-slot
 # reciprocals (build_variants/nopconst.so, -DTGNH_NO_PCONST).   usage: tools/micro/pconst_counters.sh <outdir>
 cd /tmp; export TMPDIR=/tmp
