@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
     const int N = I[0], P = I[1], R = I[2], G = I[3], ncl = I[4], ns = I[5], nsteps = I[6], perturb = I[7];
     const int chains = I[8], useDrudeChains = I[9], useCOM = I[10], precision = I[11];    // TGNH_PREC_MIXED or _DOUBLE
     const bool dbl = precision == TGNH_PREC_DOUBLE;
-    const int flags = I[12];                 // 0, or TGNH_FLAG_RESIDENT_STEP (the glue's -DDRUDETGNH_RESIDENT_STEP build)
+    const int flags = I[12];                 // 0, TGNH_FLAG_RESIDENT_STEP (the glue's -DDRUDETGNH_RESIDENT_STEP build), TGNH_FLAG_TRUST_STATE_CHANGED (its -DDRUDETGNH_TRUST_STATE_CHANGED build), or both
     const int* pairs = &I[13]; const int* resid = pairs + 2 * P; const int* group = resid + N;
     const int* clAtoms = group + N; const int* siteAtoms = clAtoms + 4 * ncl;
     const double dt = D[0], hardwall = D[1], kDrude = D[2], kTether = D[3], tol = D[4];

@@ -51,7 +51,12 @@ def run_glue(exe, tmp_path, s, group, ngroups, nsteps, perturb, chains, drude_ch
     return out[:3 * n].reshape(n, 3), out[3 * n:6 * n].reshape(n, 3), out[6 * n:-1], out[-1]
 
 
-@pytest.mark.parametrize("flags", [0, _lib.FLAG_RESIDENT_STEP])
+GLUE_FLAGS = [0, _lib.FLAG_RESIDENT_STEP,                        # the glue's default build and its -DDRUDETGNH_RESIDENT_STEP build,
+              _lib.FLAG_TRUST_STATE_CHANGED,                      # ... -DDRUDETGNH_TRUST_STATE_CHANGED (stateChanged() forwarded: the C++ mirror does)
+              _lib.FLAG_TRUST_STATE_CHANGED | _lib.FLAG_RESIDENT_STEP]
+
+
+@pytest.mark.parametrize("flags", GLUE_FLAGS)
 def test_fused_sequence_against_the_committed_vectors(exe, tmp_path, flags):
     """No constraints: tgnh_step_begin / force call-out / tgnh_step_end per step -- the case nacl_tgnh of
     tests/golden/oracle_regression.npz (512 pairs, hard wall 0.02 nm, one-link chains, 40 steps).  Double precision:
@@ -66,7 +71,7 @@ def test_fused_sequence_against_the_committed_vectors(exe, tmp_path, flags):
     assert ke == pytest.approx(0.5 * frozen["nacl_tgnh/ke"][-1].sum(), rel=1e-6)
 
 
-@pytest.mark.parametrize("flags", [0, _lib.FLAG_RESIDENT_STEP])
+@pytest.mark.parametrize("flags", GLUE_FLAGS)
 @pytest.mark.parametrize("name", ["rigid water", "ionic liquid"])
 def test_split_sequence_with_call_outs_and_state_changes(exe, tmp_path, name, flags):
     """Constraints present: begin_kick / applyConstraints / begin_move / computeVirtualSites / calcForcesAndEnergy /
@@ -74,7 +79,7 @@ def test_split_sequence_with_call_outs_and_state_changes(exe, tmp_path, name, fl
     the integrator's back (stateChanged()).  Against the oracle doing the same, 1e-6."""
     s, g, ng = synth.water_box(64, rigid=True) if name == "rigid water" else synth.ionic_liquid(12, constrained=True)
     tol, nsteps = 1e-10, 40
-    chains = 2 if flags == 0 else 1          # (step_kernel runs one-link chains; longer ones take the chain launch)
+    chains = 1 if flags & _lib.FLAG_RESIDENT_STEP else 2      # (step_kernel runs one-link chains; longer ones take the chain launch)
     pos, vel, eta_dot, ke = run_glue(exe, tmp_path, s, g, ng, nsteps, True, chains, True, True, 0.001, 0.02, tol, "mixed", flags)
     it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, chains, True, True)
     it.setMaxDrudeDistance(0.02)
