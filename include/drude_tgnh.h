@@ -111,7 +111,7 @@ typedef struct tgnh_desc {
     const double* mass;           /* [N] System::getParticleMass */
     const int32_t* pair_drude;    /* [P] DrudeForce::getParticleParameters p  */
     const int32_t* pair_parent;   /* [P] DrudeForce::getParticleParameters p1 */
-    const int32_t* group;         /* [N] getParticleTempGroup (TGNH mode; may be NULL in DUALNH) */
+    const int32_t* group;         /* [N] getParticleTempGroup (TGNH mode; ignored in DUALNH -- the Reference platform has no temperature groups -- and may be NULL there) */
     const int32_t* resid;         /* [N] getParticleResId     (TGNH mode; may be NULL in DUALNH) */
     const int32_t* constraint_i;  /* [num_constraints] or NULL */
     const int32_t* constraint_j;

@@ -75,7 +75,10 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
     c->mass.assign(d->mass, d->mass + N);
     c->pair_drude.assign(d->pair_drude, d->pair_drude + P);
     c->pair_parent.assign(d->pair_parent, d->pair_parent + P);
-    if (d->group) c->group.assign(d->group, d->group + N); else c->group.assign(N, 0);
+    // dualNH: the Reference platform never reads getParticleTempGroup (its two thermostats are "everything but the Drude motion" and
+    // "the Drude motion", Ref :426-546), so an array handed over in that mode is ignored -- used as it came, its indices sent the
+    // kinetic energy of groups 1.. into the unused and the Drude bins of the three-thermostat block (found by tools/fuzz_soak.py --modes)
+    if (tg && d->group) c->group.assign(d->group, d->group + N); else c->group.assign(N, 0);
     if (d->resid) c->resid.assign(d->resid, d->resid + N); else c->resid.clear();
 
     // pair membership; normalParticles = ascending indices in no pair (Ref :113-137, Cu :111-151)

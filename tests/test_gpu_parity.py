@@ -1265,6 +1265,26 @@ def test_bridge_identity_on_the_gpu():
         t.close(); d.close()
 
 
+@pytest.mark.parametrize("tiles", ["wave", "lds"])
+@pytest.mark.parametrize("flags", [0, RESIDENT])
+def test_dualnh_ignores_temperature_groups_on_the_gpu(flags, tiles):
+    """dualNH with the integrator's four temperature groups handed over = dualNH without any, bit for bit, and both on the
+    dualNH oracle (which has no groups to read): the Reference platform's two thermostats do not know about groups."""
+    s, g, ng = SYSTEMS["mixed"]()
+    wf = FLAG_WAVE_TILES if tiles == "wave" else 0
+    it_g, it_0 = integ(chains=3, hardwall=0.02), integ(chains=3, hardwall=0.02)
+    bind_groups(it_g, g, ng)
+    a = HipContext(s, it_g, mode="dualNH", precision="double", flags=flags | wf)
+    b = HipContext(s, it_0, mode="dualNH", precision="double", flags=flags | wf)
+    o = make_oracle(s, np.zeros_like(g), 1, "dualNH", it_0)
+    pos_o, vel_o = oracle_run(o, s, 50, x0=b.sites())
+    a.step(50); b.step(50)
+    assert np.array_equal(a.getVelocities(), b.getVelocities()) and np.array_equal(a.getPositions(), b.getPositions())
+    assert np.array_equal(a.last_kinetic_energies(), b.last_kinetic_energies())
+    assert rel_err(a.getPositions(), pos_o) <= TOL and rel_err(a.getVelocities(), vel_o) <= TOL
+    a.close(); b.close()
+
+
 def test_10000_steps_all_pass_structures_track_the_oracle():
     """Ten picoseconds, 1000 waters, double precision: the reference's pass structure, the deferred one and the one-launch
     step all stay on the oracle's trajectory (the thermostats swing the group temperature between 30 and 1200 K on this

@@ -349,6 +349,21 @@ def test_no_drude_pairs():
         HostTopology(s, integ(), mode="dualNH")
 
 
+def test_dualnh_ignores_temperature_groups():
+    """The Reference platform never reads getParticleTempGroup (Ref :426-546: "real" is everything but the Drude motion): an
+    integrator that carries groups gives, in dualNH mode, the same handle as one that carries none -- no group index in any
+    per-slot word, the same degrees of freedom.  (Used as it came, the array sent kinetic energy into the unused and the Drude
+    bins: tools/fuzz_soak.py --modes, round 4.)"""
+    s, g, ng = synth.mixed(250, 12)
+    assert ng == 4 and g.max() == 3
+    with_groups, without = HostTopology(s, integ(group=g, ngroups=ng), mode="dualNH"), HostTopology(s, integ(), mode="dualNH")
+    assert not with_groups.topology(3).any()
+    for which in (7, 8):                                             # tile starts, packed per-slot words
+        assert np.array_equal(with_groups.topology(which), without.topology(which))
+    assert not ((with_groups.topology(8).view(np.uint32) >> 2) & 255).any()
+    assert np.array_equal(with_groups.dof()[0], without.dof()[0])
+
+
 def test_up_to_32_temperature_groups():
     s, g, ng = synth.many_groups(100, 8, 32)
     t = HostTopology(s, integ(group=g, ngroups=ng))

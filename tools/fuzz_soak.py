@@ -47,21 +47,36 @@ SYSTEMS = {
     "ionic-40": lambda: synth.ionic_liquid(40),                     # 35-slot cations: wave tiles refused unless forced
     "polymer-300+200": lambda: synth.polymer_in_water(300, 200),    # one molecule of 900 slots: the COM table of long molecules
     "groups-12": lambda: synth.many_groups(150, 10, 12),            # > 8 temperature groups: the LDS bins
+    # --modes only (drawn less often: a walk takes ~1 s): enough tiles for every work-group of the one-launch step to hold several
+    "water-8000": lambda: synth.water_box(8000),                    # 40 000 slots, 625 wave tiles
+    "mixed-6000-400": lambda: synth.mixed(6000, 400),               # 48 000 slots, four groups, two kinds of tile pattern
 }
-COM = True
+BIG = ("water-8000", "mixed-6000-400")
+
+
+def ragged(k):
+    """tests/helpers.py::random_topology(k): molecules of 1-40 slots (some seeds: two longer than a tile), Drudes before or after
+    their parents and up to 30 slots away, massless sites, up to 6 groups -- as test_random_ragged_topologies_against_the_oracle"""
+    from helpers import random_topology
+    mass, pd, pp, resid, group, ngroups, cons, sizes, first, rng = random_topology(k)
+    pos = rng.uniform(0.0, 3.0, (len(mass), 3))
+    return synth._finish(mass, np.array(pd, np.int32), np.array(pp, np.int32), resid, pos, group, ngroups, rng, 300.0, 1.0, f"ragged{k}")
+
+COM, MODE, PRECISION, DRUDE_CHAINS, HARDWALL, CMM = True, "TGNH", "double", True, 0.02, False
 TWIN_FACTOR = 2000.0
 
 
 def make_build(name):
     def build(flags, exchange, chains, wave=False):
-        s, g, ng = SYSTEMS[name]()
-        it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, chains, True, COM)
-        it.setMaxDrudeDistance(0.02)
+        s, g, ng = ragged(int(name[7:])) if name.startswith("ragged-") else SYSTEMS[name]()
+        s.has_cm_motion_remover = CMM
+        it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, chains, DRUDE_CHAINS, COM)
+        it.setMaxDrudeDistance(HARDWALL)
         for _ in range(ng):
             it.addTempGroup()
         for gi in g:
             it.addParticleTempGroup(int(gi))
-        ctx = HipContext(s, it, mode="TGNH", precision="double", flags=flags | (FLAG_WAVE_TILES if wave else 0))
+        ctx = HipContext(s, it, mode=MODE, precision=PRECISION, flags=flags | (FLAG_WAVE_TILES if wave else 0))
         if exchange == "hook":
             ctx.set_allreduce(lambda t: None)
         elif exchange == "mailbox":
@@ -139,11 +154,13 @@ class SoakWalk(T.Walk):
 
 
 def main():
-    global COM
+    global COM, MODE, PRECISION, DRUDE_CHAINS, HARDWALL, CMM
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=10.0)
     ap.add_argument("--seed0", type=int, default=5000)
     ap.add_argument("--calls", type=int, default=T.CALLS_PER_WALK)
+    ap.add_argument("--modes", action="store_true", help="also draw dualNH / TGNH, mixed / double precision, useDrudeNHChains, the hard wall, "
+                    "a CMMotionRemover in the System, ragged random topologies and two 40-50 k-slot boxes")
     ap.add_argument("--trace", default="", help="with --only: compare after every call and write the errors (variant, twin) here")
     ap.add_argument("--only", default="", help="comma-separated seeds: run just these walks of the sequence --seed0 defines")
     a = ap.parse_args()
@@ -153,7 +170,7 @@ def main():
     flag_sets = [0, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP, FLAG_TRUST_STATE_CHANGED,
                  FLAG_TRUST_STATE_CHANGED | FLAG_RESIDENT_STEP]
     t_end, n, bad, chaotic = time.time() + 60.0 * a.minutes, 0, 0, 0
-    names = list(SYSTEMS)
+    names = [n for n in SYSTEMS if n not in BIG]
     while time.time() < t_end:
         seed = a.seed0 + n
         name = names[int(pick.integers(0, len(names)))]
@@ -162,7 +179,19 @@ def main():
         chains = int(pick.choice([1, 1, 2, 3, 4, 6]))
         wave = bool(pick.integers(0, 2))
         COM = bool(pick.integers(0, 4))                              # the COM group off in a quarter of the walks
-        what = f"system={name} flags={flags} exchange={exchange} chains={chains} wave={wave} com={COM} seed={seed}"
+        if a.modes:                                                  # (drawn only when asked for, so that the earlier runs' --seed0 sequences stay what they were)
+            MODE = "dualNH" if pick.integers(0, 10) < 3 else "TGNH"  # the Reference platform's algorithm in 30 % of the walks,
+            PRECISION = "mixed" if pick.integers(0, 10) < 4 else "double"
+            DRUDE_CHAINS = bool(pick.integers(0, 4))                 # ... its coupled-chain quirk (useDrudeNHChains = false) in a quarter
+            HARDWALL = 0.0 if pick.integers(0, 4) == 0 else 0.02
+            CMM = pick.integers(0, 4) == 0                           # System holds a CMMotionRemover: three degrees of freedom fewer
+            u = int(pick.integers(0, 20))
+            if u < 6:
+                name = f"ragged-{int(pick.integers(0, 200))}"
+            elif u < 8:
+                name = BIG[u - 6]
+        what = (f"system={name} flags={flags} exchange={exchange} chains={chains} wave={wave} com={COM} seed={seed}"
+                + (f" mode={MODE} precision={PRECISION} drude_chains={DRUDE_CHAINS} hardwall={HARDWALL} cmm={CMM}" if a.modes else ""))
         if only and seed not in only:
             n += 1
             if seed > max(only):
