@@ -50,8 +50,13 @@ SYSTEMS = {
     # --modes only (drawn less often: a walk takes ~1 s): enough tiles for every work-group of the one-launch step to hold several
     "water-8000": lambda: synth.water_box(8000),                    # 40 000 slots, 625 wave tiles
     "mixed-6000-400": lambda: synth.mixed(6000, 400),               # 48 000 slots, four groups, two kinds of tile pattern
+    # --modes only: constraint clusters + virtual sites (step() = the split entry points around the harness SHAKE / velocity stage;
+    # the walk's own split steps and fused pieces run without the call-outs, on both handles alike)
+    "water-rigid-300": lambda: synth.water_box(300, rigid=True),
+    "ionic-30-shake": lambda: synth.ionic_liquid(30, constrained=True),
 }
 BIG = ("water-8000", "mixed-6000-400")
+CONSTRAINED = ("water-rigid-300", "ionic-30-shake")
 
 
 def ragged(k):
@@ -161,6 +166,7 @@ def main():
     ap.add_argument("--calls", type=int, default=T.CALLS_PER_WALK)
     ap.add_argument("--modes", action="store_true", help="also draw dualNH / TGNH, mixed / double precision, useDrudeNHChains, the hard wall, "
                     "a CMMotionRemover in the System, ragged random topologies and two 40-50 k-slot boxes")
+    ap.add_argument("--constrained", action="store_true", help="with --modes: rigid water and the constrained ionic liquid too")
     ap.add_argument("--trace", default="", help="with --only: compare after every call and write the errors (variant, twin) here")
     ap.add_argument("--only", default="", help="comma-separated seeds: run just these walks of the sequence --seed0 defines")
     a = ap.parse_args()
@@ -170,7 +176,7 @@ def main():
     flag_sets = [0, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP, FLAG_TRUST_STATE_CHANGED,
                  FLAG_TRUST_STATE_CHANGED | FLAG_RESIDENT_STEP]
     t_end, n, bad, chaotic = time.time() + 60.0 * a.minutes, 0, 0, 0
-    names = [n for n in SYSTEMS if n not in BIG]
+    names = [n for n in SYSTEMS if n not in BIG + CONSTRAINED]
     while time.time() < t_end:
         seed = a.seed0 + n
         name = names[int(pick.integers(0, len(names)))]
@@ -190,6 +196,8 @@ def main():
                 name = f"ragged-{int(pick.integers(0, 200))}"
             elif u < 8:
                 name = BIG[u - 6]
+            elif u < 10 and a.constrained:
+                name = CONSTRAINED[u - 8]
         what = (f"system={name} flags={flags} exchange={exchange} chains={chains} wave={wave} com={COM} seed={seed}"
                 + (f" mode={MODE} precision={PRECISION} drude_chains={DRUDE_CHAINS} hardwall={HARDWALL} cmm={CMM}" if a.modes else ""))
         if only and seed not in only:
