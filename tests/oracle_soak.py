@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""The HIP path against the CPU oracle over RANDOM CONFIGURATIONS, for a time budget (not a test: run by hand on a GPU box; the
+suite's parity tests walk the configurations somebody thought of).  Lives under tests/ because it uses the oracle as its checker.
+
+    python tests/oracle_soak.py --minutes 8 --seed0 0 > gpurun_out/oracle_soak.txt
+
+Per case, drawn from one seeded generator: a system (one of 200 ragged random topologies of tests/helpers.py::random_topology --
+with or without random constraint clusters --, or one of the synthetic boxes: mixed, nacl, ionic liquid with and without its
+constraints, water plain and rigid, polymer in water, 6 / 12 / 32 temperature groups), the mode (TGNH / dualNH), the precision
+(double / mixed), one of the six flag sets of the call-sequence tests with or without forced wave tiles, numNHChains in 1-6, 10,
+16, useDrudeNHChains, useCOMTempGroup, the hard wall on or off, a CMMotionRemover in the System, the step size (1 / 0.5 fs), the
+sub-steps (20 / 5 / 1), temperatures and coupling times.  The integrator's temperature groups are handed to the library in BOTH
+modes (dualNH has to ignore them: the oracle's dualNH mode gets none).  Then `--steps` (30) steps on both sides with the harness
+force -- through the split entry points and the harness' constraint call-outs when the system has constraints -- and positions,
+velocities (north_star's 1e-6; the worst seen is printed) and the thermostat variables (rtol 1e-6 as in test_100_step_parity)
+are compared.  A refused configuration (TGNH_ERR_UNSUPPORTED at create: wave tiles for a long molecule, a pair across a tile cut
+...) is counted as skipped; anything else that raises or disagrees is a FAIL line with the case's seed."""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+from oracle.binding import OracleError  # noqa: E402
+from helpers import make_oracle, oracle_run, rel_err, to_internal, random_topology, random_clusters  # noqa: E402
+from openmm_drudenose_amd import synth, HipContext, _lib  # noqa: E402
+from openmm_drudenose_amd.drudetgnhplugin import (DrudeTGNHIntegrator, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES,  # noqa: E402
+                                                   FLAG_TRUST_STATE_CHANGED, TgnhError)
+
+BOXES = {
+    "mixed-200-15": lambda: synth.mixed(200, 15),
+    "nacl": synth.nacl,
+    "ionic-40": lambda: synth.ionic_liquid(40),
+    "ionic-40-shake": lambda: synth.ionic_liquid(40, constrained=True),
+    "water-343": lambda: synth.water_box(343),
+    "water-rigid-216": lambda: synth.water_box(216, rigid=True),
+    "polymer-600+200": lambda: synth.polymer_in_water(600, 200),
+    "groups-6": lambda: synth.many_groups(200, 15, 6),
+    "groups-12": lambda: synth.many_groups(200, 15, 12),
+    "groups-32": lambda: synth.many_groups(200, 15, 32),
+}
+FLAG_SETS = [0, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP, FLAG_TRUST_STATE_CHANGED,
+             FLAG_TRUST_STATE_CHANGED | FLAG_RESIDENT_STEP]
+
+
+def ragged(k, clusters):
+    mass, pd, pp, resid, group, ngroups, cons, sizes, first, rng = random_topology(k)
+    pos = rng.uniform(0.0, 3.0, (len(mass), 3))
+    if clusters:
+        ca, cd = random_clusters(rng, mass, pd, pp, sizes, first, pos)
+    s, g, ng = synth._finish(mass, np.array(pd, np.int32), np.array(pp, np.int32), resid, pos, group, ngroups, rng, 300.0, 1.0, f"ragged{k}")
+    if clusters and len(ca):
+        s.set_clusters(ca, cd)
+    return s, g, ng
+
+
+def one_case(rng, nsteps, info):
+    u = int(rng.integers(0, 10))
+    if u < 4:
+        k, clusters = int(rng.integers(0, 200)), bool(rng.integers(0, 3) == 0)
+        name, (s, g, ng) = f"ragged-{k}{'-clusters' if clusters else ''}", ragged(k, clusters)
+    else:
+        name = list(BOXES)[int(rng.integers(0, len(BOXES)))]
+        s, g, ng = BOXES[name]()
+    mode = "dualNH" if rng.integers(0, 10) < 3 else "TGNH"
+    precision = "mixed" if rng.integers(0, 10) < 4 else "double"
+    flags = FLAG_SETS[int(rng.integers(0, len(FLAG_SETS)))] | (FLAG_WAVE_TILES if rng.integers(0, 2) else 0)
+    chains = int(rng.choice([1, 1, 2, 3, 4, 5, 6, 10, 16]))
+    drude_chains, com = bool(rng.integers(0, 4)), bool(rng.integers(0, 4))
+    hardwall = 0.0 if rng.integers(0, 4) == 0 else 0.02
+    s.has_cm_motion_remover = bool(rng.integers(0, 4) == 0)
+    dt = float(rng.choice([0.001, 0.0005]))
+    sub = int(rng.choice([20, 20, 5, 1]))
+    temp, tau, dtemp, dtau = [(300.0, 0.1, 1.0, 0.005), (350.0, 0.05, 5.0, 0.01), (280.0, 0.2, 1.0, 0.1)][int(rng.integers(0, 3))]
+    what = (f"system={name} mode={mode} precision={precision} flags={flags} chains={chains} drude_chains={drude_chains} com={com} "
+            f"hardwall={hardwall} cmm={s.has_cm_motion_remover} dt={dt} substeps={sub} T={temp}/{dtemp} tau={tau}/{dtau}")
+    info["what"] = what
+    it = DrudeTGNHIntegrator(temp, tau, dtemp, dtau, dt, sub, chains, drude_chains, com)
+    it.setMaxDrudeDistance(hardwall)
+    it.setConstraintTolerance(1e-10)
+    for _ in range(ng):
+        it.addTempGroup()
+    it._particleTempGroup = np.ascontiguousarray(g, np.int32)         # handed over in both modes
+    try:
+        ctx = HipContext(s, it, mode=mode, precision=precision, flags=flags)
+    except TgnhError as e:
+        if e.status == _lib.ERR_UNSUPPORTED:
+            return "skip", what + f"  ({str(e)[:120]})", 0.0, 0.0
+        raise
+    try:
+        og, ong = (g, ng) if mode == "TGNH" else (np.zeros_like(g), 1)
+        o = make_oracle(s, og, ong, mode, it)
+        pos_o, vel_o, x0 = s.positions.copy(), s.velocities.copy(), ctx.sites()
+        if ctx.constrained:
+            f = o.harness_force(pos_o, x0, synth.K_DRUDE, synth.K_TETHER)
+            o.run_harness_constrained(pos_o, vel_o, f, x0, synth.K_DRUDE, synth.K_TETHER, 1e-10, nsteps)
+        else:
+            pos_o, vel_o = oracle_run(o, s, nsteps, x0=x0)
+        ctx.step(nsteps)
+        status = ctx.check()
+        ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
+        assert status == 0, ("status word", status)
+        assert ep <= 1e-6 and ev <= 1e-6, ("positions / velocities", ep, ev)
+        if flags & FLAG_DEFER_SCALE and ctx.pending_state() & 0x8:
+            # a rescale is owed: the deferred structure has run the NEXT step's first thermostat half already (its rescale rides
+            # on that step's first launch) -- the oracle takes that half step too, on a copy of its velocities
+            o.propagate_nhc(vel_o.copy())
+        for which in (0, 1):
+            a, b = ctx.thermostat_state(which), o.chain(which)
+            assert np.allclose(a, b, rtol=1e-6, atol=1e-9 * max(1.0, np.abs(b).max())), ("thermostat", which, float(np.abs(a - b).max()))
+        return "ok", what, ep, ev
+    finally:
+        ctx.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=8.0)
+    ap.add_argument("--seed0", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--only", default="", help="comma-separated case seeds")
+    a = ap.parse_args()
+    only = [int(x) for x in a.only.split(",") if x]
+    t_end, n, count, worst = time.time() + 60.0 * a.minutes, 0, {"ok": 0, "skip": 0, "FAIL": 0}, {"double": [0.0, 0.0], "mixed": [0.0, 0.0]}
+    while time.time() < t_end and (not only or n < len(only)):
+        seed = only[n] if only else a.seed0 + n
+        n += 1
+        rng = np.random.default_rng(seed)
+        t0 = time.time()
+        info = {"what": ""}
+        try:
+            kind, what, ep, ev = one_case(rng, a.steps, info)
+            if kind == "ok":
+                w = worst["mixed" if "precision=mixed" in what else "double"]
+                w[0], w[1] = max(w[0], ep), max(w[1], ev)
+            print(f"{kind:5s} seed={seed} {what}  pos {ep:.1e} vel {ev:.1e}  {time.time() - t0:.1f}s", flush=True)
+        except OracleError as e:                             # random clusters the oracle's own SHAKE gives up on: no verdict
+            kind = "skip"
+            print(f"skip  seed={seed} {info['what']}  (oracle: {e})", flush=True)
+        except Exception as e:  # noqa: BLE001  (a soak: log and go on)
+            kind = "FAIL"
+            print(f"FAIL  seed={seed} {info['what']}  {type(e).__name__}: {str(e)[:600]}", flush=True)
+            traceback.print_exc(limit=3, file=sys.stdout)
+        count[kind] += 1
+    print(f"{n} cases: {count['ok']} ok, {count['skip']} refused as unsupported, {count['FAIL']} failed; worst pos / vel error: "
+          f"double {worst['double'][0]:.1e} / {worst['double'][1]:.1e}, mixed {worst['mixed'][0]:.1e} / {worst['mixed'][1]:.1e}", flush=True)
+    return 1 if count["FAIL"] else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
