@@ -97,12 +97,21 @@ def one_case(rng, nsteps, info):
         og, ong = (g, ng) if mode == "TGNH" else (np.zeros_like(g), 1)
         o = make_oracle(s, og, ong, mode, it)
         pos_o, vel_o, x0 = s.positions.copy(), s.velocities.copy(), ctx.sites()
+        query = not ctx.constrained        # (A12 with constraints needs the host's projection of the shifted velocities: include/drude_tgnh.h)
+        if query:                          # the kinetic-energy query before the first step (computed: ke_sum_valid false) ...
+            f = o.harness_force(pos_o, x0, synth.K_DRUDE, synth.K_TETHER)
+            ke_h, ke_o = ctx.kinetic_energy(), o.kinetic_energy_query(vel_o, f, False)
+            assert abs(ke_h - ke_o) <= 1e-7 * abs(ke_o), ("kinetic energy query at the start", ke_h, ke_o)
         if ctx.constrained:
             f = o.harness_force(pos_o, x0, synth.K_DRUDE, synth.K_TETHER)
             o.run_harness_constrained(pos_o, vel_o, f, x0, synth.K_DRUDE, synth.K_TETHER, 1e-10, nsteps)
         else:
             pos_o, vel_o = oracle_run(o, s, nsteps, x0=x0)
         ctx.step(nsteps)
+        if query:                          # ... and after the last (TGNH: the cached bins of the last thermostat half; dualNH: shifted by half a kick)
+            f = o.harness_force(pos_o, x0, synth.K_DRUDE, synth.K_TETHER)
+            ke_h, ke_o = ctx.kinetic_energy(), o.kinetic_energy_query(vel_o, f, True)
+            assert abs(ke_h - ke_o) <= 1e-7 * abs(ke_o), ("kinetic energy query after the steps", ke_h, ke_o)
         status = ctx.check()
         ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
         assert status == 0, ("status word", status)
@@ -119,8 +128,97 @@ def one_case(rng, nsteps, info):
         ctx.close()
 
 
+def sharded_case(rng, nsteps, info):
+    """The particle-sharded path with the 'ranks' as two handles on this one GPU, each on its own stream, the kinetic
+    energies exchanged through the library's mailboxes (as test_particle_sharded_mailbox_exchange_on_one_gpu): the shards'
+    positions and velocities, put together, against the oracle's run of the WHOLE system; thermostats bit-identical on the ranks."""
+    import torch
+    from openmm_drudenose_amd.system import shard_bounds
+    u = int(rng.integers(0, 10))
+    if u < 4:
+        k = int(rng.integers(0, 200))
+        name, (s, g, ng) = f"ragged-{k}", ragged(k, False)
+    else:
+        name = [n for n in BOXES if "shake" not in n and "rigid" not in n][int(rng.integers(0, len(BOXES) - 2))]
+        s, g, ng = BOXES[name]()
+    mode = "dualNH" if rng.integers(0, 10) < 3 else "TGNH"
+    precision = "mixed" if rng.integers(0, 10) < 4 else "double"
+    flags = [0, FLAG_DEFER_SCALE, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP, FLAG_TRUST_STATE_CHANGED][int(rng.integers(0, 4))]
+    flags |= FLAG_WAVE_TILES if rng.integers(0, 2) else 0
+    chains = int(rng.choice([1, 1, 2, 3, 4, 6, 10]))
+    drude_chains, com = bool(rng.integers(0, 4)), bool(rng.integers(0, 4))
+    hardwall = 0.0 if rng.integers(0, 4) == 0 else 0.02
+    s.has_cm_motion_remover = bool(rng.integers(0, 4) == 0)
+    dt, sub = float(rng.choice([0.001, 0.0005])), int(rng.choice([20, 20, 5, 1]))
+    nranks = 2
+    what = (f"sharded x{nranks} system={name} mode={mode} precision={precision} flags={flags} chains={chains} drude_chains={drude_chains} "
+            f"com={com} hardwall={hardwall} cmm={s.has_cm_motion_remover} dt={dt} substeps={sub}")
+    info["what"] = what
+
+    def integrator(group):
+        it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, dt, sub, chains, drude_chains, com)
+        it.setMaxDrudeDistance(hardwall)
+        for _ in range(ng):
+            it.addTempGroup()
+        it._particleTempGroup = np.ascontiguousarray(group, np.int32)
+        return it
+    b = shard_bounds(s, nranks)
+    if min(np.diff(b)) == 0:
+        return "skip", what + "  (an empty shard)", 0.0, 0.0
+    parts = []
+    try:
+        try:
+            for r in range(nranks):
+                loc = s.slice_molecules(b[r], b[r + 1])
+                loc.has_cm_motion_remover = s.has_cm_motion_remover
+                parts.append(HipContext(loc, integrator(g[b[r]:b[r + 1]]), mode=mode, precision=precision, flags=flags))
+                if flags & FLAG_RESIDENT_STEP:
+                    parts[-1].set_resident_share(nranks)
+        except TgnhError as e:
+            if e.status == _lib.ERR_UNSUPPORTED:
+                return "skip", what + f"  ({str(e)[:120]})", 0.0, 0.0
+            raise
+        streams = [torch.cuda.Stream(priority=-r) for r in range(nranks)]      # two different hardware queues
+        total = sum(c.local_dof_terms() for c in parts)
+        boxes = [c.exchange_create(nranks, r)[1] for r, c in enumerate(parts)]
+        for c in parts:
+            c.set_global_dof_terms(total)
+            c.exchange_attach_pointers(boxes)
+        torch.cuda.synchronize()
+        x0 = np.concatenate([c.sites() for c in parts])
+        og, ong = (g, ng) if mode == "TGNH" else (np.zeros_like(g), 1)
+        o = make_oracle(s, og, ong, mode, integrator(g))
+        pos_o, vel_o = oracle_run(o, s, nsteps, x0=x0)
+        for _ in range(nsteps):
+            for c, st in zip(parts, streams):
+                with torch.cuda.stream(st):
+                    c.step_begin(); c.compute_forces(); c.step_end()
+        for c, st in zip(parts, streams):                            # settle every rank's pending half before any rank waits on a query
+            with torch.cuda.stream(st):
+                assert c.lib.tgnh_flush(c.h, c._stream()) == 0
+        torch.cuda.synchronize()
+        for c in parts:
+            assert c.check() == 0, ("status word", c.status_flags())
+        ep = rel_err(np.concatenate([c.getPositions() for c in parts]), pos_o)
+        ev = rel_err(np.concatenate([c.getVelocities() for c in parts]), vel_o)
+        assert ep <= 1e-6 and ev <= 1e-6, ("positions / velocities", ep, ev)
+        for which in (0, 1):
+            a = parts[0].thermostat_state(which)
+            for c in parts[1:]:
+                assert np.array_equal(a, c.thermostat_state(which)), ("thermostats differ between the ranks", which)
+        return "ok", what, ep, ev
+    finally:
+        for c in parts:
+            try:
+                c.exchange_detach()
+            except Exception:  # noqa: BLE001
+                pass
+            c.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--sharded", action="store_true", help="two ranks on this GPU with the mailbox exchange, against the oracle's run of the whole system")
     ap.add_argument("--minutes", type=float, default=8.0)
     ap.add_argument("--seed0", type=int, default=0)
     ap.add_argument("--steps", type=int, default=30)
@@ -135,7 +233,7 @@ def main():
         t0 = time.time()
         info = {"what": ""}
         try:
-            kind, what, ep, ev = one_case(rng, a.steps, info)
+            kind, what, ep, ev = (sharded_case if a.sharded else one_case)(rng, a.steps, info)
             if kind == "ok":
                 w = worst["mixed" if "precision=mixed" in what else "double"]
                 w[0], w[1] = max(w[0], ep), max(w[1], ev)
