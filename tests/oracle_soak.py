@@ -44,7 +44,13 @@ BOXES = {
     "groups-6": lambda: synth.many_groups(200, 15, 6),
     "groups-12": lambda: synth.many_groups(200, 15, 12),
     "groups-32": lambda: synth.many_groups(200, 15, 32),
+    "water-8000": lambda: synth.water_box(8000),                    # 40 000 slots: every work-group of the one-launch step holds several tiles
+    "mixed-6000-400": lambda: synth.mixed(6000, 400),               # 48 000 slots, four groups
 }
+SINGLE = False                                                     # --single: every case in single precision, at GATES["single"]
+# positions / velocities (relative, max norm), thermostat rtol, kinetic-energy query.  Single precision is not a parity gate of
+# the suite (measured and reported); here it is run for what a loose gate still catches -- NaN, a wrong launch, a status bit
+GATES = {"double": (1e-6, 1e-6, 1e-6, 1e-7), "mixed": (1e-6, 1e-6, 1e-6, 1e-7), "single": (1e-4, 2e-2, 5e-2, 1e-3)}
 FLAG_SETS = [0, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP, FLAG_TRUST_STATE_CHANGED,
              FLAG_TRUST_STATE_CHANGED | FLAG_RESIDENT_STEP]
 
@@ -70,6 +76,8 @@ def one_case(rng, nsteps, info):
         s, g, ng = BOXES[name]()
     mode = "dualNH" if rng.integers(0, 10) < 3 else "TGNH"
     precision = "mixed" if rng.integers(0, 10) < 4 else "double"
+    if SINGLE:
+        precision = "single"
     flags = FLAG_SETS[int(rng.integers(0, len(FLAG_SETS)))] | (FLAG_WAVE_TILES if rng.integers(0, 2) else 0)
     chains = int(rng.choice([1, 1, 2, 3, 4, 5, 6, 10, 16]))
     drude_chains, com = bool(rng.integers(0, 4)), bool(rng.integers(0, 4))
@@ -97,11 +105,12 @@ def one_case(rng, nsteps, info):
         og, ong = (g, ng) if mode == "TGNH" else (np.zeros_like(g), 1)
         o = make_oracle(s, og, ong, mode, it)
         pos_o, vel_o, x0 = s.positions.copy(), s.velocities.copy(), ctx.sites()
+        gate_p, gate_v, gate_t, gate_q = GATES[precision]
         query = not ctx.constrained        # (A12 with constraints needs the host's projection of the shifted velocities: include/drude_tgnh.h)
         if query:                          # the kinetic-energy query before the first step (computed: ke_sum_valid false) ...
             f = o.harness_force(pos_o, x0, synth.K_DRUDE, synth.K_TETHER)
             ke_h, ke_o = ctx.kinetic_energy(), o.kinetic_energy_query(vel_o, f, False)
-            assert abs(ke_h - ke_o) <= 1e-7 * abs(ke_o), ("kinetic energy query at the start", ke_h, ke_o)
+            assert abs(ke_h - ke_o) <= gate_q * abs(ke_o), ("kinetic energy query at the start", ke_h, ke_o)
         if ctx.constrained:
             f = o.harness_force(pos_o, x0, synth.K_DRUDE, synth.K_TETHER)
             o.run_harness_constrained(pos_o, vel_o, f, x0, synth.K_DRUDE, synth.K_TETHER, 1e-10, nsteps)
@@ -111,18 +120,18 @@ def one_case(rng, nsteps, info):
         if query:                          # ... and after the last (TGNH: the cached bins of the last thermostat half; dualNH: shifted by half a kick)
             f = o.harness_force(pos_o, x0, synth.K_DRUDE, synth.K_TETHER)
             ke_h, ke_o = ctx.kinetic_energy(), o.kinetic_energy_query(vel_o, f, True)
-            assert abs(ke_h - ke_o) <= 1e-7 * abs(ke_o), ("kinetic energy query after the steps", ke_h, ke_o)
+            assert abs(ke_h - ke_o) <= gate_q * abs(ke_o), ("kinetic energy query after the steps", ke_h, ke_o)
         status = ctx.check()
         ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
         assert status == 0, ("status word", status)
-        assert ep <= 1e-6 and ev <= 1e-6, ("positions / velocities", ep, ev)
+        assert ep <= gate_p and ev <= gate_v, ("positions / velocities", ep, ev)
         if flags & FLAG_DEFER_SCALE and ctx.pending_state() & 0x8:
             # a rescale is owed: the deferred structure has run the NEXT step's first thermostat half already (its rescale rides
             # on that step's first launch) -- the oracle takes that half step too, on a copy of its velocities
             o.propagate_nhc(vel_o.copy())
         for which in (0, 1):
             a, b = ctx.thermostat_state(which), o.chain(which)
-            assert np.allclose(a, b, rtol=1e-6, atol=1e-9 * max(1.0, np.abs(b).max())), ("thermostat", which, float(np.abs(a - b).max()))
+            assert np.allclose(a, b, rtol=gate_t, atol=gate_t * 1e-3 * max(1.0, np.abs(b).max())), ("thermostat", which, float(np.abs(a - b).max()))
         return "ok", what, ep, ev
     finally:
         ctx.close()
@@ -223,9 +232,12 @@ def main():
     ap.add_argument("--seed0", type=int, default=0)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--only", default="", help="comma-separated case seeds")
+    ap.add_argument("--single", action="store_true", help="single precision throughout, loose gates (see GATES)")
     a = ap.parse_args()
+    global SINGLE
+    SINGLE = a.single
     only = [int(x) for x in a.only.split(",") if x]
-    t_end, n, count, worst = time.time() + 60.0 * a.minutes, 0, {"ok": 0, "skip": 0, "FAIL": 0}, {"double": [0.0, 0.0], "mixed": [0.0, 0.0]}
+    t_end, n, count, worst = time.time() + 60.0 * a.minutes, 0, {"ok": 0, "skip": 0, "FAIL": 0}, {"double": [0.0, 0.0], "mixed": [0.0, 0.0], "single": [0.0, 0.0]}
     while time.time() < t_end and (not only or n < len(only)):
         seed = only[n] if only else a.seed0 + n
         n += 1
@@ -235,7 +247,7 @@ def main():
         try:
             kind, what, ep, ev = (sharded_case if a.sharded else one_case)(rng, a.steps, info)
             if kind == "ok":
-                w = worst["mixed" if "precision=mixed" in what else "double"]
+                w = worst[what.split("precision=")[1].split()[0]]
                 w[0], w[1] = max(w[0], ep), max(w[1], ev)
             print(f"{kind:5s} seed={seed} {what}  pos {ep:.1e} vel {ev:.1e}  {time.time() - t0:.1f}s", flush=True)
         except OracleError as e:                             # random clusters the oracle's own SHAKE gives up on: no verdict
@@ -247,7 +259,8 @@ def main():
             traceback.print_exc(limit=3, file=sys.stdout)
         count[kind] += 1
     print(f"{n} cases: {count['ok']} ok, {count['skip']} refused as unsupported, {count['FAIL']} failed; worst pos / vel error: "
-          f"double {worst['double'][0]:.1e} / {worst['double'][1]:.1e}, mixed {worst['mixed'][0]:.1e} / {worst['mixed'][1]:.1e}", flush=True)
+          f"double {worst['double'][0]:.1e} / {worst['double'][1]:.1e}, mixed {worst['mixed'][0]:.1e} / {worst['mixed'][1]:.1e}, "
+          f"single {worst['single'][0]:.1e} / {worst['single'][1]:.1e}", flush=True)
     return 1 if count["FAIL"] else 0
 
 
