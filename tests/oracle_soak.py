@@ -225,8 +225,72 @@ def sharded_case(rng, nsteps, info):
             c.close()
 
 
+def checkpoint_case(rng, nsteps, info):
+    """State persistence over random configurations: positions, velocities, the thermostat variables and the clock
+    (serialization.save_thermostat) are taken between two steps and put into a FRESH handle; `nsteps` further steps on both must
+    agree bit for bit -- positions, velocities, thermostats.  Flag sets without DEFER_SCALE (a deferred handle holds the coming
+    step's first thermostat half between steps and says so: serialization.py) and without TRUST_STATE_CHANGED (the restored
+    handle sums its kinetic energies again where the running one carried them: equal to rounding only)."""
+    from openmm_drudenose_amd.serialization import save_thermostat, load_thermostat
+    u = int(rng.integers(0, 10))
+    if u < 4:
+        k = int(rng.integers(0, 200))
+        name, mk = f"ragged-{k}", (lambda: ragged(k, False))
+    else:
+        name = [n for n in BOXES if "shake" not in n and "rigid" not in n][int(rng.integers(0, len(BOXES) - 2))]
+        mk = BOXES[name]
+    mode = "dualNH" if rng.integers(0, 10) < 3 else "TGNH"
+    precision = "mixed" if rng.integers(0, 10) < 4 else "double"
+    flags = int(rng.choice([0, FLAG_RESIDENT_STEP])) | (FLAG_WAVE_TILES if rng.integers(0, 2) else 0)
+    chains = int(rng.choice([1, 1, 2, 3, 4, 6, 10]))
+    drude_chains, com = bool(rng.integers(0, 4)), bool(rng.integers(0, 4))
+    hardwall = 0.0 if rng.integers(0, 4) == 0 else 0.02
+    cmm = bool(rng.integers(0, 4) == 0)
+    dt, sub = float(rng.choice([0.001, 0.0005])), int(rng.choice([20, 20, 5, 1]))
+    before = int(rng.integers(1, 12))                                # steps before the checkpoint (odd and even: the sweep direction)
+    what = (f"checkpoint after {before} steps system={name} mode={mode} precision={precision} flags={flags} chains={chains} "
+            f"drude_chains={drude_chains} com={com} hardwall={hardwall} cmm={cmm} dt={dt} substeps={sub}")
+    info["what"] = what
+
+    def context():
+        s, g, ng = mk()
+        s.has_cm_motion_remover = cmm
+        it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, dt, sub, chains, drude_chains, com)
+        it.setMaxDrudeDistance(hardwall)
+        for _ in range(ng):
+            it.addTempGroup()
+        it._particleTempGroup = np.ascontiguousarray(g, np.int32)
+        return HipContext(s, it, mode=mode, precision=precision, flags=flags)
+    try:
+        a = context()
+    except TgnhError as e:
+        if e.status == _lib.ERR_UNSUPPORTED:
+            return "skip", what + f"  ({str(e)[:120]})", 0.0, 0.0
+        raise
+    b = None
+    try:
+        a.step(before)
+        state, pos, vel = save_thermostat(a), a.getPositions(), a.getVelocities()
+        a.step(nsteps)
+        b = context()
+        b.setPositions(pos); b.setVelocities(vel); b.compute_forces()
+        load_thermostat(b, state)
+        b.step(nsteps)
+        assert a.check() == 0 and b.check() == 0 and a.time() == b.time()
+        assert np.array_equal(a.getPositions(), b.getPositions()), "positions differ after the restore"
+        assert np.array_equal(a.getVelocities(), b.getVelocities()), "velocities differ after the restore"
+        for which in range(4):
+            assert np.array_equal(a.thermostat_state(which), b.thermostat_state(which)), ("thermostat differs after the restore", which)
+        return "ok", what, 0.0, 0.0
+    finally:
+        a.close()
+        if b is not None:
+            b.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--checkpoint", action="store_true", help="checkpoint / restore into a fresh handle: bit for bit")
     ap.add_argument("--sharded", action="store_true", help="two ranks on this GPU with the mailbox exchange, against the oracle's run of the whole system")
     ap.add_argument("--minutes", type=float, default=8.0)
     ap.add_argument("--seed0", type=int, default=0)
@@ -245,7 +309,7 @@ def main():
         t0 = time.time()
         info = {"what": ""}
         try:
-            kind, what, ep, ev = (sharded_case if a.sharded else one_case)(rng, a.steps, info)
+            kind, what, ep, ev = (sharded_case if a.sharded else checkpoint_case if a.checkpoint else one_case)(rng, a.steps, info)
             if kind == "ok":
                 w = worst[what.split("precision=")[1].split()[0]]
                 w[0], w[1] = max(w[0], ep), max(w[1], ev)

@@ -33,3 +33,8 @@ def test_random_configurations_against_the_oracle():
 def test_random_sharded_configurations_against_the_oracle():
     v = _run(oracle_soak.sharded_case, range(500000, 500150), 20)
     assert v["ok"] >= 130, v
+
+
+def test_random_checkpoints_restore_bit_for_bit():
+    v = _run(oracle_soak.checkpoint_case, range(4000000, 4000150), 15)
+    assert v["ok"] >= 130, v
