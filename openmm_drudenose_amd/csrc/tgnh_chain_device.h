@@ -199,7 +199,7 @@ __device__ __forceinline__ bool chain_fast(double* eta, double* etaDot, double* 
 }
 
 // One real (temperature-group or COM) thermostat.  Cu :560-595.  CC > 0: compile-time chain length.
-template <int CC, bool LIBM = true>
+template <int CC, bool LIBM = true, bool TRY_FAST = true>
 __device__ __forceinline__ void chain_real_core(double* eta, double* etaDot, double* etaDotDot, const double* etaMass,
                                                 const int Cdyn, const ChainConst k, const double nkbt, const double kbT,
                                                 double ke, double* scale_out, double* ke_out) {
@@ -230,7 +230,7 @@ __device__ __forceinline__ void chain_real_core(double* eta, double* etaDot, dou
     double invM[CMI];                                                // 1/Q of the higher links (CC == 0: divide)
 #pragma unroll
     for (int i = 0; i < CMI; i++) invM[i] = (CC > 0) ? 1.0 / etaMass[i] : 0.0;
-    if constexpr (CC >= 2) {
+    if constexpr (CC >= 2 && TRY_FAST) {
         // Register-resident chains: the same arithmetic with the exponentials that repeat taken once.  Per sub-step
         // the reference evaluates expfac = exp(-dtc8*etaDot[i+1]) in the descending loop (Cu :566-571) and AGAIN in
         // the ascending loop (Cu :586-592), where etaDot[i+1] still holds the descending loop's value: same argument,
@@ -274,7 +274,7 @@ __device__ __forceinline__ void chain_real_core(double* eta, double* etaDot, dou
 }
 
 // The Drude thermostat.  Cu :597-642.
-template <int CC, bool LIBM = true>
+template <int CC, bool LIBM = true, bool TRY_FAST = true>
 __device__ __forceinline__ void chain_drude_core(double* eta, double* etaDot, double* etaDotDot, const double* etaMass,
                                                  const int Cdyn, const bool chains, const ChainConst k, const double nkbt,
                                                  const double kbT, double ke, double* scale_out, double* ke_out) {
@@ -302,7 +302,7 @@ __device__ __forceinline__ void chain_drude_core(double* eta, double* etaDot, do
         *ke_out = ke;
         return;
     }
-    if constexpr (CC >= 2) {                                         // as in chain_real_core: repeated exponentials once
+    if constexpr (CC >= 2 && TRY_FAST) {                             // as in chain_real_core: repeated exponentials once
         double invM[CC];
 #pragma unroll
         for (int i = 0; i < CC; i++) invM[i] = 1.0 / etaMass[i];
@@ -345,8 +345,39 @@ __device__ __forceinline__ void chain_drude_core(double* eta, double* etaDot, do
     *ke_out = ke;
 }
 
-// One TGNH thermostat (lane itg), `reps` chain calls back to back on register / LDS copies.
-template <int CC, bool LIBM = true>
+// The fast forms for real thermostats AND the Drude thermostat (with its own chain: useDrudeNHChains) in ONE call, converged: what
+// chain_real_core and chain_drude_core do before and inside chain_fast differs in parameters only -- kT, NkT, the guard of link 0
+// (Cu :561 / :579 have it, :605 / :629 do not) -- and those ride in the lane.  Called thermostat by thermostat the two kinds
+// are two code paths of a wavefront, one AFTER the other: where one wavefront holds them all (chainN_run: the chains of 2-4
+// links inside the streaming launches) that doubled the serial section every work-group of the launch waits for.  The form
+// (narrow / wide polynomial) is chosen for all lanes of the call together, as before for all lanes of a kind.
+// False: the arguments left every fast form's range (|x| >= 1: never in practice); the state is as it was.
+template <int CC, bool LIBM>
+__device__ __forceinline__ bool chain_both_fast(double* eta, double* etaDot, double* etaDotDot, const double* etaMass, const ChainConst k,
+                                                const double nkbt, const double kbT, const bool drude, const double ke_in,
+                                                double* scale_out, double* ke_out) {
+    const bool live = drude || etaMass[0] > 0;
+    const double invQ0 = live ? 1.0 / etaMass[0] : 0.0;
+    const double edd0 = etaDotDot[0];
+    if (live) etaDotDot[0] = (ke_in - nkbt) * invQ0;                 // Cu :561-563 / :605
+    double invM[CC];
+#pragma unroll
+    for (int i = 0; i < CC; i++) invM[i] = 1.0 / etaMass[i];
+    double ke = ke_in, scale = 1.0;
+    if (chain_fast<CC, LIBM>(eta, etaDot, etaDotDot, etaMass, invM, k, nkbt, kbT, live, invQ0, ke, scale, drude ? 1 : 0)) {
+        *scale_out = scale;
+        *ke_out = ke;
+        return true;
+    }
+    etaDotDot[0] = edd0;                                             // (the transcription sets it again: nothing else has changed)
+    return false;
+}
+
+// One TGNH thermostat (lane itg), `reps` chain calls back to back on register / LDS copies.  BOTH: the calling wavefront holds real
+// thermostats and the Drude thermostat (chainN_run) -- all of them through chain_both_fast in one pass; the chain kernels keep the Drude
+// thermostat on a wavefront of its own and the two cores as they were (the merged form costs chain_long_kernel<10> 66 more registers,
+// spilled to accumulation registers, and 3 us of its 36).
+template <int CC, bool LIBM = true, bool BOTH = false>
 // st_in -> st_out (may alias); `write`: this caller owns the write-back; s_scale (LDS, may be null) receives the factors.
 __device__ __forceinline__ void run_tgnh(const ChainArgs& a, const double* st_in, double* st_out, const bool write,
                                          double* s_scale, const int itg, double* lds, const double ke_in) {
@@ -375,9 +406,17 @@ __device__ __forceinline__ void run_tgnh(const ChainArgs& a, const double* st_in
     const int reps = a.chain_twice ? 2 : 1;
     double total = 1.0;
     for (int rep = 0; rep < reps; rep++) {
-        double sc, kep;
-        if (itg < NT - 1) chain_real_core<CC, LIBM>(eta, etaDot, etaDotDot, etaMass, C, k, nkbt, a.realkbT, ke, &sc, &kep);
-        else chain_drude_core<CC, LIBM>(eta, etaDot, etaDotDot, etaMass, C, L.use_drude_chains != 0, k, nkbt, a.drudekbT, ke, &sc, &kep);
+        double sc = 1.0, kep = ke;
+        const bool drude = itg == NT - 1;
+        bool done = false;
+        if constexpr (CC >= 2 && BOTH) {                             // every lane whose chain has CC moving links, in one call (chain_both_fast)
+            if (!drude || L.use_drude_chains != 0)
+                done = chain_both_fast<CC, LIBM>(eta, etaDot, etaDotDot, etaMass, k, nkbt, drude ? a.drudekbT : a.realkbT, drude, ke, &sc, &kep);
+        }
+        if (!done) {
+            if (!drude) chain_real_core<CC, LIBM, !BOTH>(eta, etaDot, etaDotDot, etaMass, C, k, nkbt, a.realkbT, ke, &sc, &kep);
+            else chain_drude_core<CC, LIBM, !BOTH>(eta, etaDot, etaDotDot, etaMass, C, L.use_drude_chains != 0, k, nkbt, a.drudekbT, ke, &sc, &kep);
+        }
         if (write) {
             if (rep == 0) { st_out[L.off_scale_a + itg] = sc; st_out[L.off_ke_post + itg] = kep; }
             else st_out[L.off_scale_b + itg] = sc;
@@ -978,8 +1017,9 @@ __device__ __forceinline__ void chain_lanes_run(const ChainArgs& a, double* st, 
 
 // Chains of 2-4 links inside a streaming launch (the one-link chains have chain1_run): called by the 64 lanes of one
 // wavefront, converged; lane itg < NT holds its thermostat's summed kinetic energy `ke`.  TGNH: lane itg runs its thermostat
-// (run_tgnh, register-resident links; the real thermostats and the Drude thermostat are two code paths of one wavefront
-// here, one after the other).  dualNH: lane 0 runs the Reference platform's coupled vectors (run_dualnh).  No library exp
+// (run_tgnh, register-resident links; the real thermostats and the Drude thermostat in ONE pass through the fast forms,
+// chain_both_fast -- until round 4 they were two code paths of this wavefront, one after the other, and the serial section every
+// work-group waits for was twice as long: C2 with three links 33.6 k -> 44.5 k steps/s).  dualNH: lane 0 runs the Reference platform's coupled vectors (run_dualnh).  No library exp
 // (chain_exp<false>): ocml's would cost the streaming kernels ~30 registers.  Longer chains keep their own launch (chain_kernel).
 __device__ __forceinline__ void chainN_run(const ChainArgs& a, const double* st_in, double* st_out, const bool write,
                                            double* s_scale, const int itg, const double ke) {
@@ -987,9 +1027,9 @@ __device__ __forceinline__ void chainN_run(const ChainArgs& a, const double* st_
     if (L.mode == TGNH_MODE_TGNH) {
         if (itg < L.NT) {
             switch (L.C) {
-                case 2: run_tgnh<2, false>(a, st_in, st_out, write, s_scale, itg, nullptr, ke); break;
-                case 3: run_tgnh<3, false>(a, st_in, st_out, write, s_scale, itg, nullptr, ke); break;
-                default: run_tgnh<4, false>(a, st_in, st_out, write, s_scale, itg, nullptr, ke); break;
+                case 2: run_tgnh<2, false, true>(a, st_in, st_out, write, s_scale, itg, nullptr, ke); break;
+                case 3: run_tgnh<3, false, true>(a, st_in, st_out, write, s_scale, itg, nullptr, ke); break;
+                default: run_tgnh<4, false, true>(a, st_in, st_out, write, s_scale, itg, nullptr, ke); break;
             }
         }
     } else {

@@ -21,6 +21,8 @@ for name, build, hw in CFG:
         runs = [("mixed", "plain", 1), ("mixed", "plain-resident", 1)]
     if name.startswith("C2") or name.startswith("metric"):       # longer chains: 3 links (in-kernel below 2 M slots) and the reference test's own 10
         runs += [("mixed", "resident", 3), ("mixed", "defer", 3), ("mixed", "resident", 10), ("mixed", "defer", 10)]
+    elif not constrained and (name.startswith("C3") or name.startswith("C4")):     # ... three links inside the launches with 2 / 4 temperature groups
+        runs += [("mixed", "resident", 3)]
     for prec, var, chains in runs:
         it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, chains, True, True)
         it.setMaxDrudeDistance(hw)
