@@ -668,11 +668,13 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         // dualNH qualifies too: with useDrudeNHChains its real and Drude chains are independent (Chain1Map), without
         // them coupled through one shuffle per sub-step (chain1q_run)
         // Chains of 2-4 links too, but in instantiations of their own that hold two work-groups per compute unit where the
-        // one-link kernels hold three (the links' registers): taken below 1 M slots, where an eager step is bound by its launches
-        // and the chain launch it saves (under a hipGraph the two forms are within 5 % of each other from 32 k to 625 k slots);
-        // beyond, the streaming launches are bandwidth-bound and keep their occupancy -- chain_kernel's 18 us cost less
-        // (profiles/r03_chain_cost.md)
-        int inline_multi_max = 1000000;
+        // one-link kernels hold three (the links' registers): taken below 2.5 M slots.  Beyond, the streaming launches are
+        // bandwidth-bound and keep their occupancy -- chain_kernel's 18 us cost less.  (The limit was 1 M slots while a launch's
+        // chain wavefront ran the real thermostats and the Drude thermostat one after the other; with both in one pass,
+        // chain_both_fast, three links inside the launches read +16 % at 625 k slots, +7 % at 1.25 M, +3..6 % at 2 M and
+        // -4 % / +1 % (one launch per step / deferred) at 5 M: tools/micro/inline_multi_threshold.py,
+        // profiles/r04_inline_multi_threshold.txt)
+        int inline_multi_max = 2500000;
 #ifdef TGNH_TUNING
         if (const char* e6 = getenv("TGNH_INLINE_MULTI_MAX")) inline_multi_max = atoi(e6);
 #endif
