@@ -1679,6 +1679,31 @@ def test_config_sizes_parity(name):
     ctx.close()
 
 
+@pytest.mark.parametrize("flags", [FLAG_DEFER_SCALE, RESIDENT])
+@pytest.mark.parametrize("chains", [3, 4])
+def test_multi_link_chains_inside_the_launches_at_two_million_slots(chains, flags):
+    """Chains of 2-4 links stay inside the streaming launches up to 2.5 M slots (round 4; 1 M before): config 5's box, where the
+    instantiations with the links' registers now run with hundreds of work-groups -- against the oracle, and no chain launch."""
+    s, g, ng = synth.water_box(400000)
+    it = integ(chains=chains, hardwall=0.02)
+    bind_groups_array(it, g, ng)
+    ctx = HipContext(s, it, mode="TGNH", precision="mixed", flags=flags)
+    o = make_oracle(s, g, ng, "TGNH", it)
+    pos_o, vel_o = oracle_run(o, s, 4, x0=ctx.sites())
+    ctx.timing(True)
+    ctx.step(4)
+    ctx.torch.cuda.synchronize(); ctx.timing(False)
+    assert ctx.timing_read(_lib.KID_CHAIN)[1] == 0                   # the chain ran inside the rescale launches / the one-launch step
+    ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
+    print(f"2 M slots, {chains} links, flags {flags}: pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= TOL and ev <= TOL and ctx.check() == 0
+    o.propagate_nhc(vel_o.copy())                                    # (deferred: the next step's first thermostat half has run)
+    for which in (0, 1):
+        a, b = ctx.thermostat_state(which), o.chain(which)
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-9 * max(1.0, np.abs(b).max()))
+    ctx.close()
+
+
 # ---------------------------------------------------------------------------
 # full size (BASELINE.json metric: 1 M Drude pairs): size-independent properties
 # ---------------------------------------------------------------------------
