@@ -1015,11 +1015,60 @@ __device__ __forceinline__ void chain_lanes_run(const ChainArgs& a, double* st, 
     }
 }
 
+// dualNH with useDrudeNHChains, CC = 2-4 links, inside a streaming launch: on the Reference platform's interleaved vectors
+// [real0, drude0, real1, drude1, ...] link i couples to link i + 2 (Ref :477, :495, numTempGroup = 2), i.e. the real chain and the Drude
+// chain never meet -- two independent chains with the arithmetic of the TGNH ones (SURVEY A9's bridge identity; Ref :471 divides
+// without the etaMass > 0 guard: both as TGNH's Drude thermostat).  Lanes 0 (real) and 2 (Drude) of the internal [real, unused,
+// Drude] order take one each through chain_both_fast, in one pass; run_dualnh, the transcription, ran them in lane 0 one after the
+// other with 2C range-tested exponentials per sub-step.  Called by lanes 0 and 2 together.  False (nothing written): the
+// arguments left the fast forms' range -- the caller falls back to run_dualnh.
+template <int CC>
+__device__ __forceinline__ bool run_dualnh_pair(const ChainArgs& a, const double* st_in, double* st_out, const bool write,
+                                                double* s_scale, const int itg, const double ke0, const double ke1, const double ke2) {
+    const ChainLayout& L = a.L;
+    const int tt = itg >> 1;                                         // 0 the real chain, 1 the Drude chain
+    double eta[CC], etaDot[CC + 1], etaDotDot[CC], etaMass[CC];
+#pragma unroll
+    for (int i = 0; i < CC; i++) {
+        eta[i] = st_in[L.off_eta + 2 * i + tt]; etaDotDot[i] = st_in[L.off_etaDotDot + 2 * i + tt]; etaMass[i] = st_in[L.off_etaMass + 2 * i + tt];
+    }
+#pragma unroll
+    for (int i = 0; i <= CC; i++) etaDot[i] = st_in[L.off_etaDot + 2 * i + tt];     // (len_etaDot = 2 C + 2: the two dummies, Ref :216-217)
+    ChainConst k;
+    const double dtc = a.dt / a.S;                                   // Ref :432-435
+    k.dtc2 = dtc / 2.0; k.dtc4 = dtc / 4.0; k.dtc8 = dtc / 8.0; k.S = a.S;
+    const double nkbt = st_in[L.off_nkbt + itg], kbT = tt ? a.drudekbT : a.realkbT;
+    const int reps = a.chain_twice ? 2 : 1;
+    double ke = tt ? ke2 : ke0, sc0 = 1.0, sc1 = 1.0, ke_post = 0.0;
+    for (int rep = 0; rep < reps; rep++) {
+        double kep, sc_rep;
+        if (!chain_both_fast<CC, false>(eta, etaDot, etaDotDot, etaMass, k, nkbt, kbT, true, ke, &sc_rep, &kep)) return false;
+        if (rep == 0) { sc0 = sc_rep; ke_post = kep; } else sc1 = sc_rep;      // (no array indexed by rep: that would live on the stack)
+        ke = kep;
+    }
+    const double total = sc0 * sc1;
+    if (s_scale) { s_scale[itg] = total; if (itg == 0) s_scale[1] = 1.0; }
+    if (!write) return true;
+    if (itg == 0) {                                                  // what run_dualnh writes for all three slots at once
+        st_out[L.off_ke + 0] = ke0; st_out[L.off_ke + 1] = ke1; st_out[L.off_ke + 2] = ke2;
+        st_out[L.off_kesum] = 0.5 * (ke0 + ke2);
+        st_out[L.off_scale_a + 1] = 1.0; st_out[L.off_scale_b + 1] = 1.0; st_out[L.off_scale + 1] = 1.0; st_out[L.off_ke_post + 1] = 0.0;
+    }
+    st_out[L.off_scale_a + itg] = sc0; st_out[L.off_ke_post + itg] = ke_post;
+    st_out[L.off_scale_b + itg] = sc1;                             // (1 when the chain ran once)
+    st_out[L.off_scale + itg] = total;
+#pragma unroll
+    for (int i = 0; i < CC; i++) { st_out[L.off_eta + 2 * i + tt] = eta[i]; st_out[L.off_etaDotDot + 2 * i + tt] = etaDotDot[i]; }
+#pragma unroll
+    for (int i = 0; i <= CC; i++) st_out[L.off_etaDot + 2 * i + tt] = etaDot[i];
+    return true;
+}
+
 // Chains of 2-4 links inside a streaming launch (the one-link chains have chain1_run): called by the 64 lanes of one
 // wavefront, converged; lane itg < NT holds its thermostat's summed kinetic energy `ke`.  TGNH: lane itg runs its thermostat
 // (run_tgnh, register-resident links; the real thermostats and the Drude thermostat in ONE pass through the fast forms,
 // chain_both_fast -- until round 4 they were two code paths of this wavefront, one after the other, and the serial section every
-// work-group waits for was twice as long: C2 with three links 33.6 k -> 44.5 k steps/s).  dualNH: lane 0 runs the Reference platform's coupled vectors (run_dualnh).  No library exp
+// work-group waits for was twice as long: C2 with three links 33.6 k -> 44.5 k steps/s).  dualNH: lanes 0 and 2 run the Reference platform's two chains where they are independent (run_dualnh_pair), lane 0 its coupled vectors otherwise (run_dualnh).  No library exp
 // (chain_exp<false>): ocml's would cost the streaming kernels ~30 registers.  Longer chains keep their own launch (chain_kernel).
 __device__ __forceinline__ void chainN_run(const ChainArgs& a, const double* st_in, double* st_out, const bool write,
                                            double* s_scale, const int itg, const double ke) {
@@ -1034,7 +1083,19 @@ __device__ __forceinline__ void chainN_run(const ChainArgs& a, const double* st_
         }
     } else {
         const double ke0 = __shfl(ke, 0, 64), ke1 = __shfl(ke, 1, 64), ke2 = __shfl(ke, 2, 64);
-        if (itg == 0) {
+        bool done = false;
+        if (L.use_drude_chains != 0) {                               // two independent chains: lanes 0 and 2, one pass (run_dualnh_pair)
+            bool ok = false;
+            if (itg == 0 || itg == 2) {
+                switch (L.C) {
+                    case 2: ok = run_dualnh_pair<2>(a, st_in, st_out, write, s_scale, itg, ke0, ke1, ke2); break;
+                    case 3: ok = run_dualnh_pair<3>(a, st_in, st_out, write, s_scale, itg, ke0, ke1, ke2); break;
+                    default: ok = run_dualnh_pair<4>(a, st_in, st_out, write, s_scale, itg, ke0, ke1, ke2); break;
+                }
+            }
+            done = __shfl((int)ok, 0, 64) != 0;                      // (the same answer in both lanes: chain_fast votes)
+        }
+        if (!done && itg == 0) {
             switch (L.C) {
                 case 2: run_dualnh<2, false>(a, st_in, st_out, write, s_scale, nullptr, ke0, ke1, ke2); break;
                 case 3: run_dualnh<3, false>(a, st_in, st_out, write, s_scale, nullptr, ke0, ke1, ke2); break;
