@@ -53,7 +53,8 @@ def parse():
                         "defer with the whole step in ONE launch whose work-groups meet on the device (step_kernel; with the "
                         "RCCL hook it steps the defer way); plain = the reference's pass structure; plain-trust = that structure with "
                         "TGNH_FLAG_TRUST_STATE_CHANGED (the begin half starts its chain from the kinetic energies the last end half "
-                        "left: no KE pass; what the OpenMM glue runs for a System without CMMotionRemover / AndersenThermostat); "
+                        "left: no KE pass; an OPTION of the OpenMM glue, off by default: it needs an accessor the reference's API class "
+                        "does not have and a System of known Force types only, INTEGRATION.md section 3); "
                         "plain-resident = the plain structure with each thermostat half one step_kernel launch; plain-resident-trust = both; "
                         "auto = resident (single precision from 3 M slots per GPU: defer) (DESIGN.md)")
     p.add_argument("--chains", type=int, default=1)
@@ -87,7 +88,7 @@ def parse():
 RCCL_SITE_OK = None
 
 
-def build_context(args, system, group, ngroups, rank, world, precision, variant):
+def build_context(args, system, group, ngroups, rank, world, precision, variant, lattice_sites=True):
     import torch
     import torch.distributed as dist
     from openmm_drudenose_amd import DrudeTGNHIntegrator, HipContext
@@ -117,7 +118,7 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant)
             dist.all_reduce(t)
             return t.cpu().numpy()
         kw = dict(allreduce=lambda t: dist.all_reduce(t), global_dof_sum=dof_sum)
-    ctx = HipContext(local, it, mode=args.mode, precision=precision, device=dev, flags=flags, **kw)
+    ctx = HipContext(local, it, mode=args.mode, precision=precision, device=dev, flags=flags, lattice_sites=lattice_sites, **kw)
     ctx.exchange = "rccl" if kw else None
     ctx.rccl_site = None
     if kw:
@@ -310,6 +311,63 @@ def timed_run(ctx, steps, warmup, world, graph_steps=0, dom_kid=0):
     if dom and dom[1]:
         ctx.leg["dominant_in_timed_region"] = {"avg_us": round(dom[0] / dom[1] * 1e3, 3), "launches": dom[1]}
     return dt
+
+
+def integrator_only_run(ctx, steps, world, graph_steps):
+    """The integrator's own launches as a TIMED REGION: the same barrier + synchronize bracket as timed_run around steps WITHOUT
+    the force call-out (tgnh_run_steps).  The force buffer is zeroed first -- left as the last call-out filled it, a frozen spring
+    force drives every Drude particle through its hard wall within ten steps and the thermostats out of every polynomial's
+    range -- so these steps are free flight under the thermostats: the same launches on the same arrays, not a trajectory.
+    At most 60 steps (a free Drude pair reaches its hard wall after ~80), a multiple of the graph's.  Call last: the state is
+    spent afterwards."""
+    import torch
+    import torch.distributed as dist
+    n = max(1, min(steps, 60))
+    ctx.flush()                                        # (a deferred variant owes velm a half kick of the OLD force buffer)
+    ctx.force.zero_()
+    replay = None
+    if graph_steps > 0 and ctx.graph_used:
+        g = min(graph_steps, n)
+        n = n // g * g
+        try:
+            replay = ctx.capture_steps(g, forces=False)
+        except Exception as e:
+            print(f"[bench] integrator-only capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+        if world > 1:
+            t = torch.tensor([1 if replay is not None else 0], dtype=torch.int32, device=CDEV)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0:
+                replay = None
+        torch.cuda.synchronize()
+        if replay is not None:
+            replay()
+            torch.cuda.synchronize()
+    else:
+        ctx.step_without_forces(2)                     # (the transition out of the steps with a call-out)
+    gc.collect()
+    gc.disable()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if replay is None:
+        ctx.step_without_forces(n)
+    else:
+        for _ in range(n // g):
+            replay()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=CDEV)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return {"value": round(n / dt, 1), "unit": "steps/s", "steps": n, "us_per_step": round(dt / n * 1e6, 2), "hipgraph": replay is not None,
+            "how": "timed region (barrier + synchronize on both sides, max over ranks) around tgnh_run_steps: step_begin + step_end with "
+                   "NO force call-out launch, force buffer zeroed (free flight under the thermostats: the same launches on the same "
+                   "arrays, not a trajectory); right after the headline leg, same context"}
 
 
 def device_copy_gbps():
@@ -730,6 +788,8 @@ def main():
                                              "(the region itself was a hipGraph replay, or ran another launch structure than asked for)")
     achieved = bytes_dom / (dom["avg_us"] * 1e-6) / 1e9
     local_slots = ctx.n
+    harness_force = ctx.sites_kind()                   # how the call-out inside `value` found its tether sites: lattice | packed | x0
+    int_only = integrator_only_run(ctx, args.steps, world, gsteps)
     close_sharded(ctx)
 
     extra = {}
@@ -749,6 +809,12 @@ def main():
             c2 = build_context(args, system, group, ngroups, rank, world, prec, var)
             timed_run(c2, args.steps, args.warmup, world, 0, dominant_kid(var))
             extra[f"{prec}/{var}"] = c2.leg
+            c2.close()
+        if harness_force == "lattice":           # the headline again with the harness force reading PACKED sites (any box, not
+            # only one molecule on a cubic lattice: what rounds 1-3 timed): `value` moves with the call-out stand-in, the integrator does not
+            c2 = build_context(args, system, group, ngroups, rank, world, args.precision, args.variant, lattice_sites=False)
+            timed_run(c2, args.steps, args.warmup, world, gsteps, dominant_kid(args.variant))
+            extra[f"{args.precision}/{args.variant}/packed-sites"] = dict(c2.leg, harness_force=c2.sites_kind())
             c2.close()
         if args.mode == "TGNH":                  # the other semantic mode (platforms/reference's algorithm), same workload
             import copy
@@ -775,7 +841,8 @@ def main():
                 "workload": f"SWM4-NDP water box, {args.molecules} molecules = {system.num_particles} particle slots, "
                             f"{system.num_pairs} Drude pairs, 1 temperature group (+ molecular-COM and Drude thermostats), "
                             f"{args.mode} mode, {args.precision} precision, numNHChains={args.chains}, hard wall "
-                            f"{args.hardwall} nm, harness force call-out inside the timed region",
+                            f"{args.hardwall} nm, harness force call-out inside the timed region (harness_force: {harness_force})",
+                "harness_force": harness_force,
                 "precision": args.precision, "variant": args.variant,
                 "variant_ran": args.variant if dkid == dominant_kid(args.variant) else {"resident": "defer", "plain-resident": "plain", "plain-resident-trust": "plain-trust"}.get(args.variant, args.variant),
                 "hipgraph": graph_used,
@@ -805,11 +872,11 @@ def main():
         # `value` times whole steps, the harness force call-out included (in a real context that slot is OpenMM's
         # calcForcesAndEnergy).  The integrator's own launches alone (SURVEY 8d reports the force kernel separately):
         own = sum(v["avg_us"] * v["launches"] for k, v in rows.items() if k != "harness force") / leg["instrumented_steps"]
+        out["integrator_only"] = dict(int_only, vs_model_roofline_steps_per_s=round(HBM_PEAK_GBS * 1e9 / b_step * world, 1))
         if own > 0:
-            out["integrator_only"] = {"steps_per_s": round(1e6 / own, 1), "us_per_step": round(own, 2),
-                                      "how": "sum of the durations of the integrator's own launches per step (instrumented repeat), force call-out excluded; "
-                                             "derived, not a timed region",
-                                      "vs_model_roofline_steps_per_s": round(HBM_PEAK_GBS * 1e9 / b_step * world, 1)}
+            out["integrator_only"]["sum_of_kernels"] = {"steps_per_s": round(1e6 / own, 1), "us_per_step": round(own, 2),
+                                                        "how": "sum of the durations of the integrator's own launches per step of the real trajectory "
+                                                               "(instrumented repeat), force call-out excluded; derived, not a timed region"}
         if extra:
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:

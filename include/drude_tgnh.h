@@ -158,7 +158,11 @@ tgnh_status tgnh_destroy(tgnh_handle h);
  *   posq   real4  [N]  (x,y,z,q)
  *   velm   mixed4 [N]  (vx,vy,vz,1/m)   -- w is read as the inverse mass
  *   force  int64  [3*padded]  fixed point x 2^32, planes x|y|z
- *   pos_delta mixed4 [N] */
+ *   pos_delta mixed4 [N]
+ * When a pointer differs from the one bound before, what the runtime knows of the allocation behind each pointer is checked
+ * against what the launches touch (TGNH_ERR_ARG: a float4 array bound as double4, N for padded).  A call with the five pointers
+ * already bound returns at once WITHOUT that check (the glue binds at every step): an array freed and allocated again, smaller,
+ * at the same address is the caller's to rebind through a NULL-free change of any pointer, or to not do. */
 tgnh_status tgnh_bind_buffers(tgnh_handle h, void* posq, void* posq_correction, void* velm,
                               const void* force, void* pos_delta);
 
@@ -195,6 +199,15 @@ tgnh_status tgnh_set_resident_share(tgnh_handle h, int share);
 /* Work-groups of the resident step kernel per compute unit that tgnh_create found resident together (a census launch checks
  * the occupancy query); 0 = the handle steps the DEFER_SCALE way (flag not set, or nothing passed the census). */
 tgnh_status tgnh_get_resident_work_groups(tgnh_handle h, int* per_compute_unit);
+/* How this handle steps: *gather = 0 the tiled kernels (every Drude partner and molecular centre of mass an on-chip look-up inside
+ * a tile of <= 512 consecutive slots, <= 32 temperature groups), 1 the GATHER path -- the reference's own un-fused kernels by
+ * global index (drudeTGNH.cu:82-301, 307-365, 435-574: normalParticles / pairParticles / particleResId lists, bins sized G + 2),
+ * taken for what the tiles cannot hold: a Drude particle more than a tile from its parent, pairs overlapping so densely in a long
+ * molecule that no cut between two of them lies within a tile's reach, more than 32 temperature groups (up to 2046), chains
+ * too long for the on-chip forms; 2 the same with its own row sum and chain kernels (more than 34 thermostats).  Much slower per
+ * slot (every look-up a global load) and always in the reference's pass structure: TGNH_FLAG_DEFER_SCALE, _RESIDENT_STEP,
+ * _TRUST_STATE_CHANGED are ignored on it.  *reason (may be NULL): why, "" for the tiled path; valid until tgnh_destroy. */
+tgnh_status tgnh_get_step_path(tgnh_handle h, int* gather, const char** reason);
 /* Which kernel this handle's next tgnh_step_begin runs as its one launch: 0 none (the streaming launches), 1 step_kernel (512-slot
  * tiles, one-link chains), 2 wstep_kernel (a whole deferred step over wave tiles, chains of 1-4 links). */
 tgnh_status tgnh_get_resident_kernel(tgnh_handle h, int* which);
@@ -274,7 +287,8 @@ tgnh_status tgnh_get_last_kinetic_energies(tgnh_handle h, void* stream, double* 
 tgnh_status tgnh_get_last_scale_factors(tgnh_handle h, void* stream, double* scale);
 /* bit0: a Drude beyond 2x the hard wall; bit1: the harness SHAKE did not converge; bit2: a mailbox exchange timed out;
  * bit3: the work-groups of a resident step did not all meet; bit4: a kinetic-energy pass that sums its own rows (tail sum) did not
- * receive every row -- the sums were left as NaN.  *flags is always filled in.  bit2, bit3, bit4 -- and bit0 in DUALNH mode, where the Reference platform throws
+ * receive every row -- the sums were left as NaN -- or a chain was handed a NaN sum (with an all-reduce attached the NaN of one
+ * rank's failed pass reaches every rank, and every rank sets the bit itself).  *flags is always filled in.  bit2, bit3, bit4 -- and bit0 in DUALNH mode, where the Reference platform throws
  * (ReferenceDrudeTGNHKernels.cpp:311-312) -- are FAILURES and sticky: once the host has seen one (here, at any other
  * tgnh_get_*, at tgnh_exchange_detach, or through the read-back the library enqueues behind every 64th step) every later
  * tgnh_step_*, tgnh_flush and tgnh_get_* returns TGNH_ERR_STATE / TGNH_ERR_HARDWALL with the message in tgnh_last_error(). */
@@ -332,6 +346,10 @@ tgnh_status tgnh_harness_lattice_hint(tgnh_handle h, int mol_slots, int side, do
 tgnh_status tgnh_harness_sites_kind(tgnh_handle h, int* kind);
 /* nsteps x { step_begin, harness force into the bound force buffer, step_end }
  * enqueued back to back with no host synchronisation. */
+/* The step loop with NO call-out: nsteps x (tgnh_step_begin, tgnh_step_end) on whatever the bound force buffer holds.  For
+ * timing the integrator's own launches between two synchronisations (bench.py's integrator_only leg zeroes the buffer first:
+ * a frozen spring force would drive every Drude particle through its hard wall within ten steps).  Not an integrator of anything. */
+tgnh_status tgnh_run_steps(tgnh_handle h, int nsteps, void* stream);
 tgnh_status tgnh_run_harness(tgnh_handle h, const void* x0, double k_drude, double k_tether,
                              int nsteps, void* stream);
 

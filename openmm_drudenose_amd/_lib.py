@@ -58,6 +58,7 @@ SIGNATURES = {
     "tgnh_set_resident_share": (C.c_int, [C.c_void_p, C.c_int]),
     "tgnh_get_resident_work_groups": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "tgnh_get_resident_kernel": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "tgnh_get_step_path": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
     "tgnh_exchange_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "tgnh_exchange_attach": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tgnh_exchange_attach_pointers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "tgnh_harness_lattice_hint": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, c_f64p, C.c_int]),
     "tgnh_harness_sites_kind": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "tgnh_run_harness": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p]),
+    "tgnh_run_steps": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "tgnh_harness_set_clusters": (C.c_int, [C.c_void_p, C.c_int, c_i32p, c_f64p]),
     "tgnh_harness_shake_positions": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
     "tgnh_harness_shake_velocities": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),

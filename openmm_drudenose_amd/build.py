@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdrudetgnh_hip.so")
-SOURCES = ["tgnh_host.cpp", "tgnh_kernels.hip", "tgnh_harness.hip"]
-HEADERS = ["tgnh_internal.h", "tgnh_chain_device.h", os.path.join("..", "..", "include", "drude_tgnh.h")]
+SOURCES = ["tgnh_host.cpp", "tgnh_kernels.hip", "tgnh_gather.hip", "tgnh_harness.hip"]
+HEADERS = ["tgnh_internal.h", "tgnh_chain_device.h", "tgnh_tile_device.h", os.path.join("..", "..", "include", "drude_tgnh.h")]
 ARCH = "gfx950"
 
 

@@ -8,6 +8,11 @@
 #include "SimTKOpenMMRealType.h"
 #include "openmm/KernelFactory.h"
 #include "openmm/hip/HipPlatform.h"
+#ifdef DRUDETGNH_THERMOSTAT_CHECKPOINT
+#include "openmm/serialization/DrudeTGNHIntegratorProxy.h"
+#include <map>
+#endif
+#include <cstring>
 #include <typeinfo>
 #include <vector>
 
@@ -19,7 +24,38 @@ void HipIntegrateDrudeTGNHStepKernel::check(tgnh_status rc) const {
         throw OpenMMException(tgnh_last_error());       // same channel as the reference's throws
 }
 
+#ifdef DRUDETGNH_THERMOSTAT_CHECKPOINT
+// Which kernel integrates for which integrator object: what the serialization proxy's reader looks up (DrudeTGNHThermostatStore,
+// serialization/include/openmm/serialization/DrudeTGNHIntegratorProxy.h).  One context per integrator (OpenMM's rule).
+static std::map<const DrudeTGNHIntegrator*, HipIntegrateDrudeTGNHStepKernel*> kernelOf;
+
+bool HipIntegrateDrudeTGNHStepKernel::readThermostat(DrudeTGNHThermostatState& state) {
+    ContextSelector selector(cu);
+    void* stream = (void*) cu.getCurrentStream();
+    std::vector<double>* arrays[3] = {&state.eta, &state.etaDot, &state.etaDotDot};
+    for (int which = 0; which < 3; which++) {
+        int len = 0;
+        check(tgnh_get_thermostat_len(handle, which, &len));
+        arrays[which]->resize(len);
+        check(tgnh_get_thermostat_state(handle, which, stream, arrays[which]->data()));
+    }
+    int64_t steps = 0;
+    check(tgnh_get_time(handle, &state.time, &steps));
+    state.stepCount = steps;
+    return true;
+}
+
+static bool readThermostatOf(const DrudeTGNHIntegrator* integrator, DrudeTGNHThermostatState& state) {
+    std::map<const DrudeTGNHIntegrator*, HipIntegrateDrudeTGNHStepKernel*>::iterator it = kernelOf.find(integrator);
+    return it != kernelOf.end() && it->second->readThermostat(state);
+}
+#endif
+
 HipIntegrateDrudeTGNHStepKernel::~HipIntegrateDrudeTGNHStepKernel() {
+#ifdef DRUDETGNH_THERMOSTAT_CHECKPOINT
+    for (std::map<const DrudeTGNHIntegrator*, HipIntegrateDrudeTGNHStepKernel*>::iterator it = kernelOf.begin(); it != kernelOf.end(); )
+        if (it->second == this) kernelOf.erase(it++); else ++it;
+#endif
     if (handle != nullptr) {
         ContextSelector selector(cu);
         tgnh_destroy(handle);
@@ -51,15 +87,30 @@ void HipIntegrateDrudeTGNHStepKernel::initialize(const System& system, const Dru
         double distance;
         system.getConstraintParameters(i, ci[i], cj[i], distance);
     }
-    bool hasCMM = false, editsVelocities = false;
+    bool hasCMM = false, onlyKnownForces = true;
+    // DRUDETGNH_TRUST_STATE_CHANGED is taken only for a System whose every Force is of a type KNOWN not to write velocities in
+    // updateContextState (an allow-list by class name, as the reference sniffs its barostat, DrudeTGNHIntegrator.cpp:117-121):
+    // CMMotionRemover and AndersenThermostat do so silently (no stateChanged), and a plugin Force this file has never heard of
+    // might -- with a deny-list such a Force would leave the begin half on a stale sum with no error.
+    static const char* const velocityNeutral[] = {"HarmonicBondForce", "HarmonicAngleForce", "PeriodicTorsionForce", "RBTorsionForce",
+        "CMAPTorsionForce", "NonbondedForce", "CustomNonbondedForce", "CustomBondForce", "CustomAngleForce", "CustomTorsionForce",
+        "CustomCompoundBondForce", "CustomCentroidBondForce", "CustomExternalForce", "CustomHbondForce", "CustomManyParticleForce",
+        "CustomGBForce", "CustomCVForce", "GBSAOBCForce", "GayBerneForce", "DrudeForce", "MonteCarloBarostat",
+        "MonteCarloAnisotropicBarostat", "MonteCarloMembraneBarostat", "MonteCarloFlexibleBarostat"};
     for (int i = 0; i < system.getNumForces(); i++) {
         if (dynamic_cast<const CMMotionRemover*>(&system.getForce(i)) != nullptr)
             hasCMM = true;
-        // forces whose updateContextState writes velocities behind the integrator (DrudeTGNHIntegrator.cpp:186), without stateChanged
-        if (dynamic_cast<const CMMotionRemover*>(&system.getForce(i)) != nullptr || dynamic_cast<const AndersenThermostat*>(&system.getForce(i)) != nullptr)
-            editsVelocities = true;
+        const char* type = typeid(system.getForce(i)).name();          // (mangled: the class name is its tail, "...<len>Name" + "E")
+        bool known = false;
+        for (size_t k = 0; k < sizeof(velocityNeutral) / sizeof(velocityNeutral[0]); k++) {
+            const char* at = strstr(type, velocityNeutral[k]);
+            if (at != nullptr && (at[strlen(velocityNeutral[k])] == 'E' || at[strlen(velocityNeutral[k])] == '\0'))
+                known = true;
+        }
+        if (!known)
+            onlyKnownForces = false;
     }
-    (void) editsVelocities;                                // (read under DRUDETGNH_TRUST_STATE_CHANGED only)
+    (void) onlyKnownForces;                                // (read under DRUDETGNH_TRUST_STATE_CHANGED only)
 
     tgnh_desc d = {};
     d.struct_size = sizeof(tgnh_desc);
@@ -77,9 +128,10 @@ void HipIntegrateDrudeTGNHStepKernel::initialize(const System& system, const Dru
     // velocities between two steps without the integrator hearing of it: Context::setVelocities and friends reach
     // DrudeTGNHIntegrator::stateChanged (DrudeTGNHIntegrator.cpp:166-170), which execute() below forwards through
     // integrator.isKineticEnergySumValid() -- the ONE-LINE accessor this option needs in DrudeTGNHIntegrator.h (INTEGRATION.md
-    // section 3) -- but CMMotionRemover and AndersenThermostat edit velocities in updateContextState silently, so a System that
-    // holds either keeps the reference's passes.  (A plugin Force that does the same must not be combined with this option.)
-    trustStateChanged = !editsVelocities;
+    // section 3); Forces are vetted by the allow-list above.  Context::applyVelocityConstraints (a user call between steps) writes
+    // velocities WITHOUT stateChanged: a caller that uses it with this option must follow it with setVelocities(getVelocities())
+    // or not build with this option.
+    trustStateChanged = onlyKnownForces;
     if (trustStateChanged)
         d.flags |= TGNH_FLAG_TRUST_STATE_CHANGED;
 #endif
@@ -110,6 +162,25 @@ void HipIntegrateDrudeTGNHStepKernel::initialize(const System& system, const Dru
     d.use_com_temp_group = integrator.getUseCOMTempGroup();
     d.max_drude_distance = integrator.getMaxDrudeDistance();
     check(tgnh_create(&d, &handle));
+#ifdef DRUDETGNH_THERMOSTAT_CHECKPOINT
+    // an integrator that came out of the XML proxy with a ThermostatState child continues where the checkpoint was taken
+    // (thermostat arrays + clock: the trajectory's bits are a function of state and step counter, include/drude_tgnh.h)
+    kernelOf[&integrator] = this;
+    DrudeTGNHThermostatStore::setReader(readThermostatOf);
+    DrudeTGNHThermostatState state;
+    if (DrudeTGNHThermostatStore::take(&integrator, state)) {
+        void* stream = (void*) cu.getCurrentStream();
+        const std::vector<double>* arrays[3] = {&state.eta, &state.etaDot, &state.etaDotDot};
+        for (int which = 0; which < 3; which++) {
+            int len = 0;
+            check(tgnh_get_thermostat_len(handle, which, &len));
+            if ((int) arrays[which]->size() != len)
+                throw OpenMMException("DrudeTGNHIntegrator: the checkpointed thermostat state does not fit this System (numNHChains / temperature groups changed?)");
+            check(tgnh_set_thermostat_state(handle, which, stream, arrays[which]->data()));
+        }
+        check(tgnh_set_time(handle, state.time, state.stepCount));
+    }
+#endif
 }
 
 void HipIntegrateDrudeTGNHStepKernel::execute(ContextImpl& context, const DrudeTGNHIntegrator& integrator) {

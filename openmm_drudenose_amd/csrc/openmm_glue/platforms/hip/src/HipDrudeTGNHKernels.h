@@ -18,6 +18,9 @@ public:
     void initialize(const System& system, const DrudeTGNHIntegrator& integrator, const DrudeForce& force);
     void execute(ContextImpl& context, const DrudeTGNHIntegrator& integrator);
     double computeKineticEnergy(ContextImpl& context, const DrudeTGNHIntegrator& integrator, bool isKESumValid);
+#ifdef DRUDETGNH_THERMOSTAT_CHECKPOINT
+    bool readThermostat(struct DrudeTGNHThermostatState& state);     // for the serialization proxy (DrudeTGNHThermostatStore)
+#endif
 private:
     void check(tgnh_status rc) const;
     HipContext& cu;

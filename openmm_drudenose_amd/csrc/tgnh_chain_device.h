@@ -10,7 +10,7 @@
 
 namespace tgnh {
 #ifdef TGNH_TRACE
-__device__ double g_chain_dbg[4];   // largest exponent argument seen by the real / Drude fast paths, times each left the polynomial's range
+static __device__ __attribute__((unused)) double g_chain_dbg[4];   // largest exponent argument seen by the real / Drude fast paths, times each left the polynomial's range
 #endif
 
 // Contraction is left on: every a*b+c below may become one fma (<= 1 ulp per operation away from the separately

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <type_traits>
 
 #include <dlfcn.h>
 #include <mutex>
@@ -66,6 +67,57 @@ static tgnh_status settle_end(tgnh_handle h, hipStream_t s);
 static bool resident_now(tgnh_handle h);
 
 // ---------------------------------------------------------------------------
+// A1 for the gather path (tgnh_gather.hip): the reference's own index lists -- normalParticles, pairParticles (Ref :113-137,
+// Cu :111-151), particleTempGroup, particleResId, particlesInResidues (Cu :114-125) -- and nothing else: no tiles, no per-slot
+// words.  Taken by build_topology for what the tiles cannot hold (c->generic_reason says what).
+// ---------------------------------------------------------------------------
+static tgnh_status build_gather_topology(tgnh_context* c, const std::vector<int>& role, const std::vector<int>& partner,
+                                         const std::vector<int>& res_order) {
+    const tgnh_desc& d = c->d;
+    const int N = d.num_particles, P = d.num_pairs;
+    const bool com = d.mode == TGNH_MODE_TGNH && d.use_com_temp_group;
+    c->tile_start.assign(1, N); c->tile_res.assign(1, 0); c->num_tiles = 0;
+    c->res_entries.assign(1, make_int2(0, 0));
+    c->meta.clear(); c->wave_tile.clear(); c->wmeta.clear(); c->num_wtiles = 0;
+    c->tile_pat.assign(1, 0u); c->wtile_pat.assign(1, 0u); c->pattern.assign(PATTERN_WORDS, 0u); c->wpattern.assign(PATTERN_WORDS, 0u);
+    c->big_first.clear(); c->big_count.clear(); c->num_big = 0;
+    // residues in order of first appearance; a particle's residue as its index in that table
+    c->g_res_table.clear(); c->g_resid.assign(N, 0);
+    if (com) {
+        std::vector<int> internal(d.num_residues, -1);
+        for (int r : res_order) { internal[r] = (int)c->g_res_table.size(); c->g_res_table.push_back(make_int2(c->res_count[r], c->res_first[r])); }
+        for (int i = 0; i < N; i++) c->g_resid[i] = internal[c->resid[i]];
+    }
+    if (c->g_res_table.empty()) c->g_res_table.push_back(make_int2(0, 0));
+    c->g_pairs.resize(std::max(P, 1));
+    for (int i = 0; i < P; i++) c->g_pairs[i] = make_int2(c->pair_drude[i], c->pair_parent[i]);
+    c->g_partner.assign(N, -1);                                  // harness force: partner | is-Drude << 31
+    for (int i = 0; i < N; i++)
+        if (partner[i] >= 0) c->g_partner[i] = role[i] == (int)ROLE_DRUDE ? (int)((unsigned)partner[i] | 0x80000000u) : partner[i];
+    if (c->host_only) return TGNH_OK;
+    auto up = [](auto** dst, const auto& v) -> hipError_t {
+        typedef typename std::remove_reference<decltype(v)>::type::value_type T;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), sizeof(T) * std::max<size_t>(v.size(), 1));
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
+    };
+    HIP_OK(up(&c->d_g_normal, c->normal));
+    HIP_OK(up(&c->d_g_pairs, c->g_pairs));
+    HIP_OK(up(&c->d_g_group, c->group));
+    HIP_OK(up(&c->d_g_resid, c->g_resid));
+    HIP_OK(up(&c->d_g_res_table, c->g_res_table));
+    HIP_OK(up(&c->d_g_partner, c->g_partner));
+    HIP_OK(hipMalloc(&c->d_g_com, 32 * c->g_res_table.size()));                 // mixed4 per residue
+    HIP_OK(hipMemset(c->d_g_com, 0, 32 * c->g_res_table.size()));
+    // (the tiled path's tables, so that nothing holds a null pointer; no launch of the gather path reads them)
+    HIP_OK(hipMalloc(&c->d_meta, sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&c->d_tile_start, sizeof(int)));
+    HIP_OK(hipMalloc(&c->d_tile_res, sizeof(int)));
+    HIP_OK(hipMalloc(&c->d_res_table, sizeof(int2)));
+    return TGNH_OK;
+}
+
+// ---------------------------------------------------------------------------
 // A1: topology + tiles
 // ---------------------------------------------------------------------------
 static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
@@ -100,8 +152,11 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
     if (tg) {
         for (int i = 0; i < N; i++)
             if (c->group[i] < 0 || c->group[i] >= d->num_groups) return fail(TGNH_ERR_ARG, "temperature group index out of range");
-        if (d->num_groups > MAX_GROUPS)
-            return fail(TGNH_ERR_UNSUPPORTED, "more than 32 temperature groups are not supported by this build");
+        if (d->num_groups > MAX_GROUPS) {                                     // K :138-200 sizes its bins by G + 2, no limit: the gather path
+            c->generic = true; c->generic_reason = "more than 32 temperature groups";
+            if (d->num_groups + 2 > GATHER_MAX_NT)
+                return fail(TGNH_ERR_UNSUPPORTED, "more than " + std::to_string(GATHER_MAX_NT - 2) + " temperature groups (a wavefront's kinetic-energy bins no longer fit the LDS)");
+        }
         for (int i = 0; i < d->num_constraints; i++) {                        // Cu :186-193
             if (!d->constraint_i || !d->constraint_j) break;
             const int a = d->constraint_i[i], b = d->constraint_j[i];
@@ -125,8 +180,11 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
             if (r < 0 || r >= R) return fail(TGNH_ERR_ARG, "residue index out of range");
             c->res_count[r] += 1;
             if (prev != r) {
-                if (com && c->res_first[r] != -1)
-                    return fail(TGNH_ERR_UNSUPPORTED, "particles of a residue are not contiguous");
+                // A residue in several runs (e.g. all Drude particles appended behind the atoms): the reference's table still says
+                // (count, first) with `first` the start of the LAST run (Cu :121-124) and its COM kernel walks `count` particles
+                // from there (K :90-91), whoever they belong to.  The tiles need molecules in one piece; the gather path reproduces
+                // that walk as it is (so does the oracle).
+                if (com && c->res_first[r] != -1 && !c->generic) { c->generic = true; c->generic_reason = "particles of a residue are not contiguous"; }
                 c->res_first[r] = i;
                 if (res_internal[r] == -1) { res_internal[r] = (int)res_order.size(); res_order.push_back(r); }
                 prev = r;
@@ -204,7 +262,7 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
     if (const char* e = getenv("TGNH_TILE_CAP")) { int v = atoi(e); if (v >= 64 && v <= TILE_SLOTS) cap = v; }
 #endif
     int start = 0;
-    while (start < N) {
+    while (start < N && !c->generic) {
         int end = std::min(start + cap, N);
         auto ok = [&](int e) {
             if (e < N && forbid[e] > 0) return false;
@@ -212,8 +270,11 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
             return true;
         };
         while (end > start && !ok(end)) end--;
-        if (end == start)
-            return fail(TGNH_ERR_UNSUPPORTED, "a Drude pair spans more than one 512-slot tile");
+        if (end == start) {              // no legal cut within a tile's reach: a Drude far from its parent (K :171-186 gathers by arbitrary
+            c->generic = true;           // index), or pairs overlapping so densely that no cut between two of them exists -> the gather path
+            c->generic_reason = "a Drude pair (or a chain of overlapping pairs) spans more than one 512-slot tile";
+            break;
+        }
         end = mol_cut(start, end, cap, ok);
         if (align > 1 && end < N) {           // prefer a cut on an `align`-slot boundary close by
             for (int e = end; e > start && e > end - 64; e--)
@@ -224,6 +285,7 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
     }
     c->tile_start.push_back(N);
     c->num_tiles = (int)c->tile_start.size() - 1;
+    if (c->generic) return build_gather_topology(c, role, partner, res_order);
 
     // per-tile residue entries (count, first slot) -- count < 0: big molecule, COM at table index -count-1 --
     // and the packed per-slot words
@@ -244,11 +306,11 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
             if (partner[i] >= 0) {
                 off = partner[i] - i;
                 if (partner[i] < c->tile_start[t] || partner[i] >= c->tile_start[t + 1] || off < -1024 || off > 1023)
-                    return fail(TGNH_ERR_UNSUPPORTED, "internal: Drude partner outside its tile");
+                    return fail(TGNH_ERR_STATE, "internal: Drude partner outside its tile");
             }
             c->meta[i] = pack_meta((uint32_t)role[i], (uint32_t)c->group[i], off, (uint32_t)(com ? local : 0));
         }
-        if (com && local + 1 > TILE_RES) return fail(TGNH_ERR_UNSUPPORTED, "internal: too many molecules in a tile");
+        if (com && local + 1 > TILE_RES) return fail(TGNH_ERR_STATE, "internal: too many molecules in a tile");
     }
     c->tile_res[c->num_tiles] = (int)entries.size();
     if (entries.empty()) entries.push_back(make_int2(0, 0));
@@ -550,6 +612,15 @@ static void free_device(tgnh_context* c) {
     if (c->d_lat_tab) (void)hipFree(c->d_lat_tab);
     if (c->d_big_table) (void)hipFree(c->d_big_table);
     if (c->d_big_com) (void)hipFree(c->d_big_com);
+    if (c->d_g_normal) (void)hipFree(c->d_g_normal);
+    if (c->d_g_pairs) (void)hipFree(c->d_g_pairs);
+    if (c->d_g_group) (void)hipFree(c->d_g_group);
+    if (c->d_g_resid) (void)hipFree(c->d_g_resid);
+    if (c->d_g_res_table) (void)hipFree(c->d_g_res_table);
+    if (c->d_g_partner) (void)hipFree(c->d_g_partner);
+    if (c->d_g_com) (void)hipFree(c->d_g_com);
+    if (c->d_g_scratch) (void)hipFree(c->d_g_scratch);
+    if (c->d_g_x0) (void)hipFree(c->d_g_x0);
     if (c->d_partials) (void)hipFree(c->d_partials);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->d_stage) (void)hipFree(c->d_stage);
@@ -585,10 +656,15 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     if (d->mode == TGNH_MODE_DUALNH && d->num_pairs == 0)   // Ref :181 reads pairParticles[0]; its chain divides by the Drude thermostat mass 0
         return fail(TGNH_ERR_UNSUPPORTED, "dualNH mode needs at least one Drude pair (the Reference platform does too)");
     if (d->step_size <= 0) return fail(TGNH_ERR_ARG, "step size must be positive");
-    {   // the chain kernel keeps chains longer than 4 links in a 2048-double LDS scratch
+    bool long_chain = false;
+    {   // the chain kernel keeps chains longer than 4 links (16 in TGNH mode: chain_long_kernel) in a 2048-double LDS scratch; what
+        // does not fit runs a thermostat per thread with its links in global memory (gather_chain_kernel, TGNH mode)
         const long need = d->mode == TGNH_MODE_TGNH ? (long)(d->num_groups + 2) * (4L * d->num_nh_chains + 1)
                                                     : 4L * (2L * d->num_nh_chains + 4);
-        if (d->num_nh_chains > 4 && need > 2048) return fail(TGNH_ERR_UNSUPPORTED, "numNHChains too large for the on-device chain");
+        if (d->num_nh_chains > (d->mode == TGNH_MODE_TGNH ? 16 : 4) && need > 2048) {
+            if (d->mode != TGNH_MODE_TGNH) return fail(TGNH_ERR_UNSUPPORTED, "numNHChains too large for the on-device chain");
+            long_chain = true;
+        }
     }
     // device == -1: host-only handle for the host logic (topology, tiles, dof); every launch on it fails
     const bool host_only = d->device == -1;
@@ -607,17 +683,25 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     c->drudekbT = d->kB * d->drude_temperature;
     make_layout(c);
     c->gb = c->L.G <= 1 ? 1 : (c->L.G <= 4 ? 4 : (c->L.G <= 8 ? 8 : 0));   // 0: KE bins in LDS
+    if (long_chain) { c->generic = true; c->generic_reason = "a chain too long for the LDS-resident form"; }
     if (!host_only) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     }
     tgnh_status rc = build_topology(c, d);
     if (rc != TGNH_OK) { free_device(c); delete c; return rc; }
+    if (c->generic) {
+        // The gather path steps in the reference's own pass structure, velocities never lagging: the flags that change the
+        // structure are dropped (all of them leave the trajectory what it is; tgnh_flush has nothing to do, state setters
+        // between steps are allowed as without TGNH_FLAG_DEFER_SCALE)
+        c->d.flags &= ~(TGNH_FLAG_DEFER_SCALE | TGNH_FLAG_RESIDENT_STEP | TGNH_FLAG_TRUST_STATE_CHANGED | TGNH_FLAG_WAVE_TILES);
+        c->gather_chain = c->d.mode == TGNH_MODE_TGNH && (c->L.NT > MAX_GROUPS + 2 || long_chain);
+    }
     // KE passes and the one-launch step over wave tiles: register bins (G <= 8), and tiles that fill their wavefront -- a wave
     // tile ends where a molecule does, so 35-slot cations leave 45 of 64 lanes busy and the 512-slot tiles, cut the same way but
     // eight times as long, win (ionic liquid 100 k: 42.0 k steps/s on the tile kernels, 40.3 k on wave tiles; 60-slot water
     // tiles: 94 % full)
-    c->wave_ke = !c->wave_tile.empty() && c->gb != 0 &&
+    c->wave_ke = !c->generic && !c->wave_tile.empty() && c->gb != 0 &&
                  ((d->flags & TGNH_FLAG_WAVE_TILES) || (double)d->num_particles >= 0.9 * WAVE_SLOTS * (double)c->num_wtiles);
 #ifdef TGNH_TUNING
     if (const char* e = getenv("TGNH_WAVE_KE")) c->wave_ke = c->wave_ke && e[0] != '0';
@@ -636,10 +720,10 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
                 }
             }
         }
-        if ((d->flags & TGNH_FLAG_DEFER_SCALE) && !inside) { free_device(c); delete c; return fail(TGNH_ERR_UNSUPPORTED, "DEFER_SCALE needs every molecule inside one temperature group"); }
+        if ((c->d.flags & TGNH_FLAG_DEFER_SCALE) && !inside) { free_device(c); delete c; return fail(TGNH_ERR_UNSUPPORTED, "DEFER_SCALE needs every molecule inside one temperature group"); }
         // TRUST_STATE_CHANGED (the reference's pass structure without the begin half's KE pass) asks the same of the topology;
         // where it does not hold the flag is ignored -- the handle recomputes, as without it (tgnh_get_pending_state bit 9 never shows)
-        c->carry_ok = (d->flags & TGNH_FLAG_TRUST_STATE_CHANGED) && !(d->flags & TGNH_FLAG_DEFER_SCALE) && inside;
+        c->carry_ok = (c->d.flags & TGNH_FLAG_TRUST_STATE_CHANGED) && !(c->d.flags & TGNH_FLAG_DEFER_SCALE) && inside;
     }
     local_dof_terms(c);
     c->global_terms = c->local_terms;
@@ -678,7 +762,7 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
 #ifdef TGNH_TUNING
         if (const char* e6 = getenv("TGNH_INLINE_MULTI_MAX")) inline_multi_max = atoi(e6);
 #endif
-        c->inline_chain = want && (c->L.C == 1 || (c->L.C <= 4 && d->num_particles < inline_multi_max));
+        c->inline_chain = want && !c->generic && (c->L.C == 1 || (c->L.C <= 4 && d->num_particles < inline_multi_max));
         if (c->L.total > 256 && c->L.C > 1) c->inline_chain = c->inline_chain && false;     // (wstep_kernel parks the block in 256 doubles)
     }
     auto alloc = [&]() -> tgnh_status {
@@ -692,6 +776,7 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&c->h_status_seen), sizeof(uint32_t), hipHostMallocDefault));
         *c->h_status_seen = 0;
 
+        if (c->gather_chain && c->L.C > 4) HIP_OK(hipMalloc(&c->d_g_scratch, sizeof(double) * (size_t)c->L.NT * (4 * c->L.C + 1)));
         HIP_OK(hipMalloc(&c->d_scalar, sizeof(double) * (1 + PLAIN_KE_PARTS)));
         HIP_OK(hipMalloc(&c->d_sync, 4 * sizeof(unsigned int)));
         HIP_OK(hipMemset(c->d_sync, 0, 4 * sizeof(unsigned int)));
@@ -863,7 +948,7 @@ extern "C" tgnh_status tgnh_exchange_create(tgnh_handle h, int world, int rank, 
     CHECK_H(h);
     if (h->host_only) return fail(TGNH_ERR_STATE, "host-only handle");
     if (world < 1 || world > XCHG_MAX_WORLD || rank < 0 || rank >= world) return fail(TGNH_ERR_ARG, "bad world / rank");
-    if (h->L.NT > XCHG_NT_PAD) return fail(TGNH_ERR_UNSUPPORTED, "too many thermostats for a mailbox");
+    if (h->L.NT > XCHG_NT_PAD || h->gather_chain) return fail(TGNH_ERR_UNSUPPORTED, "too many thermostats for a mailbox (more than 32 temperature groups: use an all-reduce hook or RCCL)");
     if (h->x_mailbox) return fail(TGNH_ERR_STATE, "exchange already created");
     HIP_OK(hipSetDevice(h->device));
     const size_t bytes = XCHG_MAILBOX_BYTES(world);
@@ -1130,7 +1215,8 @@ static void note_status(tgnh_handle h, uint32_t flags) {
         h->failed_code = TGNH_ERR_STATE;
         h->failed = "kinetic-energy pass (noticed at step " + std::to_string((long long)h->step_count) + "): work-group 0 did not "
                     "receive every work-group's row of sums within the time limit (the sums were left as NaN: nothing integrated "
-                    "on with a partial sum); the device is shared with something that keeps this launch's work-groups from running";
+                    "on with a partial sum); the device is shared with something that keeps this launch's work-groups from running "
+                    "-- or a chain was handed a NaN kinetic energy: with an all-reduce attached, the rank on which that happened";
     } else if (flags & 4u) {
         h->failed_code = TGNH_ERR_STATE;
         h->failed = "mailbox exchange timed out (noticed at step " + std::to_string((long long)h->step_count) +
@@ -1274,7 +1360,66 @@ static tgnh_status run_big_com(tgnh_handle h, bool kick, hipStream_t s) {
     return TGNH_OK;
 }
 
+// ---- the gather path (tgnh_gather.hip): the same operation masks, by global index ----
+static GatherArgs gather_args(tgnh_handle h, const double* scale) {
+    GatherArgs a{};
+    a.posq = h->posq; a.posq_corr = h->posq_corr; a.velm = h->velm;
+    a.force = reinterpret_cast<const long long*>(h->force); a.pos_delta = h->pos_delta;
+    a.normal = h->d_g_normal; a.pairs = h->d_g_pairs; a.group = h->d_g_group; a.resid = h->d_g_resid;
+    a.res_table = h->d_g_res_table; a.partner = h->d_g_partner; a.com = h->d_g_com;
+    a.scale = scale ? scale : h->d_state + h->L.off_scale;
+    a.partials = h->d_partials; a.status = h->d_status;
+    a.n = h->d.num_particles; a.padded = h->d.padded_num_particles;
+    a.n_normal = (int)h->normal.size(); a.n_pairs = h->d.num_pairs;
+    a.use_com = (h->d.mode == TGNH_MODE_TGNH && h->d.use_com_temp_group) ? 1 : 0;
+    a.n_res = a.use_com ? (int)h->g_res_table.size() : 0;
+    a.G = h->L.G; a.NT = h->L.NT;
+    a.hardwall = h->d.max_drude_distance > 0 ? 1 : 0;                         // Ref :299, Cu :372
+    a.dt = h->d.step_size; a.max_dist = h->d.max_drude_distance;
+    a.hw_scale = std::sqrt(h->d.kB * h->d.drude_temperature);                 // Ref :300, Cu :299
+    return a;
+}
+
+// One operation mask of run_tile as launches of the gather kernels: the velocity / position part (rescale, kick, drift,
+// posDelta, move, hard wall) first, the kinetic energies of what it stored after it (K's order: Cu :384-388 then :474-488).
+static tgnh_status run_gather(tgnh_handle h, int ops, int kid, hipStream_t s, const double* scale) {
+    GatherArgs a = gather_args(h, scale);
+    if ((ops & (OP_POSDELTA | OP_MOVE)) && !h->pos_delta) return fail(TGNH_ERR_STATE, "posDelta buffer not bound");
+    const int upd = ops & (OP_SCALE | OP_KICK | OP_DRIFT | OP_POSDELTA | OP_MOVE | OP_PREKICK);
+    if (ops & OP_NOSTORE) return fail(TGNH_ERR_STATE, "internal: the gather path stores every kick");
+    Timed t(h, s, kid);
+    if (upd) {
+        if ((upd & OP_SCALE) && a.use_com) {       // K :474-479 before :351-353: v - v_com of the velocities about to be rescaled
+            a.kick_com = (upd & OP_PREKICK) ? 1 : 0;
+            HIP_OK(launch_gather_com(h->d.precision, a, s));
+        }
+        a.ops = upd;
+        HIP_OK(launch_gather_update(h->d.precision, a, s));
+    }
+    if (ops & OP_KE) {
+        a.kick_com = 0;
+        if (a.use_com) HIP_OK(launch_gather_com(h->d.precision, a, s));
+        const int grid = gather_ke_grid(a);
+        HIP_OK(launch_gather_ke(h->d.precision, a, grid, s));
+        h->ke_parts = grid;
+        h->tail_summed = false;
+    }
+    return TGNH_OK;
+}
+
+// sum the rows of the gather path's kinetic-energy kernel [+ all-reduce], run the chain: more than 34 thermostats / long links
+static tgnh_status run_chain_gather(tgnh_handle h, hipStream_t s, bool sum_only) {
+    ChainArgs a = chain_args(h);
+    Timed t(h, s, KID_CHAIN);
+    HIP_OK(launch_gather_rowsum(h->d_partials, h->ke_parts, h->L.NT, h->d_state + h->L.off_ke_red, s));
+    if (h->allreduce && h->allreduce(h->d_state + h->L.off_ke_red, h->L.NT, (void*)s, h->allreduce_user) != 0)
+        return fail(TGNH_ERR_HIP, "all-reduce hook failed");
+    if (!sum_only) HIP_OK(launch_gather_chain(a, h->d_g_scratch, s));
+    return TGNH_OK;
+}
+
 static tgnh_status run_tile(tgnh_handle h, int ops, int kid, hipStream_t s, const double* scale = nullptr) {
+    if (h->generic) return run_gather(h, ops, kid, s, scale);
     TileArgs a = tile_args(h, scale);
     bool inline_chain = false;
     bool pingpong = false;
@@ -1346,6 +1491,7 @@ static ChainArgs chain_args(tgnh_handle h) {
     if (const char* e = getenv("TGNH_CHAIN_LANES")) a.lanes = e[0] != '0';
 #endif
     a.stage = h->d_stage;
+    a.status = h->d_status;
     if (h->xchg_on) a.x = h->x;
     a.commit = h->stage_pending ? 1 : 0;     // every chain_kernel launch takes over a staged block first
     h->stage_pending = false;
@@ -1363,6 +1509,7 @@ static tgnh_status commit_stage(tgnh_handle h, hipStream_t s) {
 
 // sum the work-group partials, all-reduce across ranks when sharded, run the chain
 static tgnh_status run_chain(tgnh_handle h, hipStream_t s, bool twice) {
+    if (h->gather_chain) return run_chain_gather(h, s, false);
     ChainArgs a = chain_args(h);
     a.chain_twice = twice ? 1 : 0;
     if (h->xchg_on) {                // sharded, mailbox exchange: the sum launch sends; whoever runs the chain waits
@@ -1438,6 +1585,13 @@ static bool resident_kind(tgnh_handle h, int kind) {
 }
 static bool resident_now(tgnh_handle h) {
     return resident_kind(h, (h->d.flags & TGNH_FLAG_DEFER_SCALE) ? 0 : 1);
+}
+
+extern "C" tgnh_status tgnh_get_step_path(tgnh_handle h, int* gather, const char** reason) {
+    CHECK_H(h);
+    if (gather) *gather = h->generic ? (h->gather_chain ? 2 : 1) : 0;
+    if (reason) *reason = h->generic_reason.c_str();
+    return TGNH_OK;
 }
 
 extern "C" tgnh_status tgnh_get_resident_kernel(tgnh_handle h, int* which) {
@@ -1601,8 +1755,8 @@ static tgnh_status second_half(tgnh_handle h, hipStream_t s, int kick_ops) {
     // bits) -- V r, F r | V r/w, F r = 144 B per slot where kick+KE with a store and a plain rescale move 152, and the read-only
     // pass runs at 62 us where the storing one takes 87-92 (5 M slots).  velm holds the reference's end-of-step velocities when
     // tgnh_step_end returns, as before.  (The split path's halves work on stored velocities around the constraint call-outs.)
-    const bool fold = !defer && kick_ops != 0;
-    const int nostore = kick_ops ? OP_NOSTORE : 0;
+    const bool fold = !defer && kick_ops != 0 && !h->generic;           // (the gather path stores its kick: K's own structure)
+    const int nostore = kick_ops && !h->generic ? OP_NOSTORE : 0;
     h->end_folded = fold;
     rc = run_tile(h, kick_ops | OP_KE | nostore, kick_ops ? KID_KICK_KE : KID_KE, s); if (rc) return rc;
     if (defer) {
@@ -1893,13 +2047,17 @@ extern "C" tgnh_status tgnh_compute_kinetic_energies(tgnh_handle h, void* stream
     rc = run_tile(h, OP_KE, KID_KE, s);                    // KE launch then sums in the same order, to the same bits
     h->sweep_reverse = dir;
     if (rc) return rc;
-    ChainArgs a = chain_args(h);
-    a.do_sum = 1; a.do_chain = 0;
-    if (h->xchg_on) { a.x_send = 1; a.x_wait = 1; }
-    if (!h->tail_summed) HIP_OK(launch_chain(a, s));       // (summed by the KE launch itself where the step's own KE launch is: the same bits)
-    h->tail_summed = false;
-    if (!h->xchg_on && h->allreduce && h->allreduce(h->d_state + h->L.off_ke_red, h->L.NT, (void*)s, h->allreduce_user) != 0)
-        return fail(TGNH_ERR_HIP, "all-reduce hook failed");
+    if (h->gather_chain) {
+        rc = run_chain_gather(h, s, true); if (rc) return rc;
+    } else {
+        ChainArgs a = chain_args(h);
+        a.do_sum = 1; a.do_chain = 0;
+        if (h->xchg_on) { a.x_send = 1; a.x_wait = 1; }
+        if (!h->tail_summed) HIP_OK(launch_chain(a, s));       // (summed by the KE launch itself where the step's own KE launch is: the same bits)
+        h->tail_summed = false;
+        if (!h->xchg_on && h->allreduce && h->allreduce(h->d_state + h->L.off_ke_red, h->L.NT, (void*)s, h->allreduce_user) != 0)
+            return fail(TGNH_ERR_HIP, "all-reduce hook failed");
+    }
     HIP_OK(hipMemcpyAsync(h->d_state + h->L.off_ke, h->d_state + h->L.off_ke_red, sizeof(double) * h->L.NT,
                           hipMemcpyDeviceToDevice, s));
     return TGNH_OK;
@@ -1912,6 +2070,13 @@ extern "C" tgnh_status tgnh_harness_force(tgnh_handle h, const void* x0, double 
                                           void* force_out, void* stream) {
     tgnh_status rc = entry(h, true); if (rc) return rc;
     if (!force_out) return fail(TGNH_ERR_ARG, "null force_out");
+    if (h->generic) {                                      // the gather path: partners by index (no per-slot word to read an offset from)
+        if (!x0) x0 = h->d_g_x0;
+        if (!x0) return fail(TGNH_ERR_ARG, "null x0 and no packed sites (tgnh_harness_pack_sites)");
+        Timed t(h, (hipStream_t)stream, KID_FORCE);
+        HIP_OK(launch_gather_force(h->d.precision, gather_args(h, nullptr), x0, reinterpret_cast<long long*>(force_out), k_drude, k_tether, (hipStream_t)stream));
+        return TGNH_OK;
+    }
     if (!x0 && !h->d_sflag && !h->lat_on) return fail(TGNH_ERR_ARG, "null x0 and no packed sites (tgnh_harness_pack_sites)");
     ForceArgs a{};
     a.posq = h->posq; a.posq_corr = h->posq_corr; a.x0 = x0; a.meta = h->d_meta;
@@ -1937,6 +2102,12 @@ extern "C" tgnh_status tgnh_harness_pack_sites(tgnh_handle h, const void* x0) {
     if (!x0) return fail(TGNH_ERR_ARG, "null x0");
     const int N = h->d.num_particles;
     const size_t rs = h->d.precision == TGNH_PREC_DOUBLE ? sizeof(double) : sizeof(float);
+    if (h->generic) {                                      // the gather path keeps the sites as they came (its force kernel reads them by index)
+        h->lat_on = false;
+        if (!h->d_g_x0) HIP_OK(hipMalloc(&h->d_g_x0, (size_t)std::max(N, 1) * 4 * rs));
+        HIP_OK(hipMemcpy(h->d_g_x0, x0, (size_t)N * 4 * rs, hipMemcpyDeviceToDevice));
+        return TGNH_OK;
+    }
     std::vector<unsigned char> raw((size_t)std::max(N, 1) * 4 * rs);
     HIP_OK(hipMemcpy(raw.data(), x0, (size_t)N * 4 * rs, hipMemcpyDeviceToHost));
     std::vector<uint8_t> flag((size_t)std::max(N, 1), 0);
@@ -1998,6 +2169,9 @@ extern "C" tgnh_status tgnh_harness_pack_sites(tgnh_handle h, const void* x0) {
 
 extern "C" tgnh_status tgnh_harness_lattice_hint(tgnh_handle h, int mol_slots, int side, double spacing, const double* geom, int first_molecule) {
     CHECK_H(h);
+    // a new (or withdrawn) hint is unverified until tgnh_harness_pack_sites has checked it slot by slot: the lattice kernel is
+    // not taken with it (tgnh_harness_force with x0 = NULL uses the sites packed before, or fails if there are none)
+    h->lat_on = false;
     if (mol_slots == 0) { h->lat_k = 0; h->lat_geom.clear(); return TGNH_OK; }
     if (mol_slots < 1 || mol_slots > 64 || side < 1 || side > 1290 || !(spacing > 0) || !geom || first_molecule < 0) return fail(TGNH_ERR_ARG, "bad lattice hint");
     h->lat_k = mol_slots; h->lat_side = side; h->lat_spacing = spacing; h->lat_mol0 = first_molecule;
@@ -2018,6 +2192,15 @@ extern "C" tgnh_status tgnh_run_harness(tgnh_handle h, const void* x0, double k_
         tgnh_status rc = tgnh_step_begin(h, stream); if (rc) return rc;
         rc = tgnh_harness_force(h, x0, k_drude, k_tether, const_cast<void*>(h->force), stream); if (rc) return rc;   // Cu :380 call-out
         rc = tgnh_step_end(h, stream); if (rc) return rc;
+    }
+    return TGNH_OK;
+}
+
+extern "C" tgnh_status tgnh_run_steps(tgnh_handle h, int nsteps, void* stream) {
+    CHECK_H(h);
+    for (int i = 0; i < nsteps; i++) {
+        tgnh_status rc = tgnh_step_begin(h, stream); if (rc) return rc;
+        rc = tgnh_step_end(h, stream); if (rc) return rc;          // (the force buffer is the caller's business: no call-out here)
     }
     return TGNH_OK;
 }

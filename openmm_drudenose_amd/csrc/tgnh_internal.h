@@ -156,6 +156,8 @@ struct ChainArgs {
     XchgArgs x;
     int x_send, x_wait;        // this launch sends its sums after the row sum / waits for everybody's before the chain
     double* st;                // thermostat block
+    uint32_t* status;          // the handle's status word: bit 4 when a chain is handed a NaN kinetic energy (a tail sum that gave up, here
+                               // or -- through an all-reduce -- on a peer rank: every rank then reports the failure itself)
     const double* partials;    // [nparts][NT] rows of the tile work-groups, then [nbig][NT] rows at GRID_CAP
     int nparts;
     int nbig;
@@ -264,6 +266,25 @@ struct ForceArgs {
 };
 constexpr size_t LAT_TAB_BYTES = 64 + 64 * 3 * sizeof(double);
 
+// The gather path (tgnh_gather.hip): the step by global index, the reference's own lists, for topologies the tiles cannot hold
+constexpr int GATHER_KE_ROWS = 1024;        // work-groups (= rows of partial sums) of its kinetic-energy kernel: <= GRID_CAP, chain_kernel sums them
+constexpr int GATHER_MAX_NT = 2048;         // thermostats: a row of fp64 bins per wavefront, four wavefronts, 64 KiB of LDS
+struct GatherArgs {
+    void* posq; void* posq_corr; void* velm; const long long* force; void* pos_delta;
+    const int* normal;         // [n_normal] ascending indices of the particles in no pair (Ref :137), massless sites included
+    const int2* pairs;         // [n_pairs] (Drude particle, parent) in DrudeForce order (Ref :124-127)
+    const int* group;          // [n] temperature group (Cu :117)
+    const int* resid;          // [n] residue, as index into res_table / com (Cu :118)
+    const int2* res_table;     // [n_res] (count, first particle) (Cu :121-125)
+    const int* partner;        // [n] harness force: partner | is-Drude << 31, -1 none
+    void* com;                 // mixed4 [n_res] centre-of-mass velocity, w = 1 / M (K comVelm)
+    const double* scale;       // [NT]
+    double* partials;          // [rows][NT]
+    uint32_t* status;
+    int n, padded, n_normal, n_pairs, n_res, G, NT, use_com, hardwall, ops, kick_com;
+    double dt, max_dist, hw_scale;
+};
+
 // A launcher reports THIS launch's error: whatever an earlier call left behind (e.g. a stream capture the caller
 // abandoned) is read off first.
 #define TGNH_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
@@ -283,6 +304,14 @@ int wke_blocks_per_cu(int precision, int ops, int gb);
 hipError_t launch_chain(const ChainArgs& a, hipStream_t s);
 hipError_t launch_big_com(int precision, const BigComArgs& a, hipStream_t s);
 hipError_t launch_force(int precision, const ForceArgs& a, hipStream_t s);
+// the gather path (tgnh_gather.hip)
+hipError_t launch_gather_com(int precision, const GatherArgs& a, hipStream_t s);
+int gather_ke_grid(const GatherArgs& a);
+hipError_t launch_gather_ke(int precision, const GatherArgs& a, int grid, hipStream_t s);
+hipError_t launch_gather_rowsum(const double* partials, int nrows, int NT, double* ke_red, hipStream_t s);
+hipError_t launch_gather_chain(const ChainArgs& a, double* scratch, hipStream_t s);
+hipError_t launch_gather_update(int precision, const GatherArgs& a, hipStream_t s);
+hipError_t launch_gather_force(int precision, const GatherArgs& a, const void* x0, long long* force, double k_drude, double k_tether, hipStream_t s);
 constexpr int PLAIN_KE_PARTS = 2048;         // work-group partials of the plain kinetic-energy query
 hipError_t launch_plain_ke(int precision, const void* velm, const long long* force, int n, int padded,
                            double time_shift, double* out /*[1 + PLAIN_KE_PARTS] device: out[0] = the result*/, hipStream_t s);
@@ -305,6 +334,17 @@ struct tgnh_context {
     std::vector<int2> res_entries;    // per-tile molecule entries
     std::vector<int> big_first, big_count;   // molecules longer than a tile (COM from big_com_kernel)
     int num_big = 0;
+    // the gather path: taken when the tiles cannot hold the topology (generic_reason says why); the reference's own index lists
+    bool generic = false;
+    bool gather_chain = false;        // ... and its chain too: more than 34 thermostats, or links that do not fit the LDS (gather_chain_kernel)
+    std::string generic_reason;
+    std::vector<int2> g_pairs, g_res_table;
+    std::vector<int> g_resid, g_partner;
+    int *d_g_normal = nullptr, *d_g_group = nullptr, *d_g_resid = nullptr, *d_g_partner = nullptr;
+    int2 *d_g_pairs = nullptr, *d_g_res_table = nullptr;
+    void* d_g_com = nullptr;
+    double* d_g_scratch = nullptr;    // chains longer than 4 links of more than 34 thermostats: a row of 4 C + 1 doubles each
+    void* d_g_x0 = nullptr;           // harness: the tether sites as tgnh_harness_pack_sites was handed them
     int2* d_big_table = nullptr;
     void* d_big_com = nullptr;
     std::vector<uint32_t> meta;

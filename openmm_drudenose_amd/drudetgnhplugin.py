@@ -184,6 +184,12 @@ class _HandleQueries:
     def _stream(self):
         return None
 
+    def step_path(self):
+        """('tiled', '') or ('gather', why): the reference's own un-fused kernels by global index, for what the tiles cannot hold"""
+        g, why = C.c_int(), C.c_char_p()
+        _check(self.lib.tgnh_get_step_path(self.h, C.byref(g), C.byref(why)))
+        return ("tiled", "gather", "gather")[g.value], (why.value or b"").decode()
+
     def local_dof_terms(self):
         n = C.c_int()
         _check(self.lib.tgnh_get_local_dof_terms(self.h, None, C.byref(n)))
@@ -553,6 +559,10 @@ class HipContext(_HandleQueries):
             p = p + self.posq_corr[:, :3].to(self.torch.float64)
         return p.cpu().numpy()
 
+    def flush(self):
+        """velm <- the reference's end-of-step velocities (a deferred variant's pending half kick and factors applied)"""
+        _check(self.lib.tgnh_flush(self.h, self._stream()))
+
     def getVelocities(self):
         _check(self.lib.tgnh_flush(self.h, self._stream()))
         return self.velm[:, :3].to(self.torch.float64).cpu().numpy()
@@ -615,9 +625,18 @@ class HipContext(_HandleQueries):
             _check(lib.tgnh_step_end_thermo(h, self._stream()))          # Cu :394-406
             self.ke_sum_valid = True
 
-    def capture_steps(self, steps):
+    def step_without_forces(self, steps):
+        """`steps` x (step_begin, step_end) with NO force call-out, on whatever the force buffer holds: for timing the integrator's
+        own launches (bench.py's integrator_only leg); not a trajectory of anything."""
+        if self.constrained:
+            raise TgnhError(_lib.ERR_STATE, "step_without_forces: unconstrained systems only")
+        _check(self.lib.tgnh_run_steps(self.h, int(steps), self._stream()))
+        if steps > 0:
+            self.ke_sum_valid = True
+
+    def capture_steps(self, steps, forces=True):
         """Captures `steps` time steps (harness force call-out included -- and the harness' constraint / virtual-site call-outs for a
-        system with constraints --, and the KE all-reduce when sharded) into
+        system with constraints --, and the KE all-reduce when sharded; forces=False: no call-out, see step_without_forces) into
         a hipGraph on a side stream and returns a callable that replays it.  The step sequence must not change afterwards
         (no setters).  A handle that is not in the steady state of its step sequence is brought there first, by up to
         three times `steps` real steps (see below): read the step count afterwards if it matters."""
@@ -639,9 +658,13 @@ class HipContext(_HandleQueries):
         def record():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
+                if self.constrained and not forces:
+                    raise TgnhError(_lib.ERR_STATE, "capture_steps(forces=False): unconstrained systems only")
                 if self.constrained:                         # the step loop step() runs for such a system: the split entry points around the harness' constraint call-outs
                     _check(self.lib.tgnh_run_harness_constrained(self.h, self._x0_arg(), self.k_drude, self.k_tether,
                                                                  self.integrator.getConstraintTolerance(), int(steps), self._stream()))
+                elif not forces:
+                    _check(self.lib.tgnh_run_steps(self.h, int(steps), self._stream()))
                 else:
                     _check(self.lib.tgnh_run_harness(self.h, self._x0_arg(), self.k_drude, self.k_tether, int(steps), self._stream()))
             return g

@@ -3,9 +3,14 @@
 #ifndef TGNH_OPENMM_SHIM_H_
 #define TGNH_OPENMM_SHIM_H_
 #include <exception>
+#include <typeinfo>
 #include <string>
 #include <vector>
+#ifdef TGNH_SHIM_EXPORT_DEFAULT
+#define OPENMM_EXPORT __attribute__((visibility("default")))       // what OpenMM's windowsExport.h gives a Linux build
+#else
 #define OPENMM_EXPORT
+#endif
 #define BOLTZ 8.31446261815324e-3
 namespace OpenMM {
 class System; class Platform; class ContextImpl; class HipContext; class DrudeForce; class DrudeTGNHIntegrator;
@@ -34,6 +39,10 @@ public:
 };
 class DrudeTGNHIntegrator {
 public:
+    DrudeTGNHIntegrator(double temperature, double couplingTime, double drudeTemperature, double drudeCouplingTime, double stepSize,
+                        int drudeStepsPerRealStep = 20, int numNHChains = 1, bool useDrudeNHChains = false, bool useCOMTempGroup = true);
+    void setConstraintTolerance(double tol); void setMaxDrudeDistance(double distance); void setUseCOMTempGroup(int useCOMGroup);
+    int addTempGroup(); int addParticleTempGroup(int tempGroup);
     double getTemperature() const; double getCouplingTime() const; double getDrudeTemperature() const; double getDrudeCouplingTime() const;
     double getStepSize() const; double getConstraintTolerance() const; double getMaxDrudeDistance() const;
     int getDrudeStepsPerRealStep() const; int getNumNHChains() const; bool getUseDrudeNHChains() const; bool getUseCOMTempGroup() const;
@@ -98,5 +107,24 @@ public:
     double getTime(); void setTime(double t); long long getStepCount(); void setStepCount(long long n);
 };
 class ContextSelector { public: explicit ContextSelector(ComputeContext& context); ~ContextSelector(); };
+class SerializationNode {
+public:
+    const std::string& getName() const;
+    const std::vector<SerializationNode>& getChildren() const;
+    SerializationNode& createChildNode(const std::string& name);
+    bool hasProperty(const std::string& name) const;
+    SerializationNode& setIntProperty(const std::string& name, int value); int getIntProperty(const std::string& name) const;
+    SerializationNode& setDoubleProperty(const std::string& name, double value); double getDoubleProperty(const std::string& name) const;
+    SerializationNode& setStringProperty(const std::string& name, const std::string& value); const std::string& getStringProperty(const std::string& name) const;
+    bool getBoolProperty(const std::string& name) const;
+};
+class SerializationProxy {
+public:
+    explicit SerializationProxy(const std::string& typeName);
+    virtual ~SerializationProxy();
+    virtual void serialize(const void* object, SerializationNode& node) const = 0;
+    virtual void* deserialize(const SerializationNode& node) const = 0;
+    static void registerProxy(const std::type_info& type, const SerializationProxy* proxy);
+};
 }  // namespace OpenMM
 #endif

@@ -146,3 +146,60 @@ def random_clusters(rng, mass, pd, pp, sizes, first, pos):
         atoms.append(a)
         dist.append(d)
     return np.array(atoms, np.int32).reshape(-1, 4), np.array(dist, np.float64).reshape(-1, 6)
+
+
+# ---- topologies the tiled kernels cannot hold: they step on the gather path (tgnh_gather.hip; tests/test_gather_gpu.py) ----
+def drudes_at_the_end(n_mol, seed=3):
+    """A water box as some builders write it: all atoms first (O, H, H, M per molecule), all Drude particles appended behind them.
+    Every Drude is far from its parent, and every residue comes in two runs."""
+    s, _, _ = synth.water_box(n_mol)
+    d = np.asarray(s.pair_drude)
+    keep = np.setdiff1d(np.arange(s.num_particles), d)
+    order = np.r_[keep, d]                                    # new -> old
+    inv = np.empty_like(order); inv[order] = np.arange(len(order))
+    out = synth.DrudeSystem(mass=s.mass[order], pair_drude=inv[s.pair_drude].astype(np.int32), pair_parent=inv[s.pair_parent].astype(np.int32),
+                            resid=s.resid[order], positions=s.positions[order], velocities=s.velocities[order], name="drudes-at-the-end")
+    return out, np.zeros(out.num_particles, np.int32), 1
+
+
+def onion(n=700, seed=5):
+    """One molecule whose pairs nest like onion skins (i, n - 1 - i): every cut between slot 1 and n - 1 goes through a pair."""
+    rng = np.random.default_rng(seed)
+    mass = rng.uniform(8.0, 20.0, n)
+    pd, pp = np.arange(n // 2, dtype=np.int32), (n - 1 - np.arange(n // 2)).astype(np.int32)
+    mass[pd] = 0.4
+    pos = rng.uniform(0.0, 2.0, (n, 3))
+    pos[pd] = pos[pp] + rng.normal(0.0, 0.002, (n // 2, 3))
+    return synth._finish(mass, pd, pp, np.zeros(n, np.int32), pos, np.zeros(n, np.int32), 1, rng, 300.0, 1.0, "onion")
+
+
+def far_pairs(seed=7):
+    """Water-like molecules plus one 1400-slot molecule whose Drude particles sit 600-1200 slots from their parents."""
+    rng = np.random.default_rng(seed)
+    s, g, ng = synth.mixed(200, 10)
+    n0, nb = s.num_particles, 1400
+    mass = np.r_[s.mass, rng.uniform(6.0, 30.0, nb)]
+    parents = n0 + np.arange(0, 100)
+    drudes = n0 + nb - 1 - np.arange(0, 100) * 2
+    mass[drudes] = 0.4
+    resid = np.r_[s.resid, np.full(nb, s.resid.max() + 1)].astype(np.int32)
+    group = np.r_[g, np.full(nb, 1)].astype(np.int32)
+    pos = np.r_[s.positions, rng.uniform(0.0, 4.0, (nb, 3))]
+    pos[drudes] = pos[parents] + rng.normal(0.0, 0.002, (100, 3))
+    out = synth._finish(mass, np.r_[s.pair_drude, drudes].astype(np.int32), np.r_[s.pair_parent, parents].astype(np.int32), resid, pos,
+                        group, ng, rng, 300.0, 1.0, "far-pairs")
+    return out
+
+
+def interleaved(n_mol=60):
+    """Two particles of neighbouring molecules swapped: residues 0 and 1 each come in several runs.  The reference's table says
+    (count, start of the LAST run) for them (Cu :121-124) and its COM kernel walks `count` particles from there (K :90-91),
+    whoever they belong to -- reproduced as it is, here and in the oracle (well inside the array for these two)."""
+    s, g, ng = synth.water_box(n_mol)
+    resid = s.resid.copy()
+    resid[[1, 6]] = resid[[6, 1]]
+    out = synth.DrudeSystem(mass=s.mass, pair_drude=s.pair_drude, pair_parent=s.pair_parent, resid=resid, positions=s.positions,
+                            velocities=s.velocities, name="interleaved")
+    return out, g, ng
+
+

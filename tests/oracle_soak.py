@@ -28,7 +28,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 from oracle.binding import OracleError  # noqa: E402
-from helpers import make_oracle, oracle_run, rel_err, to_internal, random_topology, random_clusters  # noqa: E402
+from helpers import (make_oracle, oracle_run, rel_err, to_internal, random_topology, random_clusters,  # noqa: E402
+                     drudes_at_the_end, onion, far_pairs, interleaved)
 from openmm_drudenose_amd import synth, HipContext, _lib  # noqa: E402
 from openmm_drudenose_amd.drudetgnhplugin import (DrudeTGNHIntegrator, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES,  # noqa: E402
                                                    FLAG_TRUST_STATE_CHANGED, TgnhError)
@@ -44,9 +45,16 @@ BOXES = {
     "groups-6": lambda: synth.many_groups(200, 15, 6),
     "groups-12": lambda: synth.many_groups(200, 15, 12),
     "groups-32": lambda: synth.many_groups(200, 15, 32),
+    # what the tiles cannot hold: the gather path (tgnh_gather.hip)
+    "groups-33": lambda: synth.many_groups(200, 15, 33),
+    "groups-100": lambda: synth.many_groups(300, 15, 100),
+    "onion-700": onion,
+    "far-pairs": far_pairs,
+    "interleaved-60": interleaved,
     "water-8000": lambda: synth.water_box(8000),                    # 40 000 slots: every work-group of the one-launch step holds several tiles
     "mixed-6000-400": lambda: synth.mixed(6000, 400),               # 48 000 slots, four groups
 }
+REFUSED, GATHER = {}, {}                                           # refusal message -> cases ; gather-path reason -> cases
 SINGLE = False                                                     # --single: every case in single precision, at GATES["single"]
 # positions / velocities (relative, max norm), thermostat rtol, kinetic-energy query.  Single precision is not a parity gate of
 # the suite (measured and reported); here it is run for what a loose gate still catches -- NaN, a wrong launch, a status bit
@@ -99,8 +107,11 @@ def one_case(rng, nsteps, info):
         ctx = HipContext(s, it, mode=mode, precision=precision, flags=flags)
     except TgnhError as e:
         if e.status == _lib.ERR_UNSUPPORTED:
+            REFUSED[str(e)[:90]] = REFUSED.get(str(e)[:90], 0) + 1
             return "skip", what + f"  ({str(e)[:120]})", 0.0, 0.0
         raise
+    if ctx.step_path()[0] == "gather":
+        GATHER[ctx.step_path()[1]] = GATHER.get(ctx.step_path()[1], 0) + 1
     try:
         og, ong = (g, ng) if mode == "TGNH" else (np.zeros_like(g), 1)
         o = make_oracle(s, og, ong, mode, it)
@@ -325,6 +336,12 @@ def main():
     print(f"{n} cases: {count['ok']} ok, {count['skip']} refused as unsupported, {count['FAIL']} failed; worst pos / vel error: "
           f"double {worst['double'][0]:.1e} / {worst['double'][1]:.1e}, mixed {worst['mixed'][0]:.1e} / {worst['mixed'][1]:.1e}, "
           f"single {worst['single'][0]:.1e} / {worst['single'][1]:.1e}", flush=True)
+    # every refusal by name: only what the reference itself cannot run may appear here (a massless pair member, Ref :132; a molecule
+    # without mass under the COM group, K :86-104; dualNH without a pair, Ref :181; DEFER_SCALE asked for a topology it cannot hold)
+    for msg, k in sorted(REFUSED.items(), key=lambda kv: -kv[1]):
+        print(f"  refused x{k}: {msg}", flush=True)
+    for why, k in sorted(GATHER.items(), key=lambda kv: -kv[1]):
+        print(f"  on the gather path x{k}: {why}", flush=True)
     return 1 if count["FAIL"] else 0
 
 

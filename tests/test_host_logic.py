@@ -282,9 +282,9 @@ def test_unsupported_topologies_fail_loudly():
     bad = s.resid.copy()
     bad[[1, 6]] = bad[[6, 1]]                                   # molecule 0 and 1 interleaved
     s2 = type(s)(mass=s.mass, pair_drude=s.pair_drude, pair_parent=s.pair_parent, resid=bad)
-    with pytest.raises(TgnhError) as e:
-        HostTopology(s2, integ())
-    assert e.value.status == _lib.ERR_UNSUPPORTED
+    # (not refused: the reference walks `count` particles from the start of the residue's last run, K :90-91 / Cu :121-124, whoever
+    # they belong to; the gather path and the oracle reproduce that walk)
+    assert HostTopology(s2, integ()).step_path() == ("gather", "particles of a residue are not contiguous")
     s3 = type(s)(mass=s.mass, pair_drude=np.r_[s.pair_drude, 2], pair_parent=np.r_[s.pair_parent, 0], resid=s.resid)
     with pytest.raises(TgnhError, match="more than one Drude pair"):
         HostTopology(s3, integ())
@@ -296,9 +296,25 @@ def test_unsupported_topologies_fail_loudly():
     with pytest.raises(TgnhError, match="no massive particle"):
         HostTopology(lone, integ())
     HostTopology(lone, integ(com=False))                            # without the COM group nothing divides by that mass
+
+
+def test_what_the_tiles_cannot_hold_takes_the_gather_path():
+    """The reference gathers by arbitrary index (K :171-186) and sizes its bins by G + 2 (K :138-200): a Drude far from its parent,
+    pairs that overlap so densely that no tile cut exists, more than 32 temperature groups are not refused -- they step through the
+    kernels of tgnh_gather.hip (tgnh_get_step_path says so, and why), with the reference's own index lists as topology."""
+    assert HostTopology(synth.water_box(4)[0], integ()).step_path() == ("tiled", "")
     far = synth.DrudeSystem(mass=np.ones(1300), pair_drude=np.array([1200]), pair_parent=np.array([0]), resid=np.zeros(1300, np.int32))
-    with pytest.raises(TgnhError, match="spans more than one"):  # Drude 1200 slots away from its parent
-        HostTopology(far, integ())
+    t = HostTopology(far, integ())                                 # Drude 1200 slots away from its parent
+    assert t.step_path()[0] == "gather" and "spans more than one" in t.step_path()[1]
+    assert np.array_equal(t.topology(0), np.setdiff1d(np.arange(1300), [0, 1200]))      # normalParticles (Ref :137)
+    assert t.topology(1).tolist() == [1200] and t.topology(2).tolist() == [0]
+    # pairs nested like onion skins over 700 slots: every cut between slot 1 and 699 goes through some pair
+    n = 700
+    dense = synth.DrudeSystem(mass=np.ones(n), pair_drude=np.arange(n // 2), pair_parent=n - 1 - np.arange(n // 2), resid=np.zeros(n, np.int32))
+    t = HostTopology(dense, integ())
+    assert t.step_path()[0] == "gather"
+    o = make_oracle(dense, np.zeros(n, np.int32), 1, "TGNH", integ())
+    assert np.allclose(t.dof()[0], o.dof()[0], rtol=1e-14)
 
 
 def test_molecule_longer_than_a_tile_is_tiled_with_a_com_table():
@@ -369,9 +385,15 @@ def test_up_to_32_temperature_groups():
     t = HostTopology(s, integ(group=g, ngroups=ng))
     o = make_oracle(s, g, ng, "TGNH", integ(group=g, ngroups=ng))
     assert t.num_thermostats() == 34 and np.allclose(t.dof()[0], o.dof()[0], rtol=1e-14)
-    s, g, ng = synth.many_groups(100, 8, 33)
-    with pytest.raises(TgnhError, match="more than 32 temperature groups"):
-        HostTopology(s, integ(group=g, ngroups=ng))
+    s, g, ng = synth.many_groups(100, 8, 33)                         # K :138-200 sizes its bins by G + 2: no limit there, the gather path here
+    t = HostTopology(s, integ(group=g, ngroups=ng))
+    o = make_oracle(s, g, ng, "TGNH", integ(group=g, ngroups=ng))
+    assert t.step_path() == ("gather", "more than 32 temperature groups")
+    assert t.num_thermostats() == 35 and np.allclose(t.dof()[0], o.dof()[0], rtol=1e-14)
+    s, g, ng = synth.many_groups(300, 8, 300)
+    t = HostTopology(s, integ(group=g, ngroups=ng, chains=3))
+    o = make_oracle(s, g, ng, "TGNH", integ(group=g, ngroups=ng, chains=3))
+    assert t.num_thermostats() == 302 and np.allclose(t.dof()[0], o.dof()[0], rtol=1e-14)
 
 
 @pytest.mark.parametrize("seed", range(12))

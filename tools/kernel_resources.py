@@ -4,20 +4,23 @@ number of instructions in the kernel's ISA that touch the stack (`stackops`: scr
 buffer instructions).  A small `scratch` with stackops 0 and no VGPR spill is a slot the register allocator reserved for
 spilled scalar registers and never used (they went to VGPR lanes): nothing is stored to memory."""
 import re, subprocess, sys, os, tempfile
-src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "openmm_drudenose_amd", "csrc", "tgnh_kernels.hip")
+csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "openmm_drudenose_amd", "csrc")
+out, stack = "", {}
 with tempfile.TemporaryDirectory() as tmp:
-    asm = os.path.join(tmp, "k.s")
-    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-x", "hip", src,
-                          "-o", asm, "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:], capture_output=True, text=True).stderr
-    stack, cur = {}, None
-    for line in open(asm):
-        m = re.match(r"^(_Z\w+):", line)
-        if m:
-            cur = m.group(1); stack[cur] = 0
-        elif cur and re.match(r"\s+(scratch_|buffer_)", line):
-            stack[cur] += 1
-        elif cur and "s_endpgm" in line:
-            cur = None
+    for name in ("tgnh_kernels.hip",):
+        asm = os.path.join(tmp, name + ".s")
+        out += subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-x", "hip",
+                               os.path.join(csrc, name), "-o", asm, "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:],
+                              capture_output=True, text=True).stderr
+        cur = None
+        for line in open(asm):
+            m = re.match(r"^(_Z\w+):", line)
+            if m:
+                cur = m.group(1); stack[cur] = 0
+            elif cur and re.match(r"\s+(scratch_|buffer_)", line):
+                stack[cur] += 1
+            elif cur and "s_endpgm" in line:
+                cur = None
 rows, cur = [], {}
 for line in out.splitlines():
     m = re.search(r"remark: [^:]*:\d+:\d+: +(.*?) \[-Rpass", line) or re.search(r"remark: +(.*?) \[-Rpass", line)

@@ -18,6 +18,13 @@ hipError_t launch_big_com(int, const BigComArgs&, hipStream_t) { return hipError
 hipError_t launch_force(int, const ForceArgs&, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_plain_ke(int, const void*, const long long*, int, int, double, double*, hipStream_t) { return hipErrorNoDevice; }
 size_t tile_lds_bytes(int, int, bool, bool) { return 0; }
+hipError_t launch_gather_com(int, const GatherArgs&, hipStream_t) { return hipErrorNoDevice; }
+int gather_ke_grid(const GatherArgs&) { return 1; }
+hipError_t launch_gather_ke(int, const GatherArgs&, int, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_gather_rowsum(const double*, int, int, double*, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_gather_chain(const ChainArgs&, double*, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_gather_update(int, const GatherArgs&, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_gather_force(int, const GatherArgs&, const void*, long long*, double, double, hipStream_t) { return hipErrorNoDevice; }
 }  // namespace tgnh
 
 extern "C" {
