@@ -390,18 +390,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, TileEnv<PREC, GB>& 
     for (int k = 0; k < SPT; k++) {
         const int idx = ts + k * TBLOCK + tid;
         if (ok[k]) {
-#ifdef TGNH_NT_TILE_STORES
-            if (VEL_W || (POS && hardwall)) nt_store(&velm[idx], v[k]);
-            if (POS) {
-                if (PREC == TGNH_PREC_MIXED) {
-                    const float hx = (float)px[k], hy = (float)py[k], hz = (float)pz[k];
-                    nt_store(&posq[idx], mk4((real)hx, (real)hy, (real)hz, pq[k]));
-                    nt_store(&pcorr[idx], make_float4((float)(px[k] - hx), (float)(py[k] - hy), (float)(pz[k] - hz), 0.0f));
-                } else {
-                    nt_store(&posq[idx], mk4((real)px[k], (real)py[k], (real)pz[k], pq[k]));
-                }
-            }
-#else
             if (VEL_W || (POS && hardwall)) velm[idx] = v[k];
             if (POS) {
                 if (PREC == TGNH_PREC_MIXED) {                   // K :457-458
@@ -412,7 +400,6 @@ __device__ __forceinline__ void tile_body(const TileArgs& a, TileEnv<PREC, GB>& 
                     posq[idx] = mk4((real)px[k], (real)py[k], (real)pz[k], pq[k]);
                 }
             }
-#endif
         }
     }
 
@@ -665,15 +652,6 @@ __device__ __forceinline__ void wave_load(const TileArgs& a, const int ws, const
     uint32_t meta = 64u << 10;
     long long fx = 0, fy = 0, fz = 0;
     if (lane < n) {
-#ifdef TGNH_NT_KE_LOADS
-        v = nt_load(&velm[idx]);
-        if (!patterned) meta = a.wmeta[idx];
-        if (OPS & OP_KICK) {
-            fx = __builtin_nontemporal_load(&a.force[idx]);
-            fy = __builtin_nontemporal_load(&a.force[idx + a.padded]);
-            fz = __builtin_nontemporal_load(&a.force[idx + 2 * a.padded]);
-        }
-#else
         v = velm[idx];
         if (!patterned) meta = a.wmeta[idx];
         if (OPS & OP_KICK) {
@@ -681,7 +659,6 @@ __device__ __forceinline__ void wave_load(const TileArgs& a, const int ws, const
             fy = a.force[idx + a.padded];
             fz = a.force[idx + 2 * a.padded];
         }
-#endif
     }
     if (patterned && lane < n) meta = pword;
     in.v = v; in.meta = meta; in.fx = fx; in.fy = fy; in.fz = fz;

@@ -5,7 +5,6 @@
 #ifndef TGNH_TILE_DEVICE_H_
 #define TGNH_TILE_DEVICE_H_
 #include "tgnh_internal.h"
-#include <type_traits>
 
 namespace tgnh {
 __device__ __forceinline__ double wave_sum(double v);
@@ -410,21 +409,6 @@ template <int PREC> struct WStepIn {
 // rescale, half kick, drift, hard wall, stores.  The arithmetic per slot is tile_body's / wke_kernel's, expression for expression.
 // Reference: K :82-113, :138-200 (COM, bins), :249-301 (rescale), :307-365 (kick), :435-466 (drift), :471-574 (hard wall).
 // ---------------------------------------------------------------------------
-// non-temporal (streaming) accesses: tuning builds only (-DTGNH_NT_STORES, -DTGNH_NT_TILE_STORES, -DTGNH_NT_KE_LOADS)
-template <typename T4> __device__ __forceinline__ void nt_store(T4* p, const T4& v) {
-    typedef decltype(v.x) S;
-    typedef S __attribute__((ext_vector_type(4))) V;
-    V u = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(u, reinterpret_cast<V*>(p));
-}
-template <typename T4> __device__ __forceinline__ T4 nt_load(const T4* p) {
-    typedef decltype(p->x) S;
-    typedef typename std::remove_cv<typename std::remove_reference<S>::type>::type S0;
-    typedef S0 __attribute__((ext_vector_type(4))) V;
-    const V u = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
-    T4 r; r.x = u.x; r.y = u.y; r.z = u.z; r.w = u.w;
-    return r;
-}
 struct WaveBounds { int ws, y, n; };        // first slot; the tile's largest molecule | pattern word << 8; slots
 
 template <int PREC, int GB> struct WaveStep {
@@ -617,16 +601,6 @@ template <int PREC, int GB> struct WaveStep {
         wfence();                                                        // the next tile's image comes after this tile's reads
         if (lane < bd.n) {
             const int idx = bd.ws + lane;
-#ifdef TGNH_NT_STORES
-            nt_store(&velm[idx], v);
-            if (PREC == TGNH_PREC_MIXED) {
-                const float hx = (float)px, hy = (float)py, hz = (float)pz;
-                nt_store(&posq[idx], mk4((real)hx, (real)hy, (real)hz, pq));
-                nt_store(&pcorr[idx], make_float4((float)(px - hx), (float)(py - hy), (float)(pz - hz), 0.0f));
-            } else {
-                nt_store(&posq[idx], mk4((real)px, (real)py, (real)pz, pq));
-            }
-#else
             velm[idx] = v;
             if (PREC == TGNH_PREC_MIXED) {                               // K :457-458
                 const float hx = (float)px, hy = (float)py, hz = (float)pz;
@@ -635,7 +609,6 @@ template <int PREC, int GB> struct WaveStep {
             } else {
                 posq[idx] = mk4((real)px, (real)py, (real)pz, pq);
             }
-#endif
         }
     }
 };

@@ -31,6 +31,10 @@ def test_two_rank_rehearsal_reports_both_exchanges():
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
     assert j["config"]["exchange"] == "rccl" and j["config"]["rccl_ranks"] == 2       # the headline is the collective hook
     assert j["config"]["slots_per_gpu"] == 50000
+    # the call-out stand-in inside `value` is named, and the integrator's own launches are a timed region of their own
+    assert j["config"]["harness_force"] in ("lattice", "packed", "x0") and j["config"]["harness_force"] in j["config"]["workload"]
+    io = j["integrator_only"]
+    assert io["value"] > j["value"] and io["steps"] >= 1 and "timed region" in io["how"] and io["sum_of_kernels"]["steps_per_s"] > 0
     mb = j["extra"]["mailbox"]
     assert "failed" not in mb, mb
     assert mb["validated_against_rccl"] is True and mb["timed_out"] is False

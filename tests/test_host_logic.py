@@ -124,7 +124,7 @@ def test_every_access_of_the_wave_tile_kernels_stays_inside_its_buffers(name, mo
       rows     one row of partial sums per work-group in a table of GRID_CAP rows, or tagged cells (row_word's layout) in an
                area sized for GRID_CAP rows of <= 10 thermostats: the largest grid any launch of the handle takes fits both.
 
-    On the reference's own testWater box (the box of the one device fault this repository has on record), the
+    On the reference's own testWater box (the box of the one device fault this repository has on record, HISTORY.md section 8b), the
     ragged topologies of helpers.random_topology, and the synthetic boxes; TGNH with and without the COM group, dualNH."""
     s, g, ng = _wave_tile_system(name)
     if mode == "dualNH":
