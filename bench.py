@@ -63,7 +63,9 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (rank 0, N=1)")
     p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                    help="replay the step loop from a hipGraph (auto: on when sharded over >1 GPU, where launches are short)")
-    p.add_argument("--graph-steps", type=int, default=10, help="time steps per captured graph")
+    p.add_argument("--graph-steps", type=int, default=50,
+                   help="time steps per captured graph (at most --steps).  A graph launch costs ~8 us of idle GPU between two replays "
+                        "(profiles/r05_step_gaps_*.md): 0.8 us per step at 10 steps per graph -- 2 %% of a 40 us step at the 8-GPU shard size --, 0.17 at 50")
     p.add_argument("--exchange", default="rccl", choices=["rccl", "mailbox"],
                    help="KE all-reduce of the HEADLINE sharded run: rccl = torch.distributed all_reduce (north_star); "
                         "mailbox = tgnh_exchange_* (stores over xGMI).  The other one is measured as an extra leg")
@@ -706,7 +708,7 @@ def main():
         args.variant = "defer" if args.precision == "single" and system.num_particles / world >= 3_000_000 else "resident"
 
     use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
-    gsteps = args.graph_steps if use_graph else 0
+    gsteps = max(1, min(args.graph_steps, args.steps)) if use_graph else 0
 
     def run_leg(exchange):
         """one timed run of the main configuration with the given exchange -> (ctx, seconds) ; ctx still open"""

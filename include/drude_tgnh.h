@@ -95,6 +95,10 @@ enum { TGNH_FLAG_TRUST_STATE_CHANGED = 16 };  /* The reference's pass structure 
                                         * whether the next half will carry over).  A hipGraph of steps recorded while carrying over
                                         * holds no KE pass: replay it only while the promise holds. */
 
+enum { TGNH_FLAG_GATHER = 32 };        /* step on the GATHER path (tgnh_get_step_path) whatever the topology: the reference's own
+                                        * un-fused kernels by global index, which the library otherwise takes only for what its
+                                        * tiles cannot hold.  For comparisons and as a fallback; several times slower per slot. */
+
 typedef struct tgnh_desc {
     uint32_t struct_size;         /* sizeof(tgnh_desc), ABI check */
     int32_t mode;                 /* TGNH_MODE_* */
@@ -206,7 +210,11 @@ tgnh_status tgnh_get_resident_work_groups(tgnh_handle h, int* per_compute_unit);
  * molecule that no cut between two of them lies within a tile's reach, more than 32 temperature groups (up to 2046), chains
  * too long for the on-chip forms; 2 the same with its own row sum and chain kernels (more than 34 thermostats).  Much slower per
  * slot (every look-up a global load) and always in the reference's pass structure: TGNH_FLAG_DEFER_SCALE, _RESIDENT_STEP,
- * _TRUST_STATE_CHANGED are ignored on it.  *reason (may be NULL): why, "" for the tiled path; valid until tgnh_destroy. */
+ * _TRUST_STATE_CHANGED are ignored on it.  *reason (may be NULL): why, "" for the tiled path; valid until tgnh_destroy.
+ * SHARDED RUNS: the ranks exchange once per thermostat half step they run, and a rank on the gather path runs the reference's
+ * two halves per step whatever its flags say -- so all ranks must be on the same path: if tgnh_get_step_path reports the gather
+ * path on ANY rank (agree on it with the collective at hand), create every rank's handle with TGNH_FLAG_GATHER.  Ranks that
+ * disagree wait for exchanges their peers never send: the mailbox exchange times out (status bit 2), a collective hangs. */
 tgnh_status tgnh_get_step_path(tgnh_handle h, int* gather, const char** reason);
 /* Which kernel this handle's next tgnh_step_begin runs as its one launch: 0 none (the streaming launches), 1 step_kernel (512-slot
  * tiles, one-link chains), 2 wstep_kernel (a whole deferred step over wave tiles, chains of 1-4 links). */

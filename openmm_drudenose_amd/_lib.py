@@ -9,7 +9,7 @@ TGNH_OK = 0
 ERR_ARG, ERR_GROUP_MISMATCH, ERR_HARDWALL, ERR_UNSUPPORTED, ERR_HIP, ERR_STATE = -1, -2, -3, -4, -5, -6
 MODE_DUALNH, MODE_TGNH = 0, 1
 PREC_SINGLE, PREC_MIXED, PREC_DOUBLE = 0, 1, 2
-FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES, FLAG_TRUST_STATE_CHANGED = 2, 4, 8, 16
+FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES, FLAG_TRUST_STATE_CHANGED, FLAG_GATHER = 2, 4, 8, 16, 32
 KID_SKD, KID_KICK_KE, KID_SCALE, KID_KE, KID_CHAIN, KID_FORCE, KID_OTHER, KID_STEP = range(8)
 KERNEL_NAMES = {KID_SKD: "scale+kick+drift", KID_KICK_KE: "kick+KE", KID_SCALE: "rescale", KID_KE: "KE",
                 KID_CHAIN: "chain", KID_FORCE: "harness force", KID_OTHER: "other", KID_STEP: "resident step"}

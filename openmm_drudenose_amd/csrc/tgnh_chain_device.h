@@ -846,12 +846,108 @@ __device__ __forceinline__ void chain1q_run(const ChainArgs& a, const Chain1Regs
     st_out[L.off_etaDot + m.ed1] = r.etaDot1;
 }
 
+// dualNH WITHOUT useDrudeNHChains (the C++ default; Ref :139-154 leaves numTempGroup = 1) and 2-4 links: the vectors are
+// [real0, drude0, real1, ..., real(C-1) | dummy, dummy] and the loops of Ref :476-481 / :494-503 make ONE coupled chain of C + 1
+// moving entries out of them -- the descending loop damps entry i with entry i + 1 (real0 with the Drude thermostat's etaDot, the
+// Drude thermostat with real1's), the ascending loop with entry i + 2, and the odd entries from 3 on take drudekbT (Ref :498).  The
+// same sequence of operations as the transcription below, in the form of the other fast chains: entries in registers, exp() a
+// short polynomial without a range test inside the loop (chain_exp9 / chain_exp_wide, the largest argument checked afterwards),
+// the two dummies' factors -- constants of the call -- formed once, (...)/etaMass[i] as a multiplication by 1/Q: 2 C + 1
+// polynomials per sub-step where the transcription evaluates 2 C + 4 range-tested exponentials.  False: an argument left every
+// fast form's range (nothing has been written; the caller runs the transcription).
+template <int CC, bool WIDE>
+__device__ __forceinline__ double dualnh_quirk_loop(double* eta, double* ed, double* edd, const double* em, const double* invM,
+                                                    const double dtc2, const double dtc4, const double dtc8, const int S,
+                                                    const double realNkbT, const double drudeNkbT, const double realkbT, const double drudekbT,
+                                                    const double ef_d1, const double ef_d2, double& realKE, double& drudeKE, double& sR, double& sD) {
+    constexpr int N = CC + 1;                                        // moving entries 0 .. C; ed[N], ed[N + 1] are the dummies
+    double xmax = 0.0;
+    auto ex = [&](const double x) { xmax = fmax(xmax, fabs(x)); return WIDE ? chain_exp_wide(x) : chain_exp9(x); };
+    for (int iter = 0; iter < S; iter++) {
+#pragma unroll
+        for (int i = N - 1; i >= 0; i--) {                           // Ref :476-481, i = idxMaxNHChains .. 0, stride numTempGroup = 1
+            const double ef = i == N - 1 ? ef_d1 : ex(-dtc8 * ed[i + 1]);
+            ed[i] *= ef; ed[i] += edd[i] * dtc4; ed[i] *= ef;
+        }
+        { const double e = ex(-dtc2 * ed[0]); sR *= e; realKE *= e * e; }        // Ref :483-486
+        { const double e = ex(-dtc2 * ed[1]); sD *= e; drudeKE *= e * e; }
+#pragma unroll
+        for (int i = 0; i < N; i++) eta[i] += dtc2 * ed[i];          // Ref :487-489
+        edd[0] = (realKE - realNkbT) * invM[0];                      // Ref :491-492
+        edd[1] = (drudeKE - drudeNkbT) * invM[1];
+#pragma unroll
+        for (int i = 0; i < N; i++) {                                // Ref :494-503, stride 2 hard-coded
+            const double ef = i == N - 1 ? ef_d2 : (i == N - 2 ? ef_d1 : ex(-dtc8 * ed[i + 2]));
+            ed[i] *= ef;
+            if (i > 1) edd[i] = (em[i - 2] * ed[i - 2] * ed[i - 2] - (i % 2 == 0 ? realkbT : drudekbT)) * invM[i];
+            ed[i] += edd[i] * dtc4; ed[i] *= ef;
+        }
+    }
+    return xmax;
+}
+template <int CC, bool LIBM>
+__device__ __forceinline__ bool dualnh_quirk_fast(const ChainArgs& a, const double* st_in, double* st_out, const bool write,
+                                                  double* s_scale, const double ke0, const double ke1, const double ke2) {
+    const ChainLayout& L = a.L;
+    constexpr int N = CC + 1;
+    double eta[N], ed[N + 2], edd[N], em[N], invM[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { eta[i] = st_in[L.off_eta + i]; edd[i] = st_in[L.off_etaDotDot + i]; em[i] = st_in[L.off_etaMass + i]; invM[i] = 1.0 / em[i]; }
+#pragma unroll
+    for (int i = 0; i < N + 2; i++) ed[i] = st_in[L.off_etaDot + i];
+    const double realNkbT = st_in[L.off_nkbt + 0], drudeNkbT = st_in[L.off_nkbt + 2];
+    const double dtc = a.dt / a.S;                                   // Ref :432-435
+    const double dtc2 = dtc / 2.0, dtc4 = dtc / 4.0, dtc8 = dtc / 8.0;
+    const double ef_d1 = chain_exp<LIBM>(-dtc8 * ed[N]), ef_d2 = chain_exp<LIBM>(-dtc8 * ed[N + 1]);    // the dummies never move
+    double realKE = ke0, drudeKE = ke2;
+    const int reps = a.chain_twice ? 2 : 1;
+    double sc0R = 1.0, sc0D = 1.0, sc1R = 1.0, sc1D = 1.0, ke_post0 = 0.0, ke_post2 = 0.0;     // (no array indexed by rep: that would live on the stack)
+    for (int rep = 0; rep < reps; rep++) {
+        edd[0] = (realKE - realNkbT) * invM[0];                      // Ref :471-472
+        edd[1] = (drudeKE - drudeNkbT) * invM[1];
+        double x0 = fmax(fabs(dtc2 * ed[0]), fabs(dtc2 * ed[1]));
+#pragma unroll
+        for (int i = 1; i < N; i++) x0 = fmax(x0, fabs(dtc8 * ed[i]));
+        double s_eta[N], s_ed[N], s_edd[N];                          // (this rep's entry state: the wide form starts from it again)
+#pragma unroll
+        for (int i = 0; i < N; i++) { s_eta[i] = eta[i]; s_ed[i] = ed[i]; s_edd[i] = edd[i]; }
+        const double kr = realKE, kd = drudeKE;
+        double sR = 1.0, sD = 1.0, xmax = 1.0;
+        if (x0 < 0.03125) xmax = dualnh_quirk_loop<CC, false>(eta, ed, edd, em, invM, dtc2, dtc4, dtc8, a.S, realNkbT, drudeNkbT, a.realkbT, a.drudekbT, ef_d1, ef_d2, realKE, drudeKE, sR, sD);
+        if (xmax >= 0.0625) {
+#pragma unroll
+            for (int i = 0; i < N; i++) { eta[i] = s_eta[i]; ed[i] = s_ed[i]; edd[i] = s_edd[i]; }
+            realKE = kr; drudeKE = kd; sR = 1.0; sD = 1.0;
+            xmax = dualnh_quirk_loop<CC, true>(eta, ed, edd, em, invM, dtc2, dtc4, dtc8, a.S, realNkbT, drudeNkbT, a.realkbT, a.drudekbT, ef_d1, ef_d2, realKE, drudeKE, sR, sD);
+            if (xmax >= 1.0) return false;
+        }
+        if (rep == 0) { sc0R = sR; sc0D = sD; ke_post0 = realKE; ke_post2 = drudeKE; } else { sc1R = sR; sc1D = sD; }
+    }
+    const double totR = sc0R * sc1R, totD = sc0D * sc1D;
+    if (s_scale) { s_scale[0] = totR; s_scale[1] = 1.0; s_scale[2] = totD; }
+    if (!write) return true;
+    st_out[L.off_ke + 0] = ke0; st_out[L.off_ke + 1] = ke1; st_out[L.off_ke + 2] = ke2;
+    st_out[L.off_kesum] = 0.5 * (ke0 + ke2);
+    st_out[L.off_scale_a + 0] = sc0R; st_out[L.off_scale_a + 1] = 1.0; st_out[L.off_scale_a + 2] = sc0D;
+    st_out[L.off_ke_post + 0] = ke_post0; st_out[L.off_ke_post + 1] = 0.0; st_out[L.off_ke_post + 2] = ke_post2;
+    st_out[L.off_scale_b + 0] = sc1R; st_out[L.off_scale_b + 1] = 1.0; st_out[L.off_scale_b + 2] = sc1D;
+    st_out[L.off_scale + 0] = totR; st_out[L.off_scale + 1] = 1.0; st_out[L.off_scale + 2] = totD;
+#pragma unroll
+    for (int i = 0; i < N; i++) { st_out[L.off_eta + i] = eta[i]; st_out[L.off_etaDotDot + i] = edd[i]; }
+#pragma unroll
+    for (int i = 0; i < N + 2; i++) st_out[L.off_etaDot + i] = ed[i];
+    return true;
+}
+
 // The Reference platform's coupled real/Drude chain on its interleaved vectors.  Ref :467-504.
 // LEN = compile-time bound of the vectors (2*CC+2), 0 = dynamic (LDS).
-template <int CC, bool LIBM = true>
+template <int CC, bool LIBM = true, bool QUIRK_FAST = true>
 __device__ __forceinline__ void run_dualnh(const ChainArgs& a, const double* st_in, double* st_out, const bool write,
                                            double* s_scale, double* lds, const double ke0, const double ke1, const double ke2) {
     const ChainLayout& L = a.L;
+    if constexpr (CC >= 2 && QUIRK_FAST) {                           // the coupled chain of the C++ default through the fast forms first
+        if (L.numTempGroup == 1 && dualnh_quirk_fast<CC, LIBM>(a, st_in, st_out, write, s_scale, ke0, ke1, ke2)) return;
+    }
     constexpr int LM = CC > 0 ? 2 * CC + 2 : 1;
     double r_eta[LM], r_etaDot[LM], r_etaDotDot[LM], r_etaMass[LM];
     double *eta = r_eta, *etaDot = r_etaDot, *etaDotDot = r_etaDotDot, *etaMass = r_etaMass;
@@ -1070,6 +1166,9 @@ __device__ __forceinline__ bool run_dualnh_pair(const ChainArgs& a, const double
 // chain_both_fast -- until round 4 they were two code paths of this wavefront, one after the other, and the serial section every
 // work-group waits for was twice as long: C2 with three links 33.6 k -> 44.5 k steps/s).  dualNH: lanes 0 and 2 run the Reference platform's two chains where they are independent (run_dualnh_pair), lane 0 its coupled vectors otherwise (run_dualnh).  No library exp
 // (chain_exp<false>): ocml's would cost the streaming kernels ~30 registers.  Longer chains keep their own launch (chain_kernel).
+// QUIRK_FAST = false (wstep_kernel, at its 228 registers): the coupled dualNH chain (useDrudeNHChains = false) stays the transcription
+// there -- with the fast form beside it the kernel spills.
+template <bool QUIRK_FAST = true>
 __device__ __forceinline__ void chainN_run(const ChainArgs& a, const double* st_in, double* st_out, const bool write,
                                            double* s_scale, const int itg, const double ke) {
     const ChainLayout& L = a.L;
@@ -1097,9 +1196,9 @@ __device__ __forceinline__ void chainN_run(const ChainArgs& a, const double* st_
         }
         if (!done && itg == 0) {
             switch (L.C) {
-                case 2: run_dualnh<2, false>(a, st_in, st_out, write, s_scale, nullptr, ke0, ke1, ke2); break;
-                case 3: run_dualnh<3, false>(a, st_in, st_out, write, s_scale, nullptr, ke0, ke1, ke2); break;
-                default: run_dualnh<4, false>(a, st_in, st_out, write, s_scale, nullptr, ke0, ke1, ke2); break;
+                case 2: run_dualnh<2, false, QUIRK_FAST>(a, st_in, st_out, write, s_scale, nullptr, ke0, ke1, ke2); break;
+                case 3: run_dualnh<3, false, QUIRK_FAST>(a, st_in, st_out, write, s_scale, nullptr, ke0, ke1, ke2); break;
+                default: run_dualnh<4, false, QUIRK_FAST>(a, st_in, st_out, write, s_scale, nullptr, ke0, ke1, ke2); break;
             }
         }
     }

@@ -684,6 +684,7 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     make_layout(c);
     c->gb = c->L.G <= 1 ? 1 : (c->L.G <= 4 ? 4 : (c->L.G <= 8 ? 8 : 0));   // 0: KE bins in LDS
     if (long_chain) { c->generic = true; c->generic_reason = "a chain too long for the LDS-resident form"; }
+    else if (d->flags & TGNH_FLAG_GATHER) { c->generic = true; c->generic_reason = "asked for (TGNH_FLAG_GATHER)"; }
     if (!host_only) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;

@@ -591,7 +591,7 @@ __global__ __launch_bounds__(TBLOCK, TGNH_MINWAVES) void tile_kernel(const TileA
                     for (int i = 0; i < NT; i++) s += a.x_wait ? s_scale[i] : a.st_in[chain_ke_src(a.chain) + i];
                     a.st_out[L.off_kesum] = 0.5 * s;
                 }
-                if (write && itg < NT && creg.ke != creg.ke) atomicOr(a.status, 16u);     // a NaN sum (a tail sum that gave up, here or on a peer rank): chain_prologue's check
+                if (write && itg < NT && !a.chain.ke_carry && creg.ke != creg.ke) atomicOr(a.status, 16u);     // a NaN sum (a tail sum that gave up, here or on a peer rank): chain_prologue's check
                 if (MULTI && !one_link) chainN_run(a.chain, a.st_in, a.st_out, write, s_scale, itg, creg.ke);
                 else if (itg < NT) {
                     if (L.c1_quirk) chain1q_run(a.chain, creg, a.st_out, write, s_scale, itg);
@@ -1171,7 +1171,9 @@ __device__ __forceinline__ void chain_prologue(const ChainArgs& a, double (*sred
     }
     // A tail sum that gave up on a row leaves NaN (wke_kernel) and sets status bit 4 on ITS rank; behind an all-reduce every rank
     // holds that NaN now, and says so itself -- no rank integrates on silently with a clean status word
-    if (tid < NT && a.status && s_ke[tid] != s_ke[tid]) atomicOr(a.status, 16u);
+    // (not for sums carried over from the last chain, ke_carry: a system without any Drude pair carries the reference's own 0/0
+    // in its Drude thermostat, harmless there -- Cu :597-605 with drudeDof = 0)
+    if (tid < NT && a.status && !a.ke_carry && s_ke[tid] != s_ke[tid]) atomicOr(a.status, 16u);
     if (a.x_send) xchg_send(a.x, NT, tid, BLOCK, s_chain, tid < NT ? s_ke[tid] : 0.0);
     if (a.x_wait) {
         __syncthreads();

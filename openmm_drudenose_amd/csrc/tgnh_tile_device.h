@@ -380,7 +380,7 @@ __device__ __forceinline__ bool step_meet(const TileArgs& a, TileEnv<PREC, GB>& 
                 const double kesum = wave_sum(itg < NT ? mine : 0.0);
                 if (itg == 63) a.st_out[L.off_kesum] = 0.5 * kesum;
             }
-            if (MULTI && L.C > 1) chainN_run(a.chain, sh.s_block, a.st_out, write, s_scale, itg, mine);
+            if (MULTI && L.C > 1) chainN_run<false>(a.chain, sh.s_block, a.st_out, write, s_scale, itg, mine);
             else if (itg < NT) {
                 if (L.c1_quirk) chain1q_run(a.chain, creg, a.st_out, write, s_scale, itg);
                 else chain1_finish(a.chain, creg, EARLY_PRE ? cpre : chain1_prepare(a.chain, creg, itg), a.st_out, write, s_scale, itg);

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (MODE_DUALNH, MODE_TGNH, PREC_SINGLE, PREC_MIXED, PREC_DOUBLE,  # noqa: F401
-                   FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES, FLAG_TRUST_STATE_CHANGED)
+                   FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES, FLAG_TRUST_STATE_CHANGED, FLAG_GATHER)
 from .synth import KB
 
 _PREC = {"single": PREC_SINGLE, "mixed": PREC_MIXED, "double": PREC_DOUBLE}

@@ -32,7 +32,7 @@ from helpers import (make_oracle, oracle_run, rel_err, to_internal, random_topol
                      drudes_at_the_end, onion, far_pairs, interleaved)
 from openmm_drudenose_amd import synth, HipContext, _lib  # noqa: E402
 from openmm_drudenose_amd.drudetgnhplugin import (DrudeTGNHIntegrator, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES,  # noqa: E402
-                                                   FLAG_TRUST_STATE_CHANGED, TgnhError)
+                                                   FLAG_TRUST_STATE_CHANGED, FLAG_GATHER, TgnhError)
 
 BOXES = {
     "mixed-200-15": lambda: synth.mixed(200, 15),
@@ -192,15 +192,31 @@ def sharded_case(rng, nsteps, info):
                 loc = s.slice_molecules(b[r], b[r + 1])
                 loc.has_cm_motion_remover = s.has_cm_motion_remover
                 parts.append(HipContext(loc, integrator(g[b[r]:b[r + 1]]), mode=mode, precision=precision, flags=flags))
+            # Every rank of a sharded run must step in the same pass structure (the same number of exchanges per step), and the
+            # gather path ignores the flags that change it: if any shard's topology took it, all shards do (include/drude_tgnh.h)
+            if len({c.step_path()[0] for c in parts}) > 1:
+                for r in range(nranks):
+                    if parts[r].step_path()[0] != "gather":
+                        parts[r].close()
+                        loc = s.slice_molecules(b[r], b[r + 1])
+                        loc.has_cm_motion_remover = s.has_cm_motion_remover
+                        parts[r] = HipContext(loc, integrator(g[b[r]:b[r + 1]]), mode=mode, precision=precision, flags=flags | FLAG_GATHER)
+            for c in parts:
                 if flags & FLAG_RESIDENT_STEP:
-                    parts[-1].set_resident_share(nranks)
+                    c.set_resident_share(nranks)
         except TgnhError as e:
             if e.status == _lib.ERR_UNSUPPORTED:
+                REFUSED[str(e)[:90]] = REFUSED.get(str(e)[:90], 0) + 1
                 return "skip", what + f"  ({str(e)[:120]})", 0.0, 0.0
             raise
         streams = [torch.cuda.Stream(priority=-r) for r in range(nranks)]      # two different hardware queues
         total = sum(c.local_dof_terms() for c in parts)
-        boxes = [c.exchange_create(nranks, r)[1] for r, c in enumerate(parts)]
+        try:
+            boxes = [c.exchange_create(nranks, r)[1] for r, c in enumerate(parts)]
+        except TgnhError as e:                              # more than 34 thermostats: the mailboxes do not hold them (an all-reduce hook does:
+            if "too many thermostats" in str(e):            # tests/test_gather_gpu.py::test_sharded_gather_path_with_an_allreduce_hook)
+                return "skip", what + "  (mailbox: <= 34 thermostats)", 0.0, 0.0
+            raise
         for c in parts:
             c.set_global_dof_terms(total)
             c.exchange_attach_pointers(boxes)
@@ -276,6 +292,7 @@ def checkpoint_case(rng, nsteps, info):
         a = context()
     except TgnhError as e:
         if e.status == _lib.ERR_UNSUPPORTED:
+            REFUSED[str(e)[:90]] = REFUSED.get(str(e)[:90], 0) + 1
             return "skip", what + f"  ({str(e)[:120]})", 0.0, 0.0
         raise
     b = None
@@ -333,7 +350,9 @@ def main():
             print(f"FAIL  seed={seed} {info['what']}  {type(e).__name__}: {str(e)[:600]}", flush=True)
             traceback.print_exc(limit=3, file=sys.stdout)
         count[kind] += 1
-    print(f"{n} cases: {count['ok']} ok, {count['skip']} refused as unsupported, {count['FAIL']} failed; worst pos / vel error: "
+    refused = sum(REFUSED.values())
+    print(f"{n} cases: {count['ok']} ok, {refused} refused as unsupported at create, {count['skip'] - refused} without a verdict (the oracle's own SHAKE "
+          f"gave up on a random cluster / an empty shard / a mailbox asked for more than 34 thermostats), {count['FAIL']} failed; worst pos / vel error: "
           f"double {worst['double'][0]:.1e} / {worst['double'][1]:.1e}, mixed {worst['mixed'][0]:.1e} / {worst['mixed'][1]:.1e}, "
           f"single {worst['single'][0]:.1e} / {worst['single'][1]:.1e}", flush=True)
     # every refusal by name: only what the reference itself cannot run may appear here (a massless pair member, Ref :132; a molecule

@@ -19,7 +19,7 @@ import pytest
 from helpers import rel_err
 from openmm_drudenose_amd import synth, HipContext, _lib
 from openmm_drudenose_amd.drudetgnhplugin import (DrudeTGNHIntegrator, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES,
-                                                   FLAG_TRUST_STATE_CHANGED, TgnhError)
+                                                   FLAG_TRUST_STATE_CHANGED, FLAG_GATHER, TgnhError)
 
 pytestmark = pytest.mark.gpu
 
@@ -227,3 +227,14 @@ def test_kinetic_energies_carried_over_survive_random_call_sequences(chains):
 def test_random_call_sequence_across_tile_kinds():
     """a wave-tile handle against a 512-slot-tile reference: every sum in another order, the loose gate"""
     Walk(FLAG_DEFER_SCALE, None, 3, seed=4242, wave=True, cross=True).run()
+
+
+@pytest.mark.parametrize("flags,exchange,chains", [(FLAG_GATHER, None, 3), (FLAG_GATHER | FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP, "hook", 1)])
+def test_random_call_sequence_on_the_gather_path(flags, exchange, chains):
+    """The gather path (tgnh_gather.hip: the reference's un-fused kernels by global index, here forced with TGNH_FLAG_GATHER on a
+    topology the tiles can hold) against a TILED plain reference over a random walk of the entry points -- steps, split steps with
+    the harness' constraint call-outs, setters, queries, a rebind: every sum in another order, the cross-kind gate.  The flags that
+    change the pass structure are ignored on it (nothing is owed between steps, setters are never refused)."""
+    w = Walk(flags, exchange, chains, seed=9000 + flags, wave=False, cross=True)
+    assert w.ctx.step_path()[0] == "gather" and w.ref.step_path()[0] == "tiled"
+    w.run()

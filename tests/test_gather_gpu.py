@@ -9,7 +9,7 @@ import pytest
 
 from openmm_drudenose_amd import synth, _lib
 from openmm_drudenose_amd.drudetgnhplugin import (DrudeTGNHIntegrator, HipContext, TgnhError, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP,
-                                                   FLAG_TRUST_STATE_CHANGED)
+                                                   FLAG_TRUST_STATE_CHANGED, FLAG_GATHER)
 from helpers import make_oracle, oracle_run, rel_err, to_internal, drudes_at_the_end, onion, far_pairs, interleaved
 
 pytestmark = pytest.mark.gpu
@@ -190,3 +190,27 @@ def test_sharded_gather_path_with_an_allreduce_hook():
     assert np.allclose(parts[0].thermostat_state(1), ref.thermostat_state(1), rtol=1e-9, atol=1e-13)
     for c in parts + [ref]:
         c.close()
+
+
+@pytest.mark.parametrize("sysname,mode", [("mixed", "TGNH"), ("polymer", "TGNH"), ("water-rigid", "TGNH"), ("il-shake", "dualNH")])
+def test_the_gather_flag_gives_the_tiled_path_s_trajectory(sysname, mode):
+    """TGNH_FLAG_GATHER on topologies the tiles CAN hold: the two implementations against each other, 60 steps -- unconstrained
+    boxes and, through the split entry points with the harness' SHAKE / virtual-site call-outs, the constrained ones"""
+    build = {"mixed": lambda: synth.mixed(300, 20), "polymer": lambda: synth.polymer_in_water(700, 100),
+             "water-rigid": lambda: synth.water_box(216, rigid=True), "il-shake": lambda: synth.ionic_liquid(40, constrained=True)}[sysname]
+    out = []
+    for flags in (0, FLAG_GATHER):
+        s, g, ng = build()
+        it = integ(chains=3, hardwall=0.02)
+        it.setConstraintTolerance(1e-10)
+        if mode == "TGNH":
+            bind_groups(it, g, ng)
+        ctx = HipContext(s, it, mode=mode, precision="double", flags=flags)
+        assert ctx.step_path()[0] == ("gather" if flags else "tiled")
+        ctx.step(60)
+        out.append((ctx.getPositions(), ctx.getVelocities(), ctx.thermostat_state(1), ctx.status_flags() & ~1))
+        ctx.close()
+    (p0, v0, t0, f0), (p1, v1, t1, f1) = out
+    print(f"gather flag vs tiled, {sysname} {mode}: pos {rel_err(p1, p0):.2e} vel {rel_err(v1, v0):.2e}")
+    assert f0 == 0 and f1 == 0
+    assert rel_err(p1, p0) < 1e-11 and rel_err(v1, v0) < 1e-9 and np.allclose(t1, t0, rtol=1e-8, atol=1e-10)

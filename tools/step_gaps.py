@@ -27,38 +27,55 @@ def main():
     ap.add_argument("--molecules", type=int, default=125000)
     ap.add_argument("--variant", default="resident")
     ap.add_argument("--dist", action="store_true")
+    ap.add_argument("--parse-only", action="store_true", help="parse the trace an earlier run left under gpurun_out/")
     a = ap.parse_args()
     from profile_round import pretty
     name = f"{a.tag}_step_gaps_{a.molecules}_{a.variant}{'_rccl' if a.dist else ''}"
     scratch = os.path.join(ROOT, "gpurun_out", "prof_" + name)
-    shutil.rmtree(scratch, ignore_errors=True)
-    os.makedirs(scratch)
-    cmd = ["rocprofv3", "--kernel-trace", "-d", scratch, "--output-format", "csv", "--", "python3", os.path.join(ROOT, "bench.py"),
-           "--molecules", str(a.molecules), "--variant", a.variant, "--graph", "on", "--steps", "2000", "--warmup", "100", "--no-extra", "--no-cpu-baseline"]
-    env = dict(os.environ, TMPDIR="/tmp")
-    if a.dist:
-        env["TGNH_FORCE_DIST"] = "1"
-    print("+", " ".join(cmd), flush=True)
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=open(os.path.join(scratch, "err.log"), "w"), env=env, cwd=ROOT)
-    if p.returncode != 0:
-        raise SystemExit(f"failed ({p.returncode}): {scratch}/err.log")
-    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1]
     import json
-    bench = json.loads(line)
+    if a.parse_only:                                     # the trace a GPU run left (gpurun merges gpurun_out/ back): parse it here
+        bench = json.load(open(os.path.join(scratch, "bench_line.json")))
+    else:
+        shutil.rmtree(scratch, ignore_errors=True)
+        os.makedirs(scratch)
+        cmd = ["rocprofv3", "--kernel-trace", "-d", scratch, "--output-format", "csv", "--", "python3", os.path.join(ROOT, "bench.py"),
+               "--molecules", str(a.molecules), "--variant", a.variant, "--graph", "on", "--steps", "2000", "--warmup", "100", "--no-extra", "--no-cpu-baseline"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        if a.dist:
+            env["TGNH_FORCE_DIST"] = "1"
+        print("+", " ".join(cmd), flush=True)
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=open(os.path.join(scratch, "err.log"), "w"), env=env, cwd=ROOT)
+        if p.returncode != 0:
+            raise SystemExit(f"failed ({p.returncode}): {scratch}/err.log")
+        line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1]
+        open(os.path.join(scratch, "bench_line.json"), "w").write(line)
+        bench = json.loads(line)
     rows = []
     for f in glob.glob(os.path.join(scratch, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    # the steady state: the longest run of launches whose names repeat with the period of one step (graph replays)
+    # the timed region: the longest run of launches whose names repeat with the period of one step (the graph replays of the
+    # step loop; warm-up, the integrator-only leg and the instrumented repeat have other periods or are shorter)
     names = [pretty(n) for _, _, n in rows]
-    tail = names[len(names) // 2:]
-    period = next(p_ for p_ in range(1, 12) if all(tail[i] == tail[i + p_] for i in range(len(tail) - p_)))
-    start = len(names) // 2
+    best = (0, 0, 1)
+    for per in range(1, 9):
+        i = 0
+        while i < len(names) - per:
+            j = i
+            while j < len(names) - per and names[j] == names[j + per]:
+                j += 1
+            if j - i > best[0]:
+                best = (j - i, i, per)
+            i = j + 1
+        if best[0] > 1500:
+            break
+    length, start, period = best
+    start, stop = start + length // 10, start + length - length // 10
     dur = collections.defaultdict(list)
     gap = collections.defaultdict(list)
     step = []
-    for i in range(start, len(rows) - period, 1):
+    for i in range(start, stop):
         s0, e0, _ = rows[i]
         dur[names[i]].append((e0 - s0) / 1e3)
         gap[f"{names[i]} -> {names[i + 1]}"].append((rows[i + 1][0] - e0) / 1e3)
