@@ -48,7 +48,7 @@ def parse():
     p.add_argument("--molecules", type=int, default=1_000_000, help="SWM4 molecules = Drude pairs (metric: 1,000,000)")
     p.add_argument("--precision", default="mixed", choices=["single", "mixed", "double"])
     p.add_argument("--mode", default="TGNH", choices=["TGNH", "dualNH"])
-    p.add_argument("--variant", default="auto", choices=["auto", "plain", "plain-trust", "plain-resident", "plain-resident-trust", "defer", "resident"],
+    p.add_argument("--variant", default="auto", choices=["auto", "plain", "plain-trust", "plain-resident", "plain-resident-trust", "defer", "resident", "plain-gather"],
                    help="defer = end-of-step rescale and second half kick folded into the next step's first pass; resident = "
                         "defer with the whole step in ONE launch whose work-groups meet on the device (step_kernel; with the "
                         "RCCL hook it steps the defer way); plain = the reference's pass structure; plain-trust = that structure with "
@@ -56,6 +56,8 @@ def parse():
                         "left: no KE pass; an OPTION of the OpenMM glue, off by default: it needs an accessor the reference's API class "
                         "does not have and a System of known Force types only, INTEGRATION.md section 3); "
                         "plain-resident = the plain structure with each thermostat half one step_kernel launch; plain-resident-trust = both; "
+                        "plain-gather = the reference's structure on the GATHER path (TGNH_FLAG_GATHER: the reference's un-fused kernels by global "
+                        "index, what the library takes for topologies its tiles cannot hold; for comparison); "
                         "auto = resident (single precision from 3 M slots per GPU: defer) (DESIGN.md)")
     p.add_argument("--chains", type=int, default=1)
     p.add_argument("--drude-steps", type=int, default=20, help="drudeStepsPerRealStep (reference default 20)")
@@ -94,13 +96,13 @@ def build_context(args, system, group, ngroups, rank, world, precision, variant,
     import torch
     import torch.distributed as dist
     from openmm_drudenose_amd import DrudeTGNHIntegrator, HipContext
-    from openmm_drudenose_amd.drudetgnhplugin import FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_TRUST_STATE_CHANGED
+    from openmm_drudenose_amd.drudetgnhplugin import FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_TRUST_STATE_CHANGED, FLAG_GATHER
     from openmm_drudenose_amd.system import shard_bounds
     it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, args.drude_steps, args.chains, True, True)
     it.setMaxDrudeDistance(args.hardwall)
     flags = {"plain": 0, "plain-trust": FLAG_TRUST_STATE_CHANGED, "plain-resident": FLAG_RESIDENT_STEP,
              "plain-resident-trust": FLAG_RESIDENT_STEP | FLAG_TRUST_STATE_CHANGED, "defer": FLAG_DEFER_SCALE,
-             "resident": FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP}[variant]
+             "resident": FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP, "plain-gather": FLAG_GATHER}[variant]
     local, lgroup = system, group
     if world > 1:
         b = shard_bounds(system, world)
@@ -640,7 +642,7 @@ def step_model_bytes(num_slots, precision, variant):
     X = 16 if precision == "single" else 32
     F = 24
     per = {"plain": 6 * V + 3 * F + 2 * X, "plain-trust": 5 * V + 3 * F + 2 * X, "plain-resident": 6 * V + 3 * F + 2 * X,
-           "plain-resident-trust": 5 * V + 3 * F + 2 * X, "defer": 3 * V + 2 * F + 2 * X,
+           "plain-resident-trust": 5 * V + 3 * F + 2 * X, "defer": 3 * V + 2 * F + 2 * X, "plain-gather": 7 * V + 2 * F + 2 * X,
            "resident": 3 * V + 2 * F + 2 * X}[variant]
     return num_slots * per
 

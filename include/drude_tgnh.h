@@ -74,7 +74,8 @@ enum { TGNH_FLAG_RESIDENT_STEP = 4 };  /* whole thermostat halves in ONE launch 
                                         * its own begin half in one launch.  Either way the handle needs the device to itself
                                         * while stepping (see tgnh_set_resident_share); <= 8 temperature groups, no
                                         * collective hook, and chains of 1-4 links with DEFER_SCALE on a topology with wave tiles
-                                        * (wstep_kernel), one-link chains otherwise (step_kernel) -- else it quietly steps with
+                                        * (wstep_kernel; not DUALNH's coupled chain of 2-4 links, useDrudeNHChains = 0), one-link
+                                        * chains otherwise (step_kernel) -- else it quietly steps with
                                         * the tile launches (tgnh_get_resident_kernel says which).
                                         * With a mailbox exchange attached and DEFER_SCALE, state queries between steps are
                                         * collective over the ranks. */

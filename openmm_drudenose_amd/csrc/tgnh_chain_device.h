@@ -908,16 +908,30 @@ __device__ __forceinline__ bool dualnh_quirk_fast(const ChainArgs& a, const doub
         double x0 = fmax(fabs(dtc2 * ed[0]), fabs(dtc2 * ed[1]));
 #pragma unroll
         for (int i = 1; i < N; i++) x0 = fmax(x0, fabs(dtc8 * ed[i]));
-        double s_eta[N], s_ed[N], s_edd[N];                          // (this rep's entry state: the wide form starts from it again)
+        // the form is chosen from the exponents at entry with a factor two of room and checked afterwards.  Short chains keep this
+        // rep's entry state in registers and start again with the wide form when the narrow one was left; long ones (5-16 links: the
+        // copies would be another 3 x 17 doubles) hand over to the transcription instead
+        constexpr bool SAVE = CC <= 4;
+        constexpr int NS = SAVE ? N : 1;
+        double s_eta[NS], s_ed[NS], s_edd[NS];
+        if constexpr (SAVE) {
 #pragma unroll
-        for (int i = 0; i < N; i++) { s_eta[i] = eta[i]; s_ed[i] = ed[i]; s_edd[i] = edd[i]; }
+            for (int i = 0; i < N; i++) { s_eta[i] = eta[i]; s_ed[i] = ed[i]; s_edd[i] = edd[i]; }
+        }
         const double kr = realKE, kd = drudeKE;
-        double sR = 1.0, sD = 1.0, xmax = 1.0;
-        if (x0 < 0.03125) xmax = dualnh_quirk_loop<CC, false>(eta, ed, edd, em, invM, dtc2, dtc4, dtc8, a.S, realNkbT, drudeNkbT, a.realkbT, a.drudekbT, ef_d1, ef_d2, realKE, drudeKE, sR, sD);
-        if (xmax >= 0.0625) {
+        double sR = 1.0, sD = 1.0, xmax = 0.0;
+        bool wide = x0 >= 0.03125;
+        if (!wide) {
+            xmax = dualnh_quirk_loop<CC, false>(eta, ed, edd, em, invM, dtc2, dtc4, dtc8, a.S, realNkbT, drudeNkbT, a.realkbT, a.drudekbT, ef_d1, ef_d2, realKE, drudeKE, sR, sD);
+            if (xmax >= 0.0625) {
+                if constexpr (!SAVE) return false;
 #pragma unroll
-            for (int i = 0; i < N; i++) { eta[i] = s_eta[i]; ed[i] = s_ed[i]; edd[i] = s_edd[i]; }
-            realKE = kr; drudeKE = kd; sR = 1.0; sD = 1.0;
+                for (int i = 0; i < NS; i++) { eta[i] = s_eta[i]; ed[i] = s_ed[i]; edd[i] = s_edd[i]; }
+                realKE = kr; drudeKE = kd; sR = 1.0; sD = 1.0;
+                wide = true;
+            }
+        }
+        if (wide) {
             xmax = dualnh_quirk_loop<CC, true>(eta, ed, edd, em, invM, dtc2, dtc4, dtc8, a.S, realNkbT, drudeNkbT, a.realkbT, a.drudekbT, ef_d1, ef_d2, realKE, drudeKE, sR, sD);
             if (xmax >= 1.0) return false;
         }

@@ -832,6 +832,10 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
                 // the same count for wstep_kernel, which runs the whole deferred step when the topology has wave tiles
                 const bool multi = c->L.C > 1;
                 bool want_w = c->wave_ke && (c->d.flags & TGNH_FLAG_DEFER_SCALE) && (c->resident_per_cu > 0 || multi);
+                // dualNH's coupled chain (useDrudeNHChains = false) of 2-4 links: wstep_kernel has no room for its fast form beside its
+                // 228 registers (chainN_run<false>), the rescale launches have -- and every kernel of every rank must run the SAME
+                // arithmetic (replicated chains stay bit-identical): such a handle steps the DEFER_SCALE way, chain inside the launch
+                if (c->d.mode == TGNH_MODE_DUALNH && !c->L.use_drude_chains && multi) want_w = false;
 #ifdef TGNH_TUNING
                 if (const char* e = getenv("TGNH_WSTEP")) want_w = want_w && e[0] != '0';
 #endif

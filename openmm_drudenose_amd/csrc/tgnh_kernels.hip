@@ -10,6 +10,10 @@
 // {rescale, half kick, drift, hard wall, KE} a launch performs is a compile-time mask,
 // so e.g. rescale+kick+drift touches each array once.  The Nose-Hoover chains run
 // on the device (chain_kernel, fp64), so a step has no host round trip.
+// Shared device code (precision traits, 64-lane sums, the kinetic-energy bins, the meeting of the one-launch step, the per-tile
+// work of the wave-tile step): tgnh_tile_device.h; the chain: tgnh_chain_device.h.  What these tiles cannot hold -- a Drude particle
+// more than a tile from its parent, more than 32 temperature groups, residues in several runs -- steps through the reference's
+// own un-fused kernels by global index instead: tgnh_gather.hip.
 //
 // Reference semantics followed (scychon/openmm_drudeNose):
 //   K  = platforms/cuda/src/kernels/drudeTGNH.cu
@@ -1283,6 +1287,32 @@ __global__ __launch_bounds__(BLOCK) void chain_long_kernel(const ChainArgs a) {
         a.st[L.off_kesum] = 0.5 * s;
     }
 }
+// dualNH, chains of 5-16 links: ten links WITHOUT useDrudeNHChains are the values of the reference's own test
+// (TestReferenceDrudeTGNHIntegrator.cpp:166), i.e. the coupled chain of Ref :476-503 with eleven moving entries.  chain_kernel runs
+// such chains as the transcription on LDS-resident vectors (run_dualnh<0>: every access a ~100-cycle round trip on a path that is
+// serial by nature); here the entries live in one lane's REGISTERS and the exponentials are the fast chains' polynomials
+// (dualnh_quirk_fast<CC>), and with useDrudeNHChains the two independent chains take a lane each (run_dualnh_pair<CC>: lanes 0
+// and 2 through chain_both_fast).  The transcription stays behind as what runs when an argument leaves the polynomials' range.
+template <int CC>
+__global__ __launch_bounds__(BLOCK) void chain_dualnh_long_kernel(const ChainArgs a) {
+    __shared__ double sred[BLOCK / 64][MAX_GROUPS + 2];
+    __shared__ double s_chain[CHAIN_LDS_DOUBLES];
+    __shared__ double s_ke[MAX_GROUPS + 2];
+    const ChainLayout& L = a.L;
+    const int tid = threadIdx.x;
+    chain_prologue(a, sred, s_chain, s_ke);
+    if (!a.do_sum) __syncthreads();
+    if (tid >= 64) return;
+    bool done = false;
+    if (L.use_drude_chains != 0) {
+        bool ok = false;
+        if (tid == 0 || tid == 2) ok = run_dualnh_pair<CC>(a, a.st, a.st, true, nullptr, tid, s_ke[0], s_ke[1], s_ke[2]);
+        done = __shfl((int)ok, 0, 64) != 0;                          // (the same answer in both lanes: chain_fast votes)
+    } else if (tid == 0) {
+        done = dualnh_quirk_fast<CC, true>(a, a.st, a.st, true, nullptr, s_ke[0], s_ke[1], s_ke[2]);
+    }
+    if (!done && tid == 0) run_dualnh<0, true, false>(a, a.st, a.st, true, nullptr, s_chain, s_ke[0], s_ke[1], s_ke[2]);
+}
 #pragma clang fp contract(fast)
 
 // ---------------------------------------------------------------------------
@@ -1635,6 +1665,14 @@ hipError_t launch_chain(const ChainArgs& a, hipStream_t s) {
             TGNH_LONG(5) TGNH_LONG(6) TGNH_LONG(7) TGNH_LONG(8) TGNH_LONG(9) TGNH_LONG(10) TGNH_LONG(11) TGNH_LONG(12)
             TGNH_LONG(13) TGNH_LONG(14) TGNH_LONG(15) TGNH_LONG(16)
 #undef TGNH_LONG
+        }
+    }
+    else if (a.L.mode == TGNH_MODE_DUALNH && a.L.C > 4 && a.L.C <= 16) {
+        switch (a.L.C) {
+#define TGNH_DLONG(c) case c: TGNH_LAUNCH(chain_dualnh_long_kernel<c>, dim3(1), dim3(BLOCK), 0, s, a); break;
+            TGNH_DLONG(5) TGNH_DLONG(6) TGNH_DLONG(7) TGNH_DLONG(8) TGNH_DLONG(9) TGNH_DLONG(10) TGNH_DLONG(11) TGNH_DLONG(12)
+            TGNH_DLONG(13) TGNH_DLONG(14) TGNH_DLONG(15) TGNH_DLONG(16)
+#undef TGNH_DLONG
         }
     }
     else TGNH_LAUNCH(chain_kernel, dim3(1), dim3(BLOCK), 0, s, a);

@@ -196,7 +196,12 @@ CASES = [
     ("groups32", "TGNH", 5, True, False, 0.0),            # ... 34 thermostats: three batches; COM thermostat inert (Q = 0)
     ("water27", "TGNH", 16, True, True, 0.0),             # ... a full row
     ("water27", "TGNH", 17, True, True, 0.0),             # longer still: the LDS-resident chain
-    ("water27", "dualNH", 10, False, True, 0.0),          # the Reference platform's own test setting (LDS-resident, quirk coupling)
+    ("water27", "dualNH", 10, False, True, 0.0),          # the Reference platform's own test setting: ten links, the coupled chain (chain_dualnh_long_kernel)
+    ("mixed", "dualNH", 5, False, True, 0.02),            # dualNH chains of 5-16 links in registers: the coupled form ...
+    ("water27", "dualNH", 16, False, True, 0.0),
+    ("mixed", "dualNH", 7, True, True, 0.0),              # ... and the two independent chains (useDrudeNHChains), a lane each
+    ("water27", "dualNH", 16, True, True, 0.02),
+    ("water27", "dualNH", 17, False, True, 0.0),          # longer still: the transcription on LDS-resident vectors
     ("water27", "dualNH", 1, True, True, 0.02),           # dualNH one-link chains: the in-kernel chain's code path
     ("mixed", "dualNH", 1, True, True, 0.0),
 ]
@@ -598,13 +603,19 @@ def test_100_step_parity_resident_step(sysname, mode, drude_chains, com, chains,
     s, g, ng, it, ctx = make(sysname, mode, precision, flags=RESIDENT, chains=chains, drude_chains=drude_chains, com=com, hardwall=0.02)
     o = make_oracle(s, g, ng, mode, it)
     pos_o, vel_o = oracle_run(o, s, 100, x0=ctx.sites())
-    assert ctx.resident_work_groups() >= 1
+    # dualNH's COUPLED chain (useDrudeNHChains = false) of 2-4 links is the one exception: wstep_kernel has no room for its fast form,
+    # and every kernel of every rank must run the same chain arithmetic -- such a handle quietly steps the DEFER_SCALE way (round 5)
+    coupled = mode == "dualNH" and not drude_chains and chains > 1
+    assert (ctx.resident_kernel() is None) if coupled else (ctx.resident_work_groups() >= 1)
     ctx.timing(True)
     ctx.step(100)
     ctx.torch.cuda.synchronize()
     ctx.timing(False)
     from openmm_drudenose_amd import _lib
-    assert ctx.timing_read(_lib.KID_STEP)[1] >= 99 and ctx.timing_read(_lib.KID_CHAIN)[1] == 0        # really one launch per step
+    if coupled:
+        assert ctx.timing_read(_lib.KID_STEP)[1] == 0 and ctx.timing_read(_lib.KID_SKD)[1] >= 99       # the deferred launches, chain inside
+    else:
+        assert ctx.timing_read(_lib.KID_STEP)[1] >= 99 and ctx.timing_read(_lib.KID_CHAIN)[1] == 0    # really one launch per step
     ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
     print(f"resident step {sysname} {mode} {precision}: pos {ep:.2e} vel {ev:.2e}")
     assert ep <= TOL and ev <= TOL and ctx.check() == 0

@@ -21,9 +21,9 @@ def test_hot_kernels_keep_their_occupancy():
     assert len(rows) > 40, out.stdout[-2000:]
     # nothing may spill to memory: no vector-register spill, not one instruction that touches the stack (a few instantiations
     # report a 36-byte scratch size with neither: a slot reserved for spilled scalar registers that all went to VGPR lanes)
-    # (chain_long_kernel<14..16>, one wavefront with the chain's links in registers, moves values between its vector and accumulation
+    # (chain_long_kernel<14..16> and chain_dualnh_long_kernel<12..16>, one wavefront with the chain's links in registers, move values between their vector and accumulation
     # registers -- reported as VGPR spills, but to AGPRs: its scratch and stack counts must still be zero)
-    spills = {k: v for k, v in rows.items() if (v[3] != 0 and not k.startswith("chain_long_kernel")) or v[4] != 0 or v[1] > 64}
+    spills = {k: v for k, v in rows.items() if (v[3] != 0 and not k.startswith(("chain_long_kernel", "chain_dualnh_long_kernel"))) or v[4] != 0 or v[1] > 64}
     assert not spills, spills
     for prec in (0, 1, 2):
         for gb in (1, 4, 8):

@@ -11,7 +11,7 @@ from openmm_drudenose_amd.drudetgnhplugin import FLAG_DEFER_SCALE
 for mols in (6400, 125000):
     s, g, ng = synth.water_box(mols)
     for flags, name in ((0, "plain"), (FLAG_DEFER_SCALE, "defer")):
-        for chains in (2, 3, 4):
+        for chains in (2, 3, 4, 10):
             it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, chains, False, True)
             it.setMaxDrudeDistance(0.02)
             ctx = HipContext(s, it, mode="dualNH", precision="mixed", flags=flags)
