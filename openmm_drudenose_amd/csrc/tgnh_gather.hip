@@ -5,12 +5,15 @@
 // has none of those limits: its kernels gather by arbitrary index (K :171-186 pairParticles, :123 particleResId) and size their
 // bins by G + 2 (K :138-200, Cu :157).  So whatever tgnh_create cannot tile -- a Drude particle more than a tile away from its
 // parent, pairs overlapping so densely in a long molecule that no cut between two pairs lies within a tile's reach, more than 32
-// temperature groups -- steps through the kernels of this file instead: the reference's own un-fused form, one work item per
-// normal particle / Drude pair / residue as in K, every look-up a global load.  Nothing here is tuned; it exists so that nothing
-// the reference accepts is refused (still refused: what the reference itself cannot run -- a massless pair member, Ref :132; a
-// molecule without mass under the COM group, K :86-104; dualNH without a pair, Ref :181).
+// temperature groups -- steps through the kernels of this file instead: the reference's own un-fused form, every look-up a global
+// load.  Work items are K's (a normal particle, a Drude pair, a residue) but walked in PARTICLE order: thread i looks at particle
+// i, does a normal particle's work, or -- on the Drude particle -- its pair's, or nothing on a parent, so that a wavefront's loads
+// and stores are consecutive wherever the topology is (K's three index lists walk the arrays two or three times, each with
+// holes: twice the memory traffic at 5 M slots).  It exists so that nothing the reference accepts is refused (still refused:
+// what the reference itself cannot run -- a massless pair member, Ref :132; a molecule without mass under the COM group,
+// K :86-104; dualNH without a pair, Ref :181).
 //
-//   gather_com_kernel    K :82-113   calcCOMVelocities            a wavefront per residue
+//   gather_com_kernel    K :82-113   calcCOMVelocities            2^k lanes per residue (k from the mean residue size)
 //   gather_ke_kernel     K :138-200  computeNormalizedKineticEnergies (with K :119-133 normalizeVelocities folded in); Ref :439-460
 //   gather_rowsum_kernel K :202-242  sumNormalizedKineticEnergies   (more than 34 thermostats; else chain_kernel's own sum)
 //   gather_chain_kernel  Cu :559-642                               (more than 34 thermostats; else chain_kernel)
@@ -32,13 +35,16 @@ __global__ __launch_bounds__(BLOCK) void gather_com_kernel(const GatherArgs a) {
     typedef typename Prec<PREC>::mixed4 mixed4;
     const mixed4* __restrict__ velm = reinterpret_cast<const mixed4*>(a.velm);
     mixed4* __restrict__ com = reinterpret_cast<mixed4*>(a.com);
-    const int lane = threadIdx.x & 63;
-    const int gw = (int)((blockIdx.x * BLOCK + threadIdx.x) >> 6), nwaves = (int)(gridDim.x * BLOCK) >> 6;
+    const int W = a.com_lanes;                                   // lanes per residue: a power of two <= 64 (launch_gather_com)
+    const int sub = threadIdx.x & (W - 1);
+    const long long team = ((long long)blockIdx.x * BLOCK + threadIdx.x) / W, nteams = (long long)gridDim.x * BLOCK / W;
     const mixed fscale = (mixed)(0.5 * a.dt / 4294967296.0);     // Cu :295
-    for (int r = gw; r < a.n_res; r += nwaves) {                 // (wavefront-uniform)
-        const int2 rt = a.res_table[r];                          // (count, first particle): contiguous molecules, Cu :121-125
+    const long long trips = (a.n_res + nteams - 1) / nteams;     // (every lane takes every trip: the sums below are wavefront-wide exchanges)
+    for (long long k = 0; k < trips; k++) {
+        const long long r = team + k * nteams;
+        const int2 rt = r < a.n_res ? a.res_table[r] : make_int2(0, 0);      // (count, first particle): contiguous molecules, Cu :121-125
         double sx = 0, sy = 0, sz = 0, sm = 0;
-        for (int j = lane; j < rt.x; j += 64) {
+        for (int j = sub; j < rt.x; j += W) {
             const int i = rt.y + j;
             if (i >= a.n) break;                                 // (a residue in several runs: K's walk of `count` particles from the last run's start may leave the array; it stops at its end here)
             const mixed4 v = velm[i];
@@ -52,8 +58,10 @@ __global__ __launch_bounds__(BLOCK) void gather_com_kernel(const GatherArgs a) {
                 sx += (double)(vx * m); sy += (double)(vy * m); sz += (double)(vz * m); sm += (double)m;
             }
         }
-        sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); sm = wave_sum(sm);
-        if (lane == 0) {
+        for (int off = W >> 1; off; off >>= 1) {                 // butterfly over the residue's lanes: a fixed order
+            sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64); sz += __shfl_xor(sz, off, 64); sm += __shfl_xor(sm, off, 64);
+        }
+        if (sub == 0 && r < a.n_res) {
             const double wi = 1.0 / sm;                          // K :101 (a molecule without mass: refused at create)
             com[r] = mk4((mixed)(sx * wi), (mixed)(sy * wi), (mixed)(sz * wi), (mixed)wi);
         }
@@ -64,6 +72,7 @@ __global__ __launch_bounds__(BLOCK) void gather_com_kernel(const GatherArgs a) {
 // kinetic-energy bins.  Work items, as K's three loops: residues (bin G: M v_com^2, K :152-158), normal particles (bin of their
 // group: m |v - v_com|^2, K :161-168; Ref :443-448), pairs (bin of the DRUDE particle's group: (m1 + m2) |cm|^2, bin G + 1:
 // mu |v2 - v1|^2, K :171-186; Ref :449-460), each particle relative to its OWN residue's centre of mass (K :123-129).
+// Items 0 .. n-1 are the particles in index order (a pair is its Drude particle's item, a parent's item is empty), then the residues.
 // One row of partial sums per work-group.  Group bins: one row of NT doubles per wavefront in LDS; per batch of 64 items a
 // wavefront adds, group by group in the order the groups first appear in the batch, the 64-lane sum of that group's values.
 // ---------------------------------------------------------------------------
@@ -80,14 +89,15 @@ __global__ __launch_bounds__(BLOCK) void gather_ke_kernel(const GatherArgs a) {
     double* const wbins = bins + (size_t)wv * NT;
     for (int b = lane; b < NT; b += 64) wbins[b] = 0.0;
     double ke_com = 0.0, ke_drude = 0.0;
-    const int n_items = a.n_normal + a.n_pairs + (a.use_com ? a.n_res : 0);
+    const long long n_items = (long long)a.n + (a.use_com ? a.n_res : 0);
     for (long long base = (long long)blockIdx.x * BLOCK + (tid & ~63); base < n_items; base += (long long)gridDim.x * BLOCK) {   // (wavefront-uniform trips)
-        const int it = (int)base + lane;
+        const long long it = base + lane;
         bool has = false;
         int g = 0;
         double val = 0.0;
-        if (it < a.n_normal) {                                   // K :161-168
-            const int p = a.normal[it];
+        const int pj = it < a.n ? a.partner[it] : 0;             // partner | is-Drude << 31 ; -1: in no pair
+        if (it < a.n && pj == -1) {                              // K :161-168
+            const int p = (int)it;
             const mixed4 v = velm[p];
             if (v.w != 0) {
                 double cx = 0, cy = 0, cz = 0;
@@ -96,8 +106,8 @@ __global__ __launch_bounds__(BLOCK) void gather_ke_kernel(const GatherArgs a) {
                 val = (rx * rx + ry * ry + rz * rz) * (double)rcp_(v.w);
                 g = a.group[p]; has = true;
             }
-        } else if (it < a.n_normal + a.n_pairs) {                // K :171-186
-            const int2 pr = a.pairs[it - a.n_normal];
+        } else if (it < a.n && pj < 0) {                         // K :171-186 (the Drude particle's item)
+            const int2 pr = make_int2((int)it, pj & 0x7fffffff);
             const mixed4 v1 = velm[pr.x], v2 = velm[pr.y];
             double c1x = 0, c1y = 0, c1z = 0, c2x = 0, c2y = 0, c2z = 0;
             if (a.use_com) {
@@ -114,8 +124,8 @@ __global__ __launch_bounds__(BLOCK) void gather_ke_kernel(const GatherArgs a) {
             val = (cmx * cmx + cmy * cmy + cmz * cmz) * (mass1 + mass2);
             ke_drude += (rlx * rlx + rly * rly + rlz * rlz) * (mass1 * mass2 * invTot);      // reduced mass = 1 / invReducedMass (K :178, :185)
             g = a.group[pr.x]; has = true;
-        } else if (it < n_items) {                               // K :152-158
-            const mixed4 c = com[it - a.n_normal - a.n_pairs];
+        } else if (it >= a.n && it < n_items) {                  // K :152-158
+            const mixed4 c = com[it - a.n];
             ke_com += ((double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z) / (double)c.w;
         }
         unsigned long long rem = __ballot(has);
@@ -183,7 +193,8 @@ __global__ __launch_bounds__(BLOCK) void gather_chain_kernel(const ChainArgs a, 
 
 // ---------------------------------------------------------------------------
 // rescale / half kick / drift / posDelta / move / hard wall, by index.  A work item is a normal particle or a PAIR (both
-// members in one thread, as K: a pair's rescale reads both old velocities and writes both new ones).
+// members in one thread, as K: a pair's rescale reads both old velocities and writes both new ones); thread i takes particle
+// i's item -- its own if it is in no pair, its pair's if it is the Drude particle, none if it is a parent.
 // Order of the operations: tile_body's (A6, A8-move, A7, A8-drift, posDelta, A10).
 // ---------------------------------------------------------------------------
 template <int PREC>
@@ -250,10 +261,10 @@ __global__ __launch_bounds__(BLOCK) void gather_update_kernel(const GatherArgs a
         }
     };
 
-    const int n_items = a.n_normal + a.n_pairs;
-    for (long long it = (long long)blockIdx.x * BLOCK + threadIdx.x; it < n_items; it += (long long)gridDim.x * BLOCK) {
-        if (it < a.n_normal) {
-            const int i = a.normal[it];
+    for (long long it = (long long)blockIdx.x * BLOCK + threadIdx.x; it < a.n; it += (long long)gridDim.x * BLOCK) {
+        const int i = (int)it;
+        const int pj = a.partner[i];                             // partner | is-Drude << 31 ; -1: in no pair
+        if (pj == -1) {
             P p; load(i, p);
             if (do_prekick) kick(p);
             if (do_scale && p.v.w != 0) {                        // K :260-265
@@ -267,7 +278,8 @@ __global__ __launch_bounds__(BLOCK) void gather_update_kernel(const GatherArgs a
             store(i, p);
             continue;
         }
-        const int2 pr = a.pairs[it - a.n_normal];                // (Drude particle, parent): K's particles.x, .y
+        if (pj >= 0) continue;                                   // a parent: its Drude particle's thread does the pair
+        const int2 pr = make_int2(i, pj & 0x7fffffff);           // (Drude particle, parent): K's particles.x, .y
         P p1, p2; load(pr.x, p1); load(pr.y, p2);
         if (do_prekick) { kick(p1); kick(p2); }
         const mixed mass1 = rcp_(p1.v.w), mass2 = rcp_(p2.v.w);  // (massless pair members: refused at create)
@@ -343,7 +355,7 @@ __global__ __launch_bounds__(BLOCK) void gather_force_kernel(const GatherArgs a,
     };
     for (long long it = (long long)blockIdx.x * BLOCK + threadIdx.x; it < a.n; it += (long long)gridDim.x * BLOCK) {
         const int i = (int)it;
-        const int pj = a.partner[i];                             // partner | is-Drude << 31 ; -1: no pair
+        const int pj = a.partner[i];
         mixed x, y, z;
         position(i, x, y, z);
         mixed fx = 0, fy = 0, fz = 0;
@@ -382,12 +394,12 @@ static int gather_grid(const long long items, const int cap) {
     }
 
 hipError_t launch_gather_com(int precision, const GatherArgs& a, hipStream_t s) {
-    const int grid = gather_grid((long long)a.n_res * 64, 4096);               // a wavefront per residue
+    const int grid = gather_grid((long long)a.n_res * a.com_lanes, 8192);
     GATHER_BY_PREC(gather_com_kernel, grid, 0, s, a)
     return hipGetLastError();
 }
 int gather_ke_grid(const GatherArgs& a) {
-    return gather_grid((long long)a.n_normal + a.n_pairs + (a.use_com ? a.n_res : 0), GATHER_KE_ROWS);
+    return gather_grid((long long)a.n + (a.use_com ? a.n_res : 0), GATHER_KE_ROWS);
 }
 hipError_t launch_gather_ke(int precision, const GatherArgs& a, int grid, hipStream_t s) {
     const size_t lds = sizeof(double) * (BLOCK / 64) * (size_t)a.NT;
@@ -404,7 +416,7 @@ hipError_t launch_gather_chain(const ChainArgs& a, double* scratch, hipStream_t 
     return hipGetLastError();
 }
 hipError_t launch_gather_update(int precision, const GatherArgs& a, hipStream_t s) {
-    const int grid = gather_grid((long long)a.n_normal + a.n_pairs, 8192);
+    const int grid = gather_grid(a.n, 8192);
     GATHER_BY_PREC(gather_update_kernel, grid, 0, s, a)
     return hipGetLastError();
 }

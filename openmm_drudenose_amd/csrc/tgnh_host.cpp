@@ -74,7 +74,7 @@ static bool resident_now(tgnh_handle h);
 static tgnh_status build_gather_topology(tgnh_context* c, const std::vector<int>& role, const std::vector<int>& partner,
                                          const std::vector<int>& res_order) {
     const tgnh_desc& d = c->d;
-    const int N = d.num_particles, P = d.num_pairs;
+    const int N = d.num_particles;
     const bool com = d.mode == TGNH_MODE_TGNH && d.use_com_temp_group;
     c->tile_start.assign(1, N); c->tile_res.assign(1, 0); c->num_tiles = 0;
     c->res_entries.assign(1, make_int2(0, 0));
@@ -89,9 +89,12 @@ static tgnh_status build_gather_topology(tgnh_context* c, const std::vector<int>
         for (int i = 0; i < N; i++) c->g_resid[i] = internal[c->resid[i]];
     }
     if (c->g_res_table.empty()) c->g_res_table.push_back(make_int2(0, 0));
-    c->g_pairs.resize(std::max(P, 1));
-    for (int i = 0; i < P; i++) c->g_pairs[i] = make_int2(c->pair_drude[i], c->pair_parent[i]);
-    c->g_partner.assign(N, -1);                                  // harness force: partner | is-Drude << 31
+    {   // gather_com_kernel's lanes per residue: the power of two that holds the mean residue
+        const size_t mean = c->g_res_table.empty() ? 1 : ((size_t)N + c->g_res_table.size() - 1) / c->g_res_table.size();
+        c->g_com_lanes = 1;
+        while (c->g_com_lanes < 64 && (size_t)c->g_com_lanes < mean) c->g_com_lanes *= 2;
+    }
+    c->g_partner.assign(N, -1);                                  // the other member of a particle's pair | is-Drude << 31
     for (int i = 0; i < N; i++)
         if (partner[i] >= 0) c->g_partner[i] = role[i] == (int)ROLE_DRUDE ? (int)((unsigned)partner[i] | 0x80000000u) : partner[i];
     if (c->host_only) return TGNH_OK;
@@ -101,8 +104,6 @@ static tgnh_status build_gather_topology(tgnh_context* c, const std::vector<int>
         if (e != hipSuccess || v.empty()) return e;
         return hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice);
     };
-    HIP_OK(up(&c->d_g_normal, c->normal));
-    HIP_OK(up(&c->d_g_pairs, c->g_pairs));
     HIP_OK(up(&c->d_g_group, c->group));
     HIP_OK(up(&c->d_g_resid, c->g_resid));
     HIP_OK(up(&c->d_g_res_table, c->g_res_table));
@@ -612,8 +613,6 @@ static void free_device(tgnh_context* c) {
     if (c->d_lat_tab) (void)hipFree(c->d_lat_tab);
     if (c->d_big_table) (void)hipFree(c->d_big_table);
     if (c->d_big_com) (void)hipFree(c->d_big_com);
-    if (c->d_g_normal) (void)hipFree(c->d_g_normal);
-    if (c->d_g_pairs) (void)hipFree(c->d_g_pairs);
     if (c->d_g_group) (void)hipFree(c->d_g_group);
     if (c->d_g_resid) (void)hipFree(c->d_g_resid);
     if (c->d_g_res_table) (void)hipFree(c->d_g_res_table);
@@ -1370,12 +1369,12 @@ static GatherArgs gather_args(tgnh_handle h, const double* scale) {
     GatherArgs a{};
     a.posq = h->posq; a.posq_corr = h->posq_corr; a.velm = h->velm;
     a.force = reinterpret_cast<const long long*>(h->force); a.pos_delta = h->pos_delta;
-    a.normal = h->d_g_normal; a.pairs = h->d_g_pairs; a.group = h->d_g_group; a.resid = h->d_g_resid;
+    a.group = h->d_g_group; a.resid = h->d_g_resid;
     a.res_table = h->d_g_res_table; a.partner = h->d_g_partner; a.com = h->d_g_com;
     a.scale = scale ? scale : h->d_state + h->L.off_scale;
     a.partials = h->d_partials; a.status = h->d_status;
     a.n = h->d.num_particles; a.padded = h->d.padded_num_particles;
-    a.n_normal = (int)h->normal.size(); a.n_pairs = h->d.num_pairs;
+    a.com_lanes = h->g_com_lanes;
     a.use_com = (h->d.mode == TGNH_MODE_TGNH && h->d.use_com_temp_group) ? 1 : 0;
     a.n_res = a.use_com ? (int)h->g_res_table.size() : 0;
     a.G = h->L.G; a.NT = h->L.NT;

@@ -271,17 +271,16 @@ constexpr int GATHER_KE_ROWS = 1024;        // work-groups (= rows of partial su
 constexpr int GATHER_MAX_NT = 2048;         // thermostats: a row of fp64 bins per wavefront, four wavefronts, 64 KiB of LDS
 struct GatherArgs {
     void* posq; void* posq_corr; void* velm; const long long* force; void* pos_delta;
-    const int* normal;         // [n_normal] ascending indices of the particles in no pair (Ref :137), massless sites included
-    const int2* pairs;         // [n_pairs] (Drude particle, parent) in DrudeForce order (Ref :124-127)
     const int* group;          // [n] temperature group (Cu :117)
     const int* resid;          // [n] residue, as index into res_table / com (Cu :118)
     const int2* res_table;     // [n_res] (count, first particle) (Cu :121-125)
-    const int* partner;        // [n] harness force: partner | is-Drude << 31, -1 none
+    const int* partner;        // [n] the other member of the particle's pair | is-Drude << 31, -1: in no pair (Ref :124-137)
     void* com;                 // mixed4 [n_res] centre-of-mass velocity, w = 1 / M (K comVelm)
     const double* scale;       // [NT]
     double* partials;          // [rows][NT]
     uint32_t* status;
-    int n, padded, n_normal, n_pairs, n_res, G, NT, use_com, hardwall, ops, kick_com;
+    int n, padded, n_res, G, NT, use_com, hardwall, ops, kick_com;
+    int com_lanes;             // gather_com_kernel: lanes per residue (a power of two <= 64)
     double dt, max_dist, hw_scale;
 };
 
@@ -338,10 +337,11 @@ struct tgnh_context {
     bool generic = false;
     bool gather_chain = false;        // ... and its chain too: more than 34 thermostats, or links that do not fit the LDS (gather_chain_kernel)
     std::string generic_reason;
-    std::vector<int2> g_pairs, g_res_table;
+    std::vector<int2> g_res_table;
     std::vector<int> g_resid, g_partner;
-    int *d_g_normal = nullptr, *d_g_group = nullptr, *d_g_resid = nullptr, *d_g_partner = nullptr;
-    int2 *d_g_pairs = nullptr, *d_g_res_table = nullptr;
+    int *d_g_group = nullptr, *d_g_resid = nullptr, *d_g_partner = nullptr;
+    int2* d_g_res_table = nullptr;
+    int g_com_lanes = 64;
     void* d_g_com = nullptr;
     double* d_g_scratch = nullptr;    // chains longer than 4 links of more than 34 thermostats: a row of 4 C + 1 doubles each
     void* d_g_x0 = nullptr;           // harness: the tether sites as tgnh_harness_pack_sites was handed them

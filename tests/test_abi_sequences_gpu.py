@@ -236,5 +236,9 @@ def test_random_call_sequence_on_the_gather_path(flags, exchange, chains):
     the harness' constraint call-outs, setters, queries, a rebind: every sum in another order, the cross-kind gate.  The flags that
     change the pass structure are ignored on it (nothing is owed between steps, setters are never refused)."""
     w = Walk(flags, exchange, chains, seed=9000 + flags, wave=False, cross=True)
+    # the third link of a three-link chain amplifies a rounding of etaDot_0 by ~ the number of degrees of freedom (Walk.__init__):
+    # 1.5e-8 relative in its etaDot at call 474 of this walk with the gather path's particle-order sums, positions 1e-12 and
+    # velocities < 5e-10 throughout; a wrong launch shows as 1e-3
+    w.gate_t = dict(rtol=1e-7, atol=1e-9)
     assert w.ctx.step_path()[0] == "gather" and w.ref.step_path()[0] == "tiled"
     w.run()
