@@ -264,75 +264,77 @@ __global__ __launch_bounds__(BLOCK) void gather_update_kernel(const GatherArgs a
     for (long long it = (long long)blockIdx.x * BLOCK + threadIdx.x; it < a.n; it += (long long)gridDim.x * BLOCK) {
         const int i = (int)it;
         const int pj = a.partner[i];                             // partner | is-Drude << 31 ; -1: in no pair
-        if (pj == -1) {
-            P p; load(i, p);
+        if (pj >= 0) continue;                                   // a parent: its Drude particle's thread does the pair
+        const bool pair = pj != -1;
+        const int2 pr = make_int2(i, pair ? pj & 0x7fffffff : i);   // (Drude particle, parent): K's particles.x, .y
+        P p1, p2;
+        load(i, p1);                                             // (the thread's own particle: one instruction stream for both kinds of item)
+        const mixed s_g = do_scale ? (mixed)a.scale[a.group[i]] : (mixed)1;      // (a pair's group is its Drude particle's, K :270)
+        if (!pair) {
+            P& p = p1;
             if (do_prekick) kick(p);
             if (do_scale && p.v.w != 0) {                        // K :260-265
-                const mixed s_g = (mixed)a.scale[a.group[i]];
                 const mixed rx = p.v.x - p.cx, ry = p.v.y - p.cy, rz = p.v.z - p.cz;
                 p.v.x = s_g * rx + s_com * (p.v.x - rx);
                 p.v.y = s_g * ry + s_com * (p.v.y - ry);
                 p.v.z = s_g * rz + s_com * (p.v.z - rz);
             }
             after_scale(p);
-            store(i, p);
-            continue;
-        }
-        if (pj >= 0) continue;                                   // a parent: its Drude particle's thread does the pair
-        const int2 pr = make_int2(i, pj & 0x7fffffff);           // (Drude particle, parent): K's particles.x, .y
-        P p1, p2; load(pr.x, p1); load(pr.y, p2);
-        if (do_prekick) { kick(p1); kick(p2); }
-        const mixed mass1 = rcp_(p1.v.w), mass2 = rcp_(p2.v.w);  // (massless pair members: refused at create)
-        const mixed invTot = rcp_(mass1 + mass2);
-        if (do_scale) {                                          // K :270-300
-            const mixed s_g = (mixed)a.scale[a.group[pr.x]];
-            const mixed m1f = invTot * mass1, m2f = invTot * mass2;
-            const mixed r1x = p1.v.x - p1.cx, r1y = p1.v.y - p1.cy, r1z = p1.v.z - p1.cz;
-            const mixed r2x = p2.v.x - p2.cx, r2y = p2.v.y - p2.cy, r2z = p2.v.z - p2.cz;
-            const mixed cmx = s_g * (r1x * m1f + r2x * m2f), cmy = s_g * (r1y * m1f + r2y * m2f), cmz = s_g * (r1z * m1f + r2z * m2f);
-            const mixed rlx = s_drude * (r2x - r1x), rly = s_drude * (r2y - r1y), rlz = s_drude * (r2z - r1z);
-            p1.v.x = cmx - rlx * m2f + s_com * (p1.v.x - r1x);
-            p1.v.y = cmy - rly * m2f + s_com * (p1.v.y - r1y);
-            p1.v.z = cmz - rlz * m2f + s_com * (p1.v.z - r1z);
-            p2.v.x = cmx + rlx * m1f + s_com * (p2.v.x - r2x);
-            p2.v.y = cmy + rly * m1f + s_com * (p2.v.y - r2y);
-            p2.v.z = cmz + rlz * m1f + s_com * (p2.v.z - r2z);
-        }
-        after_scale(p1); after_scale(p2);
-        if (hardwall) {                                          // K :471-574 ; Ref :298-363 (tile_body's arithmetic, both members here)
-            const mixed maxd = (mixed)a.max_dist, hws = (mixed)a.hw_scale;
-            const mixed dx = p1.px - p2.px, dy = p1.py - p2.py, dz = p1.pz - p2.pz;          // Drude - parent (K :487)
-            const mixed d2 = dx * dx + dy * dy + dz * dz;
-            if (d2 > maxd * maxd) {
-                const mixed r = sqrt_(d2);
-                const mixed rInv = rcp_(r);
-                if (rInv * maxd < (mixed)0.5) atomicOr(a.status, 1u);                         // Ref :311-312
-                const mixed bx = dx * rInv, by = dy * rInv, bz = dz * rInv;
-                const mixed deltaR = r - maxd;
-                mixed deltaT = dt;
-                mixed dotvr1 = p1.v.x * bx + p1.v.y * by + p1.v.z * bz;
-                const mixed vp1x = p1.v.x - bx * dotvr1, vp1y = p1.v.y - by * dotvr1, vp1z = p1.v.z - bz * dotvr1;
-                mixed dotvr2 = p2.v.x * bx + p2.v.y * by + p2.v.z * bz;
-                const mixed vp2x = p2.v.x - bx * dotvr2, vp2y = p2.v.y - by * dotvr2, vp2z = p2.v.z - bz * dotvr2;
-                const mixed vbCMass = (mass1 * dotvr1 + mass2 * dotvr2) * invTot;
-                dotvr1 -= vbCMass;
-                dotvr2 -= vbCMass;
-                if (dotvr1 != dotvr2) deltaT = deltaR / abs_(dotvr1 - dotvr2);
-                if (deltaT > dt) deltaT = dt;
-                const mixed vBond = hws / sqrt_(mass1);
-                dotvr1 = -dotvr1 * vBond * mass2 * invTot / abs_(dotvr1);
-                dotvr2 = -dotvr2 * vBond * mass1 * invTot / abs_(dotvr2);
-                const mixed dr1 = -deltaR * mass2 * invTot + deltaT * dotvr1;
-                const mixed dr2 = deltaR * mass1 * invTot + deltaT * dotvr2;
-                dotvr1 += vbCMass;
-                dotvr2 += vbCMass;
-                p1.px += bx * dr1; p1.py += by * dr1; p1.pz += bz * dr1;
-                p1.v.x = vp1x + bx * dotvr1; p1.v.y = vp1y + by * dotvr1; p1.v.z = vp1z + bz * dotvr1;
-                p2.px += bx * dr2; p2.py += by * dr2; p2.pz += bz * dr2;
-                p2.v.x = vp2x + bx * dotvr2; p2.v.y = vp2y + by * dotvr2; p2.v.z = vp2z + bz * dotvr2;
+        } else {
+            load(pr.y, p2);
+            if (do_prekick) { kick(p1); kick(p2); }
+            const mixed mass1 = rcp_(p1.v.w), mass2 = rcp_(p2.v.w);      // (massless pair members: refused at create)
+            const mixed invTot = rcp_(mass1 + mass2);
+            if (do_scale) {                                      // K :270-300
+                const mixed m1f = invTot * mass1, m2f = invTot * mass2;
+                const mixed r1x = p1.v.x - p1.cx, r1y = p1.v.y - p1.cy, r1z = p1.v.z - p1.cz;
+                const mixed r2x = p2.v.x - p2.cx, r2y = p2.v.y - p2.cy, r2z = p2.v.z - p2.cz;
+                const mixed cmx = s_g * (r1x * m1f + r2x * m2f), cmy = s_g * (r1y * m1f + r2y * m2f), cmz = s_g * (r1z * m1f + r2z * m2f);
+                const mixed rlx = s_drude * (r2x - r1x), rly = s_drude * (r2y - r1y), rlz = s_drude * (r2z - r1z);
+                p1.v.x = cmx - rlx * m2f + s_com * (p1.v.x - r1x);
+                p1.v.y = cmy - rly * m2f + s_com * (p1.v.y - r1y);
+                p1.v.z = cmz - rlz * m2f + s_com * (p1.v.z - r1z);
+                p2.v.x = cmx + rlx * m1f + s_com * (p2.v.x - r2x);
+                p2.v.y = cmy + rly * m1f + s_com * (p2.v.y - r2y);
+                p2.v.z = cmz + rlz * m1f + s_com * (p2.v.z - r2z);
             }
+            after_scale(p1); after_scale(p2);
+            if (hardwall) {                                      // K :471-574 ; Ref :298-363 (tile_body's arithmetic, both members here)
+                const mixed maxd = (mixed)a.max_dist, hws = (mixed)a.hw_scale;
+                const mixed dx = p1.px - p2.px, dy = p1.py - p2.py, dz = p1.pz - p2.pz;          // Drude - parent (K :487)
+                const mixed d2 = dx * dx + dy * dy + dz * dz;
+                if (d2 > maxd * maxd) {
+                    const mixed r = sqrt_(d2);
+                    const mixed rInv = rcp_(r);
+                    if (rInv * maxd < (mixed)0.5) atomicOr(a.status, 1u);                         // Ref :311-312
+                    const mixed bx = dx * rInv, by = dy * rInv, bz = dz * rInv;
+                    const mixed deltaR = r - maxd;
+                    mixed deltaT = dt;
+                    mixed dotvr1 = p1.v.x * bx + p1.v.y * by + p1.v.z * bz;
+                    const mixed vp1x = p1.v.x - bx * dotvr1, vp1y = p1.v.y - by * dotvr1, vp1z = p1.v.z - bz * dotvr1;
+                    mixed dotvr2 = p2.v.x * bx + p2.v.y * by + p2.v.z * bz;
+                    const mixed vp2x = p2.v.x - bx * dotvr2, vp2y = p2.v.y - by * dotvr2, vp2z = p2.v.z - bz * dotvr2;
+                    const mixed vbCMass = (mass1 * dotvr1 + mass2 * dotvr2) * invTot;
+                    dotvr1 -= vbCMass;
+                    dotvr2 -= vbCMass;
+                    if (dotvr1 != dotvr2) deltaT = deltaR / abs_(dotvr1 - dotvr2);
+                    if (deltaT > dt) deltaT = dt;
+                    const mixed vBond = hws / sqrt_(mass1);
+                    dotvr1 = -dotvr1 * vBond * mass2 * invTot / abs_(dotvr1);
+                    dotvr2 = -dotvr2 * vBond * mass1 * invTot / abs_(dotvr2);
+                    const mixed dr1 = -deltaR * mass2 * invTot + deltaT * dotvr1;
+                    const mixed dr2 = deltaR * mass1 * invTot + deltaT * dotvr2;
+                    dotvr1 += vbCMass;
+                    dotvr2 += vbCMass;
+                    p1.px += bx * dr1; p1.py += by * dr1; p1.pz += bz * dr1;
+                    p1.v.x = vp1x + bx * dotvr1; p1.v.y = vp1y + by * dotvr1; p1.v.z = vp1z + bz * dotvr1;
+                    p2.px += bx * dr2; p2.py += by * dr2; p2.pz += bz * dr2;
+                    p2.v.x = vp2x + bx * dotvr2; p2.v.y = vp2y + by * dotvr2; p2.v.z = vp2z + bz * dotvr2;
+                }
+            }
+            store(pr.y, p2);
         }
-        store(pr.x, p1); store(pr.y, p2);
+        store(i, p1);
     }
 }
 

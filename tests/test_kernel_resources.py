@@ -25,6 +25,8 @@ def test_hot_kernels_keep_their_occupancy():
     # registers -- reported as VGPR spills, but to AGPRs: its scratch and stack counts must still be zero)
     spills = {k: v for k, v in rows.items() if (v[3] != 0 and not k.startswith(("chain_long_kernel", "chain_dualnh_long_kernel"))) or v[4] != 0 or v[1] > 64}
     assert not spills, spills
+    for prec in (0, 1, 2):          # the gather path (tgnh_gather.hip): untuned, but at >= 3 wavefronts per SIMD and (above) without a spill
+        assert rows[f"gather_update_kernel<{prec}>"][2] >= 3 and rows[f"gather_ke_kernel<{prec}>"][2] >= 8, (prec, rows[f"gather_update_kernel<{prec}>"])
     for prec in (0, 1, 2):
         for gb in (1, 4, 8):
             for kind in range(5):        # a whole deferred step; the halves of the reference's structure, fused and split

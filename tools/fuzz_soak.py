@@ -36,7 +36,7 @@ import pytest  # noqa: E402
 import test_abi_sequences_gpu as T  # noqa: E402
 from openmm_drudenose_amd import synth, HipContext  # noqa: E402
 from openmm_drudenose_amd.drudetgnhplugin import (DrudeTGNHIntegrator, FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES,  # noqa: E402
-                                                   FLAG_TRUST_STATE_CHANGED, TgnhError)
+                                                   FLAG_TRUST_STATE_CHANGED, FLAG_GATHER, TgnhError)
 from openmm_drudenose_amd import _lib  # noqa: E402
 
 SYSTEMS = {
@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--modes", action="store_true", help="also draw dualNH / TGNH, mixed / double precision, useDrudeNHChains, the hard wall, "
                     "a CMMotionRemover in the System, ragged random topologies and two 40-50 k-slot boxes")
     ap.add_argument("--constrained", action="store_true", help="with --modes: rigid water and the constrained ionic liquid too")
+    ap.add_argument("--gather", action="store_true", help="half of the walks on the gather path (TGNH_FLAG_GATHER) against the tiled plain handle: "
+                    "every sum in another order, the suite's cross-kind gates")
     ap.add_argument("--trace", default="", help="with --only: compare after every call and write the errors (variant, twin) here")
     ap.add_argument("--only", default="", help="comma-separated seeds: run just these walks of the sequence --seed0 defines")
     a = ap.parse_args()
@@ -198,6 +200,8 @@ def main():
                 name = BIG[u - 6]
             elif u < 10 and a.constrained:
                 name = CONSTRAINED[u - 8]
+        if a.gather and pick.integers(0, 2):
+            flags |= FLAG_GATHER
         what = (f"system={name} flags={flags} exchange={exchange} chains={chains} wave={wave} com={COM} seed={seed}"
                 + (f" mode={MODE} precision={PRECISION} drude_chains={DRUDE_CHAINS} hardwall={HARDWALL} cmm={CMM}" if a.modes else ""))
         if only and seed not in only:
@@ -209,6 +213,8 @@ def main():
         t0 = time.time()
         try:
             w = SoakWalk(flags, exchange, chains, seed=seed, wave=wave)
+            if flags & FLAG_GATHER:                                  # (tests/test_abi_sequences_gpu.py::test_random_call_sequence_on_the_gather_path's gates)
+                w.gate_v, w.gate_t = 5e-10, dict(rtol=1e-7, atol=1e-9)
             if a.trace:
                 T.CHECK_EVERY = 1
                 w.trace = open(a.trace, "a")

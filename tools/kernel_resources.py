@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Prints VGPR/SGPR/LDS/occupancy per gfx950 kernel of tgnh_kernels.hip (hipcc -Rpass-analysis), the VGPR spills, and the
+"""Prints VGPR/SGPR/LDS/occupancy per gfx950 kernel of tgnh_kernels.hip and tgnh_gather.hip (hipcc -Rpass-analysis), the VGPR spills, and the
 number of instructions in the kernel's ISA that touch the stack (`stackops`: scratch_* / buffer_* -- nothing else here uses
 buffer instructions).  A small `scratch` with stackops 0 and no VGPR spill is a slot the register allocator reserved for
 spilled scalar registers and never used (they went to VGPR lanes): nothing is stored to memory."""
@@ -7,7 +7,7 @@ import re, subprocess, sys, os, tempfile
 csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "openmm_drudenose_amd", "csrc")
 out, stack = "", {}
 with tempfile.TemporaryDirectory() as tmp:
-    for name in ("tgnh_kernels.hip",):
+    for name in ("tgnh_kernels.hip", "tgnh_gather.hip"):
         asm = os.path.join(tmp, name + ".s")
         out += subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-x", "hip",
                                os.path.join(csrc, name), "-o", asm, "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:],
