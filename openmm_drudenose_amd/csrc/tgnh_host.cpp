@@ -1393,10 +1393,14 @@ static tgnh_status run_gather(tgnh_handle h, int ops, int kid, hipStream_t s, co
     if (ops & OP_NOSTORE) return fail(TGNH_ERR_STATE, "internal: the gather path stores every kick");
     Timed t(h, s, kid);
     if (upd) {
-        if ((upd & OP_SCALE) && a.use_com) {       // K :474-479 before :351-353: v - v_com of the velocities about to be rescaled
+        // K :474-479 before :351-353: v - v_com of the velocities about to be rescaled.  On this path every rescale follows a
+        // kinetic-energy pass and its chain inside one entry point (the flags that would part them are ignored), so the table
+        // that pass left is of these very velocities: not computed again
+        if ((upd & OP_SCALE) && a.use_com && !(h->g_com_fresh && !(upd & OP_PREKICK))) {
             a.kick_com = (upd & OP_PREKICK) ? 1 : 0;
             HIP_OK(launch_gather_com(h->d.precision, a, s));
         }
+        h->g_com_fresh = false;
         a.ops = upd;
         HIP_OK(launch_gather_update(h->d.precision, a, s));
     }
@@ -1407,6 +1411,7 @@ static tgnh_status run_gather(tgnh_handle h, int ops, int kid, hipStream_t s, co
         HIP_OK(launch_gather_ke(h->d.precision, a, grid, s));
         h->ke_parts = grid;
         h->tail_summed = false;
+        h->g_com_fresh = a.use_com != 0;
     }
     return TGNH_OK;
 }
@@ -1685,6 +1690,7 @@ static tgnh_status first_half(tgnh_handle h, hipStream_t s) {
 // the trajectory is no longer the integrator's, so nothing more is computed on it.
 static tgnh_status entry(tgnh_handle h, bool need_bufs) {
     if (!h) return fail(TGNH_ERR_ARG, "null handle");
+    h->g_com_fresh = false;                                           // (the caller may have written velocities since the last entry point)
     if (need_bufs) { tgnh_status rc = need_buffers(h); if (rc) return rc; }
     if (!h->host_only) {
         HIP_OK(hipSetDevice(h->device));

@@ -342,6 +342,7 @@ struct tgnh_context {
     int *d_g_group = nullptr, *d_g_resid = nullptr, *d_g_partner = nullptr;
     int2* d_g_res_table = nullptr;
     int g_com_lanes = 64;
+    bool g_com_fresh = false;         // the COM table is of the velocities as they are (set by a KE pass; cleared by the next launch that writes velocities and on entry to every entry point)
     void* d_g_com = nullptr;
     double* d_g_scratch = nullptr;    // chains longer than 4 links of more than 34 thermostats: a row of 4 C + 1 doubles each
     void* d_g_x0 = nullptr;           // harness: the tether sites as tgnh_harness_pack_sites was handed them
