@@ -134,6 +134,30 @@ def test_kinetic_energy_queries_on_the_gather_path():
     ctx.close()
 
 
+def test_velocities_written_between_a_kinetic_energy_query_and_a_step():
+    """The gather path's rescale launches reuse the centre-of-mass table of the kinetic-energy pass before them (run_gather,
+    tgnh_host.cpp) -- only inside one entry point: a query's table must not outlive velocities the caller writes after it.  The
+    same calls on a tiled handle of the same system (TGNH mode, COM group on, molecules of different composition so that a
+    stale table would show in the first rescale)."""
+    out = []
+    for flags in (0, FLAG_GATHER):
+        s, g, ng = synth.mixed(200, 15)
+        it = integ(chains=1)
+        bind_groups(it, g, ng)
+        ctx = HipContext(s, it, mode="TGNH", precision="double", flags=flags)
+        ctx.step(3)
+        ctx.compute_kinetic_energies()                          # leaves a table of THESE velocities
+        rng = np.random.default_rng(5)
+        v = ctx.getVelocities()
+        per_mol = rng.normal(0.0, 0.5, (int(s.resid.max()) + 1, 3))          # a different drift for every molecule: every COM velocity changes
+        ctx.setVelocities(v + per_mol[s.resid])
+        ctx.step(2)
+        out.append((ctx.getPositions(), ctx.getVelocities()))
+        ctx.close()
+    (p0, v0), (p1, v1) = out
+    assert rel_err(p1, p0) < 1e-12 and rel_err(v1, v0) < 1e-11, (rel_err(p1, p0), rel_err(v1, v0))
+
+
 def test_sharded_gather_path_with_an_allreduce_hook():
     """Two handles own the two halves of the molecules of a 40-group box (more than 34 thermostats: the gather path's own row sum
     and chain), each hook adds the other's kinetic-energy sums (what RCCL does across GPUs; the pattern of
