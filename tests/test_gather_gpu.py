@@ -136,9 +136,11 @@ def test_kinetic_energy_queries_on_the_gather_path():
 
 def test_velocities_written_between_a_kinetic_energy_query_and_a_step():
     """The gather path's rescale launches reuse the centre-of-mass table of the kinetic-energy pass before them (run_gather,
-    tgnh_host.cpp) -- only inside one entry point: a query's table must not outlive velocities the caller writes after it.  The
-    same calls on a tiled handle of the same system (TGNH mode, COM group on, molecules of different composition so that a
-    stale table would show in the first rescale)."""
+    tgnh_host.cpp) -- inside one entry point only: a query's table must not outlive velocities the caller writes after it.
+    Today every rescale of this path follows a kinetic-energy pass inside the same entry point (the flags that would part them
+    are ignored), so no sequence of calls reaches a stale table even without entry()'s clearing of the mark (checked once with a
+    build that lacked it: this test passed there too); it pins the sequence that a change to that rule would break first.  The
+    same calls on a tiled handle of the same system (TGNH mode, COM group on, a different drift added to every molecule)."""
     out = []
     for flags in (0, FLAG_GATHER):
         s, g, ng = synth.mixed(200, 15)
