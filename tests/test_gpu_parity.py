@@ -12,7 +12,7 @@ import pytest
 
 from openmm_drudenose_amd import synth, _lib
 from openmm_drudenose_amd.drudetgnhplugin import (DrudeTGNHIntegrator, HipContext, TgnhError,
-                                                   FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES, FLAG_TRUST_STATE_CHANGED)
+                                                   FLAG_DEFER_SCALE, FLAG_RESIDENT_STEP, FLAG_WAVE_TILES, FLAG_TRUST_STATE_CHANGED, FLAG_GATHER)
 from helpers import make_oracle, oracle_run, rel_err, to_internal
 
 pytestmark = pytest.mark.gpu
@@ -1817,6 +1817,8 @@ RESIDENT_DEFER = FLAG_DEFER_SCALE | FLAG_RESIDENT_STEP
     ("TGNH", FLAG_RESIDENT_STEP, "mixed"),   # ... with each thermostat half one step_kernel launch
     ("TGNH", FLAG_TRUST_STATE_CHANGED, "mixed"),                        # ... without the begin half's KE pass (bench.py's plain-trust leg)
     ("TGNH", FLAG_TRUST_STATE_CHANGED | FLAG_RESIDENT_STEP, "mixed"),   # ... and the end half as one launch (plain-resident-trust)
+    ("TGNH", FLAG_GATHER, "mixed"),          # the gather path (tgnh_gather.hip) at the metric size: bench.py's plain-gather variant
+    ("dualNH", FLAG_GATHER, "mixed"),
 ])
 def test_full_size_steps_against_the_oracle(mode, flags, precision):
     """The metric configuration itself against the oracle directly, through every launch structure bench.py times: a few steps
@@ -1829,6 +1831,7 @@ def test_full_size_steps_against_the_oracle(mode, flags, precision):
         bind_groups_array(it, g, ng)
     ctx = HipContext(s, it, mode=mode, precision=precision, flags=flags)
     assert np.array_equal(ctx.sites(), x0)
+    assert ctx.step_path()[0] == ("gather" if flags & FLAG_GATHER else "tiled")
     ctx.timing(True)
     ctx.step(3)
     ep, ev = rel_err(ctx.getPositions(), pos_o), rel_err(ctx.getVelocities(), vel_o)
