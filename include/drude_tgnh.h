@@ -104,7 +104,7 @@ typedef struct tgnh_desc {
     uint32_t struct_size;         /* sizeof(tgnh_desc), ABI check */
     int32_t mode;                 /* TGNH_MODE_* */
     int32_t precision;            /* TGNH_PREC_* */
-    int32_t flags;                /* TGNH_FLAG_* */
+    int32_t flags;                /* TGNH_FLAG_* ; any other bit: TGNH_ERR_ARG (a binding built against a newer header) */
     int32_t device;               /* HIP device ordinal; -1 = host-only handle (topology, tiles, dof queries; no launches) */
     int32_t num_particles;        /* N: particle slots owned by this handle */
     int32_t padded_num_particles; /* stride of the 3 force planes (OpenMM PADDED_NUM_ATOMS), >= N */

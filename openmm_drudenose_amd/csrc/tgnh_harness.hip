@@ -309,7 +309,7 @@ extern "C" tgnh_status tgnh_harness_set_clusters(tgnh_handle h, int n, const int
     if (!h) H_FAIL(TGNH_ERR_ARG, "null handle");
     if (h->host_only) H_FAIL(TGNH_ERR_STATE, "host-only handle");
     if (n < 0 || (n > 0 && (!atoms || !dist))) H_FAIL(TGNH_ERR_ARG, "bad cluster arrays");
-    for (int i = 0; i < 4 * n; i++)
+    for (long long i = 0; i < 4LL * n; i++)
         if (atoms[i] < -1 || atoms[i] >= h->d.num_particles) H_FAIL(TGNH_ERR_ARG, "cluster atom index out of range");
     H_HIP(hipSetDevice(h->device));
     if (h->d_cl_atoms) { (void)hipFree(h->d_cl_atoms); h->d_cl_atoms = nullptr; }
@@ -353,7 +353,7 @@ extern "C" tgnh_status tgnh_harness_set_virtual_sites(tgnh_handle h, int n, cons
     if (!h) H_FAIL(TGNH_ERR_ARG, "null handle");
     if (h->host_only) H_FAIL(TGNH_ERR_STATE, "host-only handle");
     if (n < 0 || (n > 0 && (!atoms || !weights))) H_FAIL(TGNH_ERR_ARG, "bad virtual-site arrays");
-    for (int i = 0; i < 4 * n; i++)
+    for (long long i = 0; i < 4LL * n; i++)
         if (atoms[i] < 0 || atoms[i] >= h->d.num_particles) H_FAIL(TGNH_ERR_ARG, "virtual-site atom index out of range");
     H_HIP(hipSetDevice(h->device));
     if (h->d_vs_atoms) { (void)hipFree(h->d_vs_atoms); h->d_vs_atoms = nullptr; }

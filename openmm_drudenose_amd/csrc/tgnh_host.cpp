@@ -224,7 +224,9 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
     if (com) {
         for (int r : res_order) {
             if (is_big[r]) continue;
-            const int lo = c->res_first[r], hi = lo + c->res_count[r] - 1;
+            // (a residue in several runs -- the gather path, decided above -- has its `count` particles counted from the start of its
+            // LAST run: that walk may leave the array; found by tests/test_desc_fuzz.py as a write behind `forbid`)
+            const int lo = c->res_first[r], hi = std::min(lo + c->res_count[r] - 1, N - 1);
             forbid[lo + 1] += 1; forbid[hi + 1] -= 1;
         }
     }
@@ -651,10 +653,12 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     if (d->num_nh_chains < 1 || d->drude_steps_per_real_step < 1) return fail(TGNH_ERR_ARG, "numNHChains and drudeStepsPerRealStep must be >= 1");
     if (d->mode == TGNH_MODE_TGNH && (d->num_groups < 1 || d->num_residues < 1 || !d->group || !d->resid))
         return fail(TGNH_ERR_ARG, "TGNH mode needs temperature groups and residues");
-    if (d->max_drude_distance < 0) return fail(TGNH_ERR_ARG, "setMaxDrudeDistance: Distance cannot be negative");   // API :98-99
+    if (!(d->max_drude_distance >= 0)) return fail(TGNH_ERR_ARG, "setMaxDrudeDistance: Distance cannot be negative");   // API :98-99 (NaN neither)
+    if (d->flags & ~(uint32_t)(TGNH_FLAG_DEFER_SCALE | TGNH_FLAG_RESIDENT_STEP | TGNH_FLAG_WAVE_TILES | TGNH_FLAG_TRUST_STATE_CHANGED | TGNH_FLAG_GATHER))
+        return fail(TGNH_ERR_ARG, "unknown bits in tgnh_desc.flags (a newer header than this library?)");
     if (d->mode == TGNH_MODE_DUALNH && d->num_pairs == 0)   // Ref :181 reads pairParticles[0]; its chain divides by the Drude thermostat mass 0
         return fail(TGNH_ERR_UNSUPPORTED, "dualNH mode needs at least one Drude pair (the Reference platform does too)");
-    if (d->step_size <= 0) return fail(TGNH_ERR_ARG, "step size must be positive");
+    if (!(d->step_size > 0) || !std::isfinite(d->step_size)) return fail(TGNH_ERR_ARG, "step size must be positive");
     bool long_chain = false;
     {   // the chain kernel keeps chains longer than 4 links (16 in TGNH mode: chain_long_kernel) in a 2048-double LDS scratch; what
         // does not fit runs a thermostat per thread with its links in global memory (gather_chain_kernel, TGNH mode)
@@ -710,14 +714,12 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
         // molecule is scaled by two different factors, which moves its centre of mass (K :260-300)
         bool inside = true;
         if (d->mode == TGNH_MODE_TGNH && d->use_com_temp_group) {
-            for (int r = 0; r < d->num_residues && inside; r++) {
-                int g0 = -1;
-                for (int j = 0; j < c->res_count[r]; j++) {
-                    const int i = c->res_first[r] + j;
-                    if (c->mass[i] == 0.0) continue;
-                    if (g0 == -1) g0 = c->group[i];
-                    else if (g0 != c->group[i]) { inside = false; break; }
-                }
+            std::vector<int> g0(d->num_residues, -1);      // (by particle, not by (first, count): a residue may come in several runs)
+            for (int i = 0; i < d->num_particles && inside; i++) {
+                if (c->mass[i] == 0.0) continue;
+                int& g = g0[c->resid[i]];
+                if (g == -1) g = c->group[i];
+                else if (g != c->group[i]) inside = false;
             }
         }
         if ((c->d.flags & TGNH_FLAG_DEFER_SCALE) && !inside) { free_device(c); delete c; return fail(TGNH_ERR_UNSUPPORTED, "DEFER_SCALE needs every molecule inside one temperature group"); }
@@ -910,7 +912,7 @@ static tgnh_status deferred_guard(tgnh_handle h, const char* what) {
 
 extern "C" tgnh_status tgnh_set_step_size(tgnh_handle h, double dt) {
     CHECK_H(h);
-    if (dt <= 0) return fail(TGNH_ERR_ARG, "step size must be positive");
+    if (!(dt > 0) || !std::isfinite(dt)) return fail(TGNH_ERR_ARG, "step size must be positive");
     if (dt != h->d.step_size) { tgnh_status rc = deferred_guard(h, "tgnh_set_step_size"); if (rc) return rc; }
     h->d.step_size = dt;
     return TGNH_OK;
@@ -924,7 +926,7 @@ extern "C" tgnh_status tgnh_set_drude_steps_per_real_step(tgnh_handle h, int n) 
 }
 extern "C" tgnh_status tgnh_set_max_drude_distance(tgnh_handle h, double dist) {
     CHECK_H(h);
-    if (dist < 0) return fail(TGNH_ERR_ARG, "setMaxDrudeDistance: Distance cannot be negative");   // API :98-99
+    if (!(dist >= 0)) return fail(TGNH_ERR_ARG, "setMaxDrudeDistance: Distance cannot be negative");   // API :98-99 (NaN neither)
     h->d.max_drude_distance = dist;
     return TGNH_OK;
 }
@@ -1902,6 +1904,7 @@ extern "C" tgnh_status tgnh_state_changed(tgnh_handle h) {
 // queries
 // ---------------------------------------------------------------------------
 static tgnh_status read_state(tgnh_handle h, int off, int n, hipStream_t s, double* out) {
+    if (!out) return fail(TGNH_ERR_ARG, "null out");
     if (h->host_only) { std::copy(h->h_state.begin() + off, h->h_state.begin() + off + n, out); return TGNH_OK; }
     { tgnh_status rc = entry(h, false); if (rc) return rc; }
     { tgnh_status rc = materialize_chain(h, s); if (rc) return rc; }
@@ -1979,6 +1982,7 @@ static bool chain_section(tgnh_handle h, int which, int* off, int* len) {
 extern "C" tgnh_status tgnh_get_thermostat_len(tgnh_handle h, int which, int* len) {
     CHECK_H(h);
     int off;
+    if (!len) return fail(TGNH_ERR_ARG, "null out");
     if (!chain_section(h, which, &off, len)) return fail(TGNH_ERR_ARG, "bad thermostat array id");
     return TGNH_OK;
 }
@@ -1992,6 +1996,7 @@ extern "C" tgnh_status tgnh_set_thermostat_state(tgnh_handle h, int which, void*
     CHECK_H(h);
     int off, len;
     if (!chain_section(h, which, &off, &len)) return fail(TGNH_ERR_ARG, "bad thermostat array id");
+    if (!in) return fail(TGNH_ERR_ARG, "null in");
     tgnh_status rc = deferred_guard(h, "tgnh_set_thermostat_state"); if (rc) return rc;
     h->ke_carry = false;
     if (h->host_only) { std::copy(in, in + len, h->h_state.begin() + off); return TGNH_OK; }
@@ -2020,6 +2025,7 @@ static const std::vector<int>* topo_vec(tgnh_handle h, int which) {
 }
 extern "C" tgnh_status tgnh_get_topology_len(tgnh_handle h, int which, int* len) {
     CHECK_H(h);
+    if (!len) return fail(TGNH_ERR_ARG, "null out");
     if (which == 8) { *len = (int)h->meta.size(); return TGNH_OK; }
     if (which == 9) { *len = 2 * (int)h->wave_tile.size(); return TGNH_OK; }      // wave tiles: (first slot, largest molecule) pairs, one more than tiles; 0 = none
     if (which == 10) { *len = (int)h->wmeta.size(); return TGNH_OK; }
@@ -2034,6 +2040,7 @@ extern "C" tgnh_status tgnh_get_topology_len(tgnh_handle h, int which, int* len)
 }
 extern "C" tgnh_status tgnh_get_topology(tgnh_handle h, int which, int32_t* out) {
     CHECK_H(h);
+    if (!out) return fail(TGNH_ERR_ARG, "null out");
     auto put = [&](const void* src, size_t bytes) { if (bytes) std::memcpy(out, src, bytes); return TGNH_OK; };     // (an empty array has no data())
     if (which == 8) return put(h->meta.data(), sizeof(uint32_t) * h->meta.size());
     if (which == 9) return put(h->wave_tile.data(), sizeof(int2) * h->wave_tile.size());
@@ -2256,6 +2263,7 @@ extern "C" tgnh_status tgnh_timing_read(tgnh_handle h, int kernel, double* total
 }
 extern "C" tgnh_status tgnh_algorithmic_bytes(tgnh_handle h, int kernel, double* bytes) {
     CHECK_H(h);
+    if (!bytes) return fail(TGNH_ERR_ARG, "null out");
     // state arrays only.  V = velocity vec4, F = 3 x int64, X = position (+correction) per direction.
     const double N = h->d.num_particles;
     const double V = h->d.precision == TGNH_PREC_SINGLE ? 16 : 32;

@@ -160,6 +160,33 @@ def test_velocities_written_between_a_kinetic_energy_query_and_a_step():
     assert rel_err(p1, p0) < 1e-12 and rel_err(v1, v0) < 1e-11, (rel_err(p1, p0), rel_err(v1, v0))
 
 
+def test_residues_scattered_all_over_the_array_stay_inside_it():
+    """A residue array in random order (every residue in many runs): the reference's table then says (count, start of the LAST run)
+    and its COM kernel walks `count` particles from there (K :90-91) -- behind the end of the arrays for the residues whose last
+    run lies near it: undefined in the reference and in the oracle alike, so there is no trajectory to compare.  The library's walk
+    stops at the array's end (gather_com_kernel), tgnh_create's tile bookkeeping too (found by tests/test_desc_fuzz.py): the handle
+    steps, everything stays finite, the same launches give the same bits twice."""
+    out = []
+    for rep in range(2):
+        s, g, ng = synth.mixed(120, 10)
+        rng = np.random.default_rng(11)
+        resid = s.resid.copy()
+        rng.shuffle(resid)
+        s2 = type(s)(mass=s.mass, pair_drude=s.pair_drude, pair_parent=s.pair_parent, resid=resid, positions=s.positions,
+                     velocities=s.velocities)
+        it = integ(chains=2, hardwall=0.02)
+        bind_groups(it, np.zeros_like(g), 1)                    # (one group: a Drude particle and its parent must share theirs, Ref :128-131)
+        ctx = HipContext(s2, it, mode="TGNH", precision="mixed")
+        assert ctx.step_path() == ("gather", "particles of a residue are not contiguous")
+        ctx.step(10)
+        pos, vel = ctx.getPositions(), ctx.getVelocities()
+        assert np.isfinite(pos).all() and np.isfinite(vel).all() and np.isfinite(ctx.compute_kinetic_energies()).all()
+        assert ctx.status_flags() & ~1 == 0
+        out.append((pos, vel))
+        ctx.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_sharded_gather_path_with_an_allreduce_hook():
     """Two handles own the two halves of the molecules of a 40-group box (more than 34 thermostats: the gather path's own row sum
     and chain), each hook adds the other's kinetic-energy sums (what RCCL does across GPUs; the pattern of
