@@ -107,7 +107,7 @@ typedef struct tgnh_desc {
     int32_t flags;                /* TGNH_FLAG_* ; any other bit: TGNH_ERR_ARG (a binding built against a newer header) */
     int32_t device;               /* HIP device ordinal; -1 = host-only handle (topology, tiles, dof queries; no launches) */
     int32_t num_particles;        /* N: particle slots owned by this handle */
-    int32_t padded_num_particles; /* stride of the 3 force planes (OpenMM PADDED_NUM_ATOMS), >= N */
+    int32_t padded_num_particles; /* stride of the 3 force planes (OpenMM PADDED_NUM_ATOMS), >= N and <= 715 827 882 (3 x stride in 32-bit indices, as K :318-320) */
     int32_t num_pairs;            /* P: Drude pairs, DrudeForce order */
     int32_t num_groups;           /* G: getNumTempGroups() (TGNH mode) */
     int32_t num_residues;         /* R: getNumResidues()   (TGNH mode) */

@@ -159,9 +159,12 @@ static tgnh_status build_topology(tgnh_context* c, const tgnh_desc* d) {
                 return fail(TGNH_ERR_UNSUPPORTED, "more than " + std::to_string(GATHER_MAX_NT - 2) + " temperature groups (a wavefront's kinetic-energy bins no longer fit the LDS)");
         }
         for (int i = 0; i < d->num_constraints; i++) {                        // Cu :186-193
-            if (!d->constraint_i || !d->constraint_j) break;
-            const int a = d->constraint_i[i], b = d->constraint_j[i];
-            if (a < 0 || a >= N || b < 0 || b >= N) return fail(TGNH_ERR_ARG, "constraint index out of range");
+            if (!d->constraint_i) break;                                       // (no arrays: every constraint counts against group 0, local_dof_terms)
+            const int a = d->constraint_i[i];
+            if (a < 0 || a >= N) return fail(TGNH_ERR_ARG, "constraint index out of range");       // (read again by local_dof_terms)
+            if (!d->constraint_j) continue;
+            const int b = d->constraint_j[i];
+            if (b < 0 || b >= N) return fail(TGNH_ERR_ARG, "constraint index out of range");
             if (c->group[a] != c->group[b])
                 return fail(TGNH_ERR_GROUP_MISMATCH, "Temperature group of constrained particles must be the same");
         }
@@ -650,6 +653,9 @@ extern "C" tgnh_status tgnh_create(const tgnh_desc* d, tgnh_handle* out) {
     if (d->num_particles < 1 || d->num_pairs < 0 || !d->mass || (d->num_pairs && (!d->pair_drude || !d->pair_parent)))
         return fail(TGNH_ERR_ARG, "bad particle / pair arrays");
     if (d->padded_num_particles < d->num_particles) return fail(TGNH_ERR_ARG, "padded_num_particles < num_particles");
+    if (d->num_constraints < 0) return fail(TGNH_ERR_ARG, "negative num_constraints");
+    if (3LL * d->padded_num_particles > 2147483647LL)      // force[i + 2 paddedN] in 32-bit indices, here as in the reference's kernels (K :318-320)
+        return fail(TGNH_ERR_UNSUPPORTED, "more than 715 827 882 padded particle slots: the index into the third force plane leaves 32 bits");
     if (d->num_nh_chains < 1 || d->drude_steps_per_real_step < 1) return fail(TGNH_ERR_ARG, "numNHChains and drudeStepsPerRealStep must be >= 1");
     if (d->mode == TGNH_MODE_TGNH && (d->num_groups < 1 || d->num_residues < 1 || !d->group || !d->resid))
         return fail(TGNH_ERR_ARG, "TGNH mode needs temperature groups and residues");

@@ -43,13 +43,15 @@ def point(d, a):
     d.resid = a["resid"].ctypes.data_as(_lib.c_i32p)
     d.constraint_i = a["ci"].ctypes.data_as(_lib.c_i32p) if len(a["ci"]) else None
     d.constraint_j = a["cj"].ctypes.data_as(_lib.c_i32p) if len(a["cj"]) else None
+    for name in a.get("null", ()):
+        setattr(d, name, None)
 
 
 def mutate(d, a, rng):
     """one to three random corruptions; returns their names"""
     n, done = d.num_particles, []
     for _ in range(int(rng.integers(1, 4))):
-        m = int(rng.integers(0, 22))
+        m = int(rng.integers(0, 24))
         done.append(m)
         idx = lambda arr: int(rng.integers(0, max(len(arr), 1)))          # noqa: E731
         if m == 0 and len(a["pd"]):
@@ -83,7 +85,7 @@ def mutate(d, a, rng):
         elif m == 14:
             d.max_drude_distance = float(rng.choice([-0.01, np.nan, np.inf, 1e-30]))
         elif m == 15:
-            d.padded_num_particles = int(rng.choice([0, n - 1, -32]))
+            d.padded_num_particles = int(rng.choice([0, n - 1, -32, 715_827_883, 2**31 - 1]))
         elif m == 16 and len(a["ci"]):
             a["ci"][idx(a["ci"])] = int(rng.choice([-1, n, 2**31 - 1]))
         elif m == 17:
@@ -98,6 +100,11 @@ def mutate(d, a, rng):
                     setattr(d, name, float(rng.choice([0.0, -1.0, np.nan, np.inf])))
         elif m == 21:
             d.mode = _lib.MODE_DUALNH                                  # (valid: the other semantic mode over the same arrays)
+        elif m == 22:
+            a["null"] = a.get("null", ()) + (str(rng.choice(["group", "resid", "mass", "pair_drude", "constraint_i"])),)   # a null array pointer (legal for group / resid in dualNH mode)
+        elif m == 23:
+            d.mode = _lib.MODE_DUALNH
+            a["null"] = a.get("null", ()) + ("group", "resid")
     return done
 
 
