@@ -72,7 +72,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < P; i++) { drude.shimDrude.push_back(pairs[2 * i]); drude.shimParent.push_back(pairs[2 * i + 1]); }
     CMMotionRemover cmm;
     sys.shimForces.push_back(&drude);
-    if (perturb) sys.shimForces.push_back(&cmm);
+    if (perturb == 1) sys.shimForces.push_back(&cmm);               // (perturb == 2: the same change of the velocities, made by a USER between steps -- Context::setVelocities -> stateChanged -- with no such Force in the System)
     std::unique_ptr<DrudeTGNHIntegrator> integ(new DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, dt, 20, chains, useDrudeChains != 0, useCOM != 0));
     integ->setMaxDrudeDistance(hardwall);
     integ->setConstraintTolerance(tol);
@@ -195,6 +195,8 @@ int main(int argc, char** argv) {
             double p[3] = {0, 0, 0}, m = 0;
             for (int i = 0; i < N; i++) if (mass[i] > 0) { for (int k = 0; k < 3; k++) p[k] += mass[i] * velm[4 * i + k]; m += mass[i]; }
             for (int i = 0; i < N; i++) if (mass[i] > 0) for (int k = 0; k < 3; k++) velm[4 * i + k] -= p[k] / m;
+            if (perturb == 2)                                          // the USER's change: every velocity 3 % smaller (6 % of every kinetic energy: a stale sum shows)
+                for (int i = 0; i < N; i++) for (int k = 0; k < 3; k++) velm[4 * i + k] *= 0.97;
             HIPCHK(hipMemcpy(d_velm, velm.data(), 32 * N, hipMemcpyHostToDevice));
             integ->shimKEValid = false;
         }

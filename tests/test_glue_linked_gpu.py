@@ -99,6 +99,33 @@ def test_the_linked_glue_split_sequence_with_call_outs_and_state_changes(exes, t
     assert np.allclose(eta_dot, o.chain(1), rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("flags", [_lib.FLAG_TRUST_STATE_CHANGED, _lib.FLAG_TRUST_STATE_CHANGED | _lib.FLAG_RESIDENT_STEP, 0])
+def test_a_trusting_build_hears_of_velocities_the_user_sets(exes, tmp_path, flags):
+    """-DDRUDETGNH_TRUST_STATE_CHANGED with a System of velocity-neutral forces only (a DrudeForce): the glue takes the flag, the begin
+    half starts from the carried sums -- and when the user writes velocities between steps (Context::setVelocities -> stateChanged ->
+    isKineticEnergySumValid() false) execute() must forward it (tgnh_state_changed), or the next chain runs on a stale sum (1e-3).
+    Against the oracle with the same change of the velocities before every step."""
+    s, g, ng = synth.nacl()
+    nsteps = 30
+    pos, vel, eta_dot, ke = run_linked(exes[flags], tmp_path, s, g, ng, nsteps, 2, 1, True, True, 0.001, 0.02, 1e-5, "double", flags)
+    it = DrudeTGNHIntegrator(300.0, 0.1, 1.0, 0.005, 0.001, 20, 1, True, True)
+    it.setMaxDrudeDistance(0.02)
+    o = make_oracle(s, g, ng, "TGNH", it)
+    x0 = s.positions.copy()
+    po, vo = s.positions.copy(), s.velocities.copy()
+    m = s.mass
+    massive = m > 0
+    f = o.harness_force(po, x0, synth.K_DRUDE, synth.K_TETHER)
+    for _ in range(nsteps):
+        vo[massive] -= (m[massive, None] * vo[massive]).sum(0) / m[massive].sum()
+        vo *= 0.97                                               # (6 % of every kinetic energy: without the forwarding the velocities end 1e-3 off, checked once)
+        o.run_harness(po, vo, f, x0, synth.K_DRUDE, synth.K_TETHER, 1)
+    ep, ev = rel_err(pos, po), rel_err(vel, vo)
+    print(f"linked glue, user-set velocities, variant {flags}: pos {ep:.2e} vel {ev:.2e}")
+    assert ep <= 1e-6 and ev <= 1e-6
+    assert np.allclose(eta_dot, o.chain(1), rtol=1e-6, atol=1e-9)
+
+
 @pytest.mark.parametrize("flags", [0, _lib.FLAG_RESIDENT_STEP])      # (a TRUST build recomputes the sums on the first step of a new integrator -- its
 @pytest.mark.parametrize("name", ["nacl", "rigid water"])              # isKineticEnergySumValid() starts false, as the API's -- where the old one carried them: equal to rounding only)
 def test_checkpoint_through_the_xml_proxy_continues_bit_for_bit(exes, tmp_path, name, flags):
