@@ -4,8 +4,11 @@ The XML carries the nine properties of the reference's proxy under the same name
 (serialization/src/DrudeTGNHIntegratorProxy.cpp:43-55), in the shape OpenMM's XmlSerializer gives a
 root node (`<Integrator type="DrudeTGNHIntegrator" version="1" .../>`), so files are interchangeable.
 What the reference's proxy drops (maxDrudeDistance, useCOMTempGroup, temperature groups)
-is written as extra attributes / children that an older reader ignores.  The thermostat variables
-(eta, etaDot, etaDotDot), which the reference cannot checkpoint at all, go into a plain dict.
+is written as extra attributes / children that an older reader ignores, and so are the thermostat
+variables (eta, etaDot, etaDotDot) and the clock, which the reference cannot checkpoint at all -- all in
+the node shapes of the plugin tree's C++ proxy (csrc/openmm_glue/serialization/src/DrudeTGNHIntegratorProxy.cpp:
+`<TempGroups count><Particle group/>...`, `<ThermostatState time stepCount><eta><Value v/>...`), so a file
+written by either is read by the other (tests/test_glue_linked_gpu.py feeds the C++ proxy's output to this reader).
 """
 import xml.etree.ElementTree as ET
 
@@ -21,7 +24,8 @@ _INTS = [("drudeStepsPerRealStep", "getDrudeStepsPerRealStep"), ("numNHChains", 
          ("useDrudeNHChains", "getUseDrudeNHChains")]
 
 
-def serialize(integrator, root_name="Integrator"):
+def serialize(integrator, root_name="Integrator", thermostat=None):
+    """thermostat: a dict as save_thermostat() returns -> a ThermostatState child (eta, etaDot, etaDotDot, time, stepCount)"""
     node = ET.Element(root_name, {"type": "DrudeTGNHIntegrator", "version": "1"})
     for name, getter in _DOUBLES:
         node.set(name, repr(float(getattr(integrator, getter)())))
@@ -30,13 +34,21 @@ def serialize(integrator, root_name="Integrator"):
     # extensions (ignored by the reference's version-1 reader)
     node.set("maxDrudeDistance", repr(float(integrator.getMaxDrudeDistance())))
     node.set("useCOMTempGroup", str(int(integrator.getUseCOMTempGroup())))
-    if integrator._particleTempGroup:
+    if integrator.getNumTempGroups() > 0:
         g = ET.SubElement(node, "TempGroups", {"count": str(integrator.getNumTempGroups())})
-        g.text = " ".join(str(x) for x in integrator._particleTempGroup)
+        for x in integrator._particleTempGroup:
+            ET.SubElement(g, "Particle", {"group": str(int(x))})
+    if thermostat is not None:
+        t = ET.SubElement(node, "ThermostatState", {"time": repr(float(thermostat["time"])), "stepCount": str(int(thermostat["stepCount"]))})
+        for key in ("eta", "etaDot", "etaDotDot"):
+            a = ET.SubElement(t, key)
+            for v in np.asarray(thermostat[key], np.float64):
+                ET.SubElement(a, "Value", {"v": repr(float(v))})
     return ET.tostring(node, encoding="unicode")
 
 
-def deserialize(text):
+def deserialize(text, with_thermostat=False):
+    """-> the integrator; with_thermostat: (integrator, dict or None) -- the ThermostatState child as load_thermostat() takes it"""
     node = ET.fromstring(text)
     if node.get("type") != "DrudeTGNHIntegrator":
         raise TgnhError(_lib.ERR_ARG, "not a DrudeTGNHIntegrator node")
@@ -55,9 +67,20 @@ def deserialize(text):
     if g is not None:
         for _ in range(int(g.get("count"))):
             it.addTempGroup()
-        for x in (g.text or "").split():
+        for x in (g.text or "").split():                         # (files written before round 5 held the table as text)
             it.addParticleTempGroup(int(x))
-    return it
+        for p in g.findall("Particle"):
+            it.addParticleTempGroup(int(p.get("group")))
+    if not with_thermostat:
+        return it
+    t = node.find("ThermostatState")
+    state = None
+    if t is not None:
+        state = {"time": float(t.get("time")), "stepCount": int(t.get("stepCount"))}
+        for key in ("eta", "etaDot", "etaDotDot"):
+            a = t.find(key)
+            state[key] = np.array([float(v.get("v")) for v in a.findall("Value")]) if a is not None else np.zeros(0)
+    return it, state
 
 
 def save_thermostat(ctx):

@@ -33,6 +33,17 @@ using namespace OpenMM;
 #define HIPCHK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { std::printf("HIP error %s at %s:%d\n", hipGetErrorString(r_), __FILE__, __LINE__); return 2; } } while (0)
 #define TG(e) do { if ((e) != TGNH_OK) { std::printf("tgnh error: %s (%s:%d)\n", tgnh_last_error(), __FILE__, __LINE__); return 3; } } while (0)
 
+// the node tree as OpenMM's XmlSerializer would write it: <Name prop="value" ...> children </Name>, the root with the proxy's type name
+static void dumpXml(FILE* f, const SerializationNode& n, const std::string& name, const std::string& type, int depth) {
+    std::fprintf(f, "%*s<%s", 2 * depth, "", name.c_str());
+    if (!type.empty()) std::fprintf(f, " type=\"%s\"", type.c_str());
+    for (const auto& p : n.shimProperties) std::fprintf(f, " %s=\"%s\"", p.first.c_str(), p.second.c_str());
+    if (n.getChildren().empty()) { std::fprintf(f, "/>\n"); return; }
+    std::fprintf(f, ">\n");
+    for (const SerializationNode& c : n.getChildren()) dumpXml(f, c, c.getName(), "", depth + 1);
+    std::fprintf(f, "%*s</%s>\n", 2 * depth, "", name.c_str());
+}
+
 template <class T> static std::vector<T> slurp(const char* path) {
     std::vector<T> v;
     FILE* f = std::fopen(path, "rb");
@@ -178,6 +189,10 @@ int main(int argc, char** argv) {
                 bool has = false;
                 for (const SerializationNode& c : node.getChildren()) has = has || c.getName() == "ThermostatState";
                 if (!has) { std::printf("no ThermostatState in the node\n"); return 9; }
+                if (FILE* xf = std::fopen((std::string(argv[3]) + ".xml").c_str(), "w")) {       // for the Python reader (openmm_drudenose_amd/serialization.py)
+                    dumpXml(xf, node, "Integrator", proxy->shimTypeName, 0);
+                    std::fclose(xf);
+                }
                 DrudeTGNHIntegrator* fresh = reinterpret_cast<DrudeTGNHIntegrator*>(proxy->deserialize(node));
                 kernel.reset();
                 integ.reset(fresh);

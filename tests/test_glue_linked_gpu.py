@@ -143,6 +143,20 @@ def test_checkpoint_through_the_xml_proxy_continues_bit_for_bit(exes, tmp_path, 
     parts = run_linked(exes[flags], tmp_path / "b", *args, split_at=17)
     for a, b in zip(whole, parts):
         assert np.array_equal(np.asarray(a), np.asarray(b))
+    # what the C++ proxy wrote at step 17, read by the Python reader of the same format (openmm_drudenose_amd/serialization.py)
+    from openmm_drudenose_amd import serialization
+    it, state = serialization.deserialize(open(tmp_path / "b" / "out.bin.xml").read(), with_thermostat=True)
+    assert (it.getStepSize(), it.getMaxDrudeDistance(), it.getNumNHChains(), it.getUseDrudeNHChains(), it.getUseCOMTempGroup()) == (0.001, 0.02, args[5], 1, 1)
+    assert it.getConstraintTolerance() == args[10] and it.getNumTempGroups() == ng
+    assert [it.getParticleTempGroup(i) for i in range(s.num_particles)] == [int(x) for x in g]
+    assert state["stepCount"] == 17 and state["time"] == pytest.approx(17 * 0.001, rel=1e-12)
+    assert len(state["etaDot"]) == len(whole[2]) and len(state["eta"]) == len(state["etaDotDot"]) > 0 and np.isfinite(state["etaDot"]).all()   # (etaDot: one more entry per thermostat, Cu :229-231)
+    # ... and written again by the Python writer: the same tree
+    import xml.etree.ElementTree as ET
+    again = ET.fromstring(serialization.serialize(it, thermostat=state))
+    first = ET.fromstring(open(tmp_path / "b" / "out.bin.xml").read())
+    flat = lambda e: [(x.tag, sorted((k, v if k in ("type", "stepCount", "count", "group") else float(v)) for k, v in x.attrib.items())) for x in e.iter()]   # noqa: E731
+    assert flat(again) == flat(first)
 
 
 def test_the_mirror_is_the_glue(exes, tmp_path):
