@@ -32,6 +32,7 @@ CASES = {
     "groups33": lambda: synth.many_groups(300, 20, 33),          # one more than the tiled kernels' bins hold
     "groups40": lambda: synth.many_groups(300, 20, 40),          # more than chain_kernel's 34 thermostats: gather_rowsum / gather_chain
     "groups300": lambda: synth.many_groups(400, 20, 300),
+    "groups2046": lambda: synth.many_groups(2100, 60, 2046),      # the most the kinetic-energy kernel's per-wavefront bins hold (64 KiB of LDS); 2047: refused
     "drudes-at-the-end": lambda: drudes_at_the_end(300),          # (COM group off in TGNH mode: with it the reference's walk of `count`
                                                                   # particles from a residue's last run leaves the array for the last residues)
     "interleaved": interleaved,
@@ -185,6 +186,15 @@ def test_residues_scattered_all_over_the_array_stay_inside_it():
         out.append((pos, vel))
         ctx.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_more_groups_than_the_bins_hold_are_refused():
+    s, g, ng = synth.many_groups(2100, 60, 2047)
+    it = integ()
+    bind_groups(it, g, ng)
+    with pytest.raises(TgnhError) as e:
+        HipContext(s, it, mode="TGNH", precision="double")
+    assert e.value.status == _lib.ERR_UNSUPPORTED and "2046 temperature groups" in str(e.value)
 
 
 def test_sharded_gather_path_with_an_allreduce_hook():
