@@ -41,7 +41,9 @@ enum {
     TGNH_ERR_ARG = -1,            /* bad argument / size */
     TGNH_ERR_GROUP_MISMATCH = -2, /* CudaDrudeTGNHKernels.cpp:145-146, :192-193 */
     TGNH_ERR_HARDWALL = -3,       /* ReferenceDrudeTGNHKernels.cpp:311-312 */
-    TGNH_ERR_UNSUPPORTED = -4,    /* topology the fused tile path cannot hold */
+    TGNH_ERR_UNSUPPORTED = -4,    /* what the reference itself cannot run (a massless pair member, a molecule without mass under the COM group,
+                                     dualNH without a pair), sizes beyond an index's or a bin's reach, a flag the topology cannot take;
+                                     NOT a topology the tiles cannot hold: that steps on the gather path (tgnh_get_step_path) */
     TGNH_ERR_HIP = -5,            /* a HIP runtime call failed */
     TGNH_ERR_STATE = -6           /* call order (buffers not bound, ...) */
 };

@@ -67,9 +67,11 @@ static tgnh_status settle_end(tgnh_handle h, hipStream_t s);
 static bool resident_now(tgnh_handle h);
 
 // ---------------------------------------------------------------------------
-// A1 for the gather path (tgnh_gather.hip): the reference's own index lists -- normalParticles, pairParticles (Ref :113-137,
-// Cu :111-151), particleTempGroup, particleResId, particlesInResidues (Cu :114-125) -- and nothing else: no tiles, no per-slot
-// words.  Taken by build_topology for what the tiles cannot hold (c->generic_reason says what).
+// A1 for the gather path (tgnh_gather.hip): the reference's index lists -- normalParticles, pairParticles (Ref :113-137,
+// Cu :111-151), particleTempGroup, particleResId, particlesInResidues (Cu :114-125) -- turned per-particle (every particle's pair
+// partner | is-Drude << 31, or -1; its group; its residue's index) so that the kernels walk the arrays once, in index order, plus
+// the residue table (count, first) and nothing else: no tiles, no per-slot words.  Taken by build_topology for what the tiles
+// cannot hold (c->generic_reason says what).
 // ---------------------------------------------------------------------------
 static tgnh_status build_gather_topology(tgnh_context* c, const std::vector<int>& role, const std::vector<int>& partner,
                                          const std::vector<int>& res_order) {

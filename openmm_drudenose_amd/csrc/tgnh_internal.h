@@ -333,7 +333,7 @@ struct tgnh_context {
     std::vector<int2> res_entries;    // per-tile molecule entries
     std::vector<int> big_first, big_count;   // molecules longer than a tile (COM from big_com_kernel)
     int num_big = 0;
-    // the gather path: taken when the tiles cannot hold the topology (generic_reason says why); the reference's own index lists
+    // the gather path: taken when the tiles cannot hold the topology (generic_reason says why); the reference's index lists, per particle
     bool generic = false;
     bool gather_chain = false;        // ... and its chain too: more than 34 thermostats, or links that do not fit the LDS (gather_chain_kernel)
     std::string generic_reason;
