@@ -50,36 +50,36 @@ public:
                         double stepSize, int drudeStepsPerRealStep = 20, int numNHChains = 1,
                         int useDrudeNHChains = True, int useCOMTempGroup = True);
 
-    /* thermostat parameters */
-    double getTemperature() const;
-    void setTemperature(double temp);
-    double getCouplingTime() const;
-    void setCouplingTime(double tau);
-    double getDrudeTemperature() const;
-    void setDrudeTemperature(double temp);
-    double getDrudeCouplingTime() const;
-    void setDrudeCouplingTime(double tau);
-    int getDrudeStepsPerRealStep() const;
-    void setDrudeStepsPerRealStep(int drudeSteps);
-    int getNumNHChains() const;
-    void setNumNHChains(int numChains);
-    int getUseDrudeNHChains() const;
-    void setUseDrudeNHChains(int useDrudeNHChains);
-    int getUseCOMTempGroup() const;
-    void setUseCOMTempGroup(int useCOMTempGroup);
-
-    /* hard wall */
-    double getMaxDrudeDistance() const;
-    void setMaxDrudeDistance(double distance);
-
-    /* temperature groups */
-    int getNumTempGroups() const;
+    /* the temperature-group table (user scripts fill it before the Context is made) */
     int addTempGroup();
     int addParticleTempGroup(int tempGroup);
     void setParticleTempGroup(int particle, int tempGroup);
     %apply int& OUTPUT { int& tempGroup };
     void getParticleTempGroup(int particle, int& tempGroup) const;
     %clear int& tempGroup;
+    int getNumTempGroups() const;
+
+    /* what the thermostats are asked for: read ... */
+    double getTemperature() const;
+    double getDrudeTemperature() const;
+    double getCouplingTime() const;
+    double getDrudeCouplingTime() const;
+    double getMaxDrudeDistance() const;
+    int getNumNHChains() const;
+    int getDrudeStepsPerRealStep() const;
+    int getUseDrudeNHChains() const;
+    int getUseCOMTempGroup() const;
+
+    /* ... and write (temperatures in kelvin, times in picoseconds, the hard-wall distance in nanometres; 0 = no wall) */
+    void setTemperature(double kelvin);
+    void setDrudeTemperature(double kelvin);
+    void setCouplingTime(double picoseconds);
+    void setDrudeCouplingTime(double picoseconds);
+    void setMaxDrudeDistance(double nanometres);
+    void setNumNHChains(int links);
+    void setDrudeStepsPerRealStep(int substeps);
+    void setUseDrudeNHChains(int yes);
+    void setUseCOMTempGroup(int yes);
 
     virtual void step(int steps);
 };

@@ -44,20 +44,28 @@ static vector<double> readArray(const SerializationNode& node) {
     return values;
 }
 
+// The reference's nine properties (serialization/src/DrudeTGNHIntegratorProxy.cpp:43-55): the same names and the same version, so
+// that files of either proxy are read by the other.
+namespace {
+struct RealProperty { const char* name; double (DrudeTGNHIntegrator::*get)() const; };
+struct CountProperty { const char* name; int (DrudeTGNHIntegrator::*get)() const; };
+const RealProperty realProperties[] = {
+    {"stepSize", &DrudeTGNHIntegrator::getStepSize},          {"constraintTolerance", &DrudeTGNHIntegrator::getConstraintTolerance},
+    {"temperature", &DrudeTGNHIntegrator::getTemperature},    {"couplingTime", &DrudeTGNHIntegrator::getCouplingTime},
+    {"drudeTemperature", &DrudeTGNHIntegrator::getDrudeTemperature}, {"drudeCouplingTime", &DrudeTGNHIntegrator::getDrudeCouplingTime}};
+const CountProperty countProperties[] = {
+    {"drudeStepsPerRealStep", &DrudeTGNHIntegrator::getDrudeStepsPerRealStep}, {"numNHChains", &DrudeTGNHIntegrator::getNumNHChains}};
+const int proxyVersion = 1;
+}
+
 void DrudeTGNHIntegratorProxy::serialize(const void* object, SerializationNode& node) const {
-    node.setIntProperty("version", 1);
-    const DrudeTGNHIntegrator& integrator = *reinterpret_cast<const DrudeTGNHIntegrator*>(object);
-    // the reference's nine (serialization/src/DrudeTGNHIntegratorProxy.cpp:43-55): same names, same version -- files of either
-    // proxy are read by the other
-    node.setDoubleProperty("stepSize", integrator.getStepSize());
-    node.setDoubleProperty("constraintTolerance", integrator.getConstraintTolerance());
-    node.setDoubleProperty("temperature", integrator.getTemperature());
-    node.setDoubleProperty("couplingTime", integrator.getCouplingTime());
-    node.setDoubleProperty("drudeTemperature", integrator.getDrudeTemperature());
-    node.setDoubleProperty("drudeCouplingTime", integrator.getDrudeCouplingTime());
-    node.setIntProperty("drudeStepsPerRealStep", integrator.getDrudeStepsPerRealStep());
-    node.setIntProperty("numNHChains", integrator.getNumNHChains());
-    node.setIntProperty("useDrudeNHChains", integrator.getUseDrudeNHChains());
+    const DrudeTGNHIntegrator& integrator = *static_cast<const DrudeTGNHIntegrator*>(object);
+    node.setIntProperty("version", proxyVersion);
+    for (const RealProperty& p : realProperties)
+        node.setDoubleProperty(p.name, (integrator.*p.get)());
+    for (const CountProperty& p : countProperties)
+        node.setIntProperty(p.name, (integrator.*p.get)());
+    node.setIntProperty("useDrudeNHChains", integrator.getUseDrudeNHChains() ? 1 : 0);
     // what that proxy drops (a version-1 reader of the reference ignores properties and children it does not ask for)
     node.setDoubleProperty("maxDrudeDistance", integrator.getMaxDrudeDistance());
     node.setIntProperty("useCOMTempGroup", integrator.getUseCOMTempGroup());
@@ -89,13 +97,15 @@ void DrudeTGNHIntegratorProxy::serialize(const void* object, SerializationNode& 
 }
 
 void* DrudeTGNHIntegratorProxy::deserialize(const SerializationNode& node) const {
-    if (node.getIntProperty("version") != 1)
-        throw OpenMMException("Unsupported version number");
-    DrudeTGNHIntegrator *integrator = new DrudeTGNHIntegrator(node.getDoubleProperty("temperature"),
-            node.getDoubleProperty("couplingTime"), node.getDoubleProperty("drudeTemperature"),
-            node.getDoubleProperty("drudeCouplingTime"), node.getDoubleProperty("stepSize"),
-            node.getIntProperty("drudeStepsPerRealStep"), node.getIntProperty("numNHChains"),
-            node.getBoolProperty("useDrudeNHChains"));
+    const int version = node.getIntProperty("version");
+    if (version != proxyVersion)
+        throw OpenMMException("Unsupported version number");                     // (the reference's message, :58-59)
+    const double temperature = node.getDoubleProperty("temperature"), couplingTime = node.getDoubleProperty("couplingTime");
+    const double drudeTemperature = node.getDoubleProperty("drudeTemperature"), drudeCouplingTime = node.getDoubleProperty("drudeCouplingTime");
+    const int substeps = node.getIntProperty("drudeStepsPerRealStep"), links = node.getIntProperty("numNHChains");
+    const bool drudeChains = node.getBoolProperty("useDrudeNHChains");
+    DrudeTGNHIntegrator* integrator = new DrudeTGNHIntegrator(temperature, couplingTime, drudeTemperature, drudeCouplingTime,
+                                                              node.getDoubleProperty("stepSize"), substeps, links, drudeChains);
     try {
         integrator->setConstraintTolerance(node.getDoubleProperty("constraintTolerance"));
         // files written by the reference's proxy have none of the following: the constructor's defaults stay

@@ -57,6 +57,8 @@ def test_the_proxy_and_the_python_writer_agree_on_the_attributes():
     text = open(os.path.join(GLUE_DIR, "serialization", "src", "DrudeTGNHIntegratorProxy.cpp")).read()
     body = text[text.index("void DrudeTGNHIntegratorProxy::serialize"):text.index("DrudeTGNHThermostatState state;")]
     written = set(re.findall(r'node\.set(?:Int|Double)Property\("(\w+)"', body))
+    tables = text[text.index("const RealProperty realProperties[]"):text.index("const int proxyVersion")]      # (the reference's nine go through two tables)
+    written |= set(re.findall(r'\{"(\w+)", &DrudeTGNHIntegrator::get', tables))
     reference_nine = {"stepSize", "constraintTolerance", "temperature", "couplingTime", "drudeTemperature", "drudeCouplingTime",
                       "drudeStepsPerRealStep", "numNHChains", "useDrudeNHChains"}
     assert written == reference_nine | {"version", "maxDrudeDistance", "useCOMTempGroup"}, written
