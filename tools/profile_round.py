@@ -108,6 +108,8 @@ def main():
     prec = line["config"]["precision"]
     if line["roofline"]["kernel"] in ("step_kernel", "wstep_kernel"):        # (bench.py names the kernel that ran: tgnh_get_resident_kernel)
         dom = f"{line['roofline']['kernel']}<{prec},deferred step>" if variant == "resident" else f"step_kernel<{prec},plain begin half>"
+    elif variant == "plain-gather":                          # the gather path (tgnh_gather.hip): its update kernel, all four launches per step of it together
+        dom = f"gather_update_kernel<{PREC.index(prec)}>"
     else:
         dom = f"tile<{prec},{'prekick+' if variant == 'defer' else ''}rescale+kick+drift>"
     with open(os.path.join(prof, f"{a.tag}_summary.md"), "w") as f:
