@@ -9,7 +9,9 @@
 // load.  Work items are K's (a normal particle, a Drude pair, a residue) but walked in PARTICLE order: thread i looks at particle
 // i, does a normal particle's work, or -- on the Drude particle -- its pair's, or nothing on a parent, so that a wavefront's loads
 // and stores are consecutive wherever the topology is (K's three index lists walk the arrays two or three times, each with
-// holes: twice the memory traffic at 5 M slots).  It exists so that nothing the reference accepts is refused (still refused:
+// holes: twice the memory traffic at 5 M slots), and a thread asks for its own particle's data BEFORE it knows the particle's
+// role (a parent's loads hit its neighbours' lines and are dropped): no load but a pair's second member waits for an index word.
+// It exists so that nothing the reference accepts is refused (still refused:
 // what the reference itself cannot run -- a massless pair member, Ref :132; a molecule without mass under the COM group,
 // K :86-104; dualNH without a pair, Ref :181).
 //
@@ -95,25 +97,26 @@ __global__ __launch_bounds__(BLOCK) void gather_ke_kernel(const GatherArgs a) {
         bool has = false;
         int g = 0;
         double val = 0.0;
-        const int pj = it < a.n ? a.partner[it] : 0;             // partner | is-Drude << 31 ; -1: in no pair
-        if (it < a.n && pj == -1) {                              // K :161-168
-            const int p = (int)it;
-            const mixed4 v = velm[p];
-            if (v.w != 0) {
-                double cx = 0, cy = 0, cz = 0;
-                if (a.use_com) { const mixed4 c = com[a.resid[p]]; cx = c.x; cy = c.y; cz = c.z; }
-                const double rx = v.x - cx, ry = v.y - cy, rz = v.z - cz;
-                val = (rx * rx + ry * ry + rz * rz) * (double)rcp_(v.w);
-                g = a.group[p]; has = true;
+        // the thread's own particle, asked for before its partner word is back (a parent's loads hit the lines of its neighbours;
+        // nothing of them is used): one dependent load level less
+        const bool part = it < a.n;
+        const int p = part ? (int)it : 0;
+        const int pj = part ? a.partner[p] : 0;                  // partner | is-Drude << 31 ; -1: in no pair
+        const mixed4 v1 = velm[p];
+        const int g1 = a.group[p];
+        double c1x = 0, c1y = 0, c1z = 0;
+        if (a.use_com) { const mixed4 c = com[a.resid[p]]; c1x = c.x; c1y = c.y; c1z = c.z; }
+        if (part && pj == -1) {                                  // K :161-168
+            if (v1.w != 0) {
+                const double rx = v1.x - c1x, ry = v1.y - c1y, rz = v1.z - c1z;
+                val = (rx * rx + ry * ry + rz * rz) * (double)rcp_(v1.w);
+                g = g1; has = true;
             }
-        } else if (it < a.n && pj < 0) {                         // K :171-186 (the Drude particle's item)
-            const int2 pr = make_int2((int)it, pj & 0x7fffffff);
-            const mixed4 v1 = velm[pr.x], v2 = velm[pr.y];
-            double c1x = 0, c1y = 0, c1z = 0, c2x = 0, c2y = 0, c2z = 0;
-            if (a.use_com) {
-                const mixed4 c1 = com[a.resid[pr.x]], c2 = com[a.resid[pr.y]];
-                c1x = c1.x; c1y = c1.y; c1z = c1.z; c2x = c2.x; c2y = c2.y; c2z = c2.z;
-            }
+        } else if (part && pj < 0) {                             // K :171-186 (the Drude particle's item)
+            const int q = pj & 0x7fffffff;
+            const mixed4 v2 = velm[q];
+            double c2x = 0, c2y = 0, c2z = 0;
+            if (a.use_com) { const mixed4 c2 = com[a.resid[q]]; c2x = c2.x; c2y = c2.y; c2z = c2.z; }
             const double r1x = v1.x - c1x, r1y = v1.y - c1y, r1z = v1.z - c1z;
             const double r2x = v2.x - c2x, r2y = v2.y - c2y, r2z = v2.z - c2z;
             const double mass1 = rcp_(v1.w), mass2 = rcp_(v2.w);
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(BLOCK) void gather_ke_kernel(const GatherArgs a) {
             const double rlx = r2x - r1x, rly = r2y - r1y, rlz = r2z - r1z;
             val = (cmx * cmx + cmy * cmy + cmz * cmz) * (mass1 + mass2);
             ke_drude += (rlx * rlx + rly * rly + rlz * rlz) * (mass1 * mass2 * invTot);      // reduced mass = 1 / invReducedMass (K :178, :185)
-            g = a.group[pr.x]; has = true;
+            g = g1; has = true;
         } else if (it >= a.n && it < n_items) {                  // K :152-158
             const mixed4 c = com[it - a.n];
             ke_com += ((double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z) / (double)c.w;
@@ -264,11 +267,12 @@ __global__ __launch_bounds__(BLOCK) void gather_update_kernel(const GatherArgs a
     for (long long it = (long long)blockIdx.x * BLOCK + threadIdx.x; it < a.n; it += (long long)gridDim.x * BLOCK) {
         const int i = (int)it;
         const int pj = a.partner[i];                             // partner | is-Drude << 31 ; -1: in no pair
+        P p1, p2;
+        load(i, p1);                                             // the thread's own particle -- one instruction stream for both kinds of item, and a parent's too
+                                                                 // (nothing of it is used: its lines are its neighbours'): no load of it waits for the partner word
         if (pj >= 0) continue;                                   // a parent: its Drude particle's thread does the pair
         const bool pair = pj != -1;
         const int2 pr = make_int2(i, pair ? pj & 0x7fffffff : i);   // (Drude particle, parent): K's particles.x, .y
-        P p1, p2;
-        load(i, p1);                                             // (the thread's own particle: one instruction stream for both kinds of item)
         const mixed s_g = do_scale ? (mixed)a.scale[a.group[i]] : (mixed)1;      // (a pair's group is its Drude particle's, K :270)
         if (!pair) {
             P& p = p1;
