@@ -807,6 +807,7 @@ def main():
         extra["mailbox"] = dict(extra.get("mailbox", {}), **mailbox_info)
     if world == 1 and not args.no_extra:
         for prec, var in ((args.precision, "plain"), (args.precision, "plain-trust"), (args.precision, "plain-resident"), (args.precision, "plain-resident-trust"), (args.precision, "defer"), (args.precision, "resident"),
+                          (args.precision, "plain-gather"),       # the reference's structure on the gather path (TGNH_FLAG_GATHER): what a topology the tiles cannot hold gets
                           ("single", "defer" if system.num_particles / world >= 3_000_000 else args.variant)):
             if (prec, var) == (args.precision, args.variant):
                 continue
